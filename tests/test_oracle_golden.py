@@ -1,0 +1,137 @@
+"""CPU: the oracle (oracle/awr_oracle.py) against the golden vectors that tools/gen_golden.py
+produced by running the real reference in the dev container.  These tests are what pins the
+oracle; the -m gpu tests then compare the HIP path with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import awr_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _hashed(shape, stream, scale):
+    return torch.from_numpy((O._hash_uniform(int(np.prod(shape)), stream, 99) * np.float32(2 * scale)).reshape(shape).copy())
+
+
+def test_manifest_matches_reference_checkpoint_layout(golden_dir):
+    man = json.load(open(os.path.join(golden_dir, "statedict_manifest.json")))
+    for name, (net, J) in {"resnet_18_J14": ("resnet_18", 14), "hourglass_1_J14": ("hourglass_1", 14),
+                           "hourglass_2_J21": ("hourglass_2", 21)}.items():
+        ours = O.manifest_for(net, J)
+        assert [k for k, _, _ in ours] == [e[0] for e in man[name]]
+        assert [list(s) for _, s, _ in ours] == [e[1] for e in man[name]]
+        assert [("int64" if kind == "counter" else "float32") for _, _, kind in ours] == [e[2] for e in man[name]]
+    assert len(man["resnet_18_J14"]) == 142 and len(man["hourglass_1_J14"]) == 409
+
+
+@pytest.mark.parametrize("tag", ["j14_ks04", "j14_ks10", "j21_h256"])
+def test_head_forward_backward(golden_dir, tag):
+    g = _load(golden_dir, "head_%s.npz" % tag)
+    img = torch.from_numpy(g["img"])
+    J, ks = int(g["J"]), float(g["ks"])
+    F = img.shape[-1] // 2
+    off = _hashed((2, 4 * J, F, F), int(g["offset_stream"]), float(g["offset_scale"]))
+    jt = O.offset2joint_softmax(off, img, ks)
+    np.testing.assert_allclose(jt.numpy(), g["jt"], rtol=0, atol=2e-6)
+    gj = torch.from_numpy(g["g_jt"])
+    go = O.head_backward(off, img, ks, gj)
+    scale = float(np.abs(g["g_val"]).max())
+    np.testing.assert_allclose(go.reshape(-1).numpy()[g["g_idx"]], g["g_val"], rtol=0, atol=2e-6 * scale + 1e-9)
+    assert abs(float(go.double().norm()) - float(g["g_l2"])) <= 1e-5 * float(g["g_l2"])
+    # autograd of the restated forward agrees with the closed form the HIP kernel implements
+    off.requires_grad_(True)
+    (ga,) = torch.autograd.grad((O.offset2joint_softmax(off, img, ks) * gj).sum(), off)
+    assert float((ga - go).abs().max()) <= 2e-6 * float(go.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("tag", ["j14_ks04", "j14_ks10", "j21_h256"])
+def test_joint2offset_and_roundtrip(golden_dir, tag):
+    g = _load(golden_dir, "j2o_%s.npz" % tag)
+    img, jt = torch.from_numpy(g["img"]), torch.from_numpy(g["jt"])
+    out = O.joint2offset(jt, img, float(g["ks"]), int(g["F"]))
+    assert list(out.shape) == list(g["shape"])
+    dense = np.zeros(int(np.prod(g["shape"])), np.float32)
+    dense[g["nz_idx"]] = g["nz_val"]
+    np.testing.assert_allclose(out.reshape(-1).numpy(), dense, rtol=0, atol=1e-6)
+    rt = O.offset2joint_softmax(out, img, float(g["ks"]))
+    np.testing.assert_allclose(rt.numpy(), g["roundtrip"], rtol=0, atol=2e-6)
+
+
+def test_huber(golden_dir):
+    g = _load(golden_dir, "huber.npz")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = torch.from_numpy(g["y"])
+    loss = O.huber(x, y)
+    (gx,) = torch.autograd.grad(loss, x)
+    assert abs(float(loss) - float(g["loss"])) < 1e-9
+    np.testing.assert_allclose(gx.numpy(), g["gx"], rtol=0, atol=1e-9)
+    # identities: Huber(delta) == torch huber_loss; grad == clamp(z, +-delta)/N  
+    assert abs(float(loss) - float(torch.nn.functional.huber_loss(x, y, delta=0.01))) < 1e-9
+    z = (x - y).detach()
+    np.testing.assert_allclose(gx.numpy(), (z.clamp(-0.01, 0.01) / z.numel()).numpy(), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1", "hourglass_2"])
+def test_backbone_forward(golden_dir, net):
+    g = _load(golden_dir, "%s_fwd.npz" % net)
+    img = torch.from_numpy(g["img"])
+    J, ks = int(g["J"]), float(g["ks"])
+    man = O.manifest_for(net, J)
+    for mode in ("eval", "train"):
+        sd = O.procedural_state(man, seed=0)
+        with torch.no_grad():
+            outs = O.backbone_forward(net, sd, img, training=(mode == "train"))
+        for s, o in enumerate(outs):
+            ref = g["%s_s%d_val" % (mode, s)]
+            tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(o.reshape(-1).numpy()[g["%s_s%d_idx" % (mode, s)]], ref, rtol=0, atol=tol)
+            assert abs(float(o.double().norm()) - float(g["%s_s%d_l2" % (mode, s)])) <= 1e-5 * float(g["%s_s%d_l2" % (mode, s)])
+            jt = O.offset2joint_softmax(o, img, ks)
+            np.testing.assert_allclose(jt.numpy(), g["%s_s%d_jt" % (mode, s)], rtol=0, atol=1e-5)
+        if mode == "train":
+            for i, k in enumerate(g["bn_keys"]):
+                np.testing.assert_allclose(sd[str(k)].numpy(), g["bn_%d" % i], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
+def test_train_step(golden_dir, net):
+    g = _load(golden_dir, "%s_train.npz" % net)
+    img, jt_gt = torch.from_numpy(g["img"]), torch.from_numpy(g["jt_gt"])
+    J, ks = int(g["J"]), float(g["ks"])
+    man = O.manifest_for(net, J)
+    pkeys = [str(k) for k in g["pkeys"]]
+    assert pkeys == O.params_of(None, man)
+    smp = [int(np.minimum(((O._hash_uniform(1, 1000 + 40 + i, 7).astype(np.float64) + 0.5) * int(np.prod(s))).astype(np.int64),
+                          int(np.prod(s)) - 1)[0]) for i, (k, s) in enumerate((k, s) for k, s, kd in man if kd in O.PARAM_KINDS)]
+    for tag, (cw, dw) in {"c0": (0.0, 1.0), "c1": (1.0, 1.0)}.items():
+        sd = O.procedural_state(man, seed=1)
+        ost = {"step": 0, "m": {}, "v": {}}
+        loss, lc, ld, grads, jt = O.train_step(net, sd, ost, img, jt_gt, ks, cw, dw)
+        assert abs(float(loss) - float(g[tag + "_loss0"])) <= 1e-6 * max(1.0, abs(float(loss)))
+        np.testing.assert_allclose(jt.numpy(), g[tag + "_jt0"], rtol=0, atol=1e-5)
+        assert sorted(k for k, v in grads.items() if v is None) == sorted(str(k) for k in g["nograd"])
+        for i, k in enumerate(pkeys):
+            if grads[k] is None:
+                assert g[tag + "_grad_l2"][i] == -1.0
+                continue
+            ref = float(g[tag + "_grad_l2"][i])
+            assert abs(float(grads[k].double().norm()) - ref) <= 1e-4 * ref + 1e-12, k
+        np.testing.assert_allclose(np.array([float(sd[k].reshape(-1)[smp[i]]) for i, k in enumerate(pkeys)], np.float32),
+                                   g[tag + "_param_smp1"], rtol=0, atol=2e-6)
+        loss1 = O.train_step(net, sd, ost, img, jt_gt, ks, cw, dw)[0]
+        assert abs(float(loss1) - float(g[tag + "_loss1"])) <= 1e-5 * max(1.0, abs(float(loss1)))
+
+
+def test_evaluator(golden_dir):
+    g = _load(golden_dir, "eval_feed.npz")
+    errs, uvd = O.joint_errors_mm(g["jt_uvd"], g["jt_xyz_gt"], g["center"], g["M"], g["cube"])
+    mpe, med, auc, pck, _ = O.measures(errs)
+    assert abs(mpe - float(g["mpe"])) < 1e-4 and abs(auc - float(g["auc"])) < 1e-6 and abs(med - float(g["med"])) < 1e-4
+    np.testing.assert_allclose(pck, g["pck"], atol=1e-9)
+    np.testing.assert_allclose(uvd, g["uvd"], atol=1e-3)
