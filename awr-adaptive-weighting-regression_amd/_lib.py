@@ -1,0 +1,134 @@
+"""ctypes binding of libawr_hip.so (the C ABI declared in include/awr_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises at import.
+Set AWR_AUTO_BUILD=1 to let it invoke hipcc once (the same thing __graft_entry__.build() does).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+c_f32p = C.c_void_p      # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class AwrError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_build.LIB):
+        if os.environ.get("AWR_AUTO_BUILD", "0") == "1":
+            _build.build_lib(verbose=False)
+        else:
+            raise AwrError("libawr_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or set AWR_AUTO_BUILD=1. There is no CPU/PyTorch fallback for the AWR hot path." % _build.LIB)
+    return C.CDLL(_build.LIB)
+
+
+lib = _load()
+
+
+class Phase(C.Structure):
+    _fields_ = [("py", C.c_int), ("px", C.c_int), ("ntaps", C.c_int),
+                ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16), ("wt", C.c_int8 * 16)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p),
+                ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("bias", C.c_void_p),
+                ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("res", C.c_void_p), ("stats", C.c_void_p),
+                ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
+                ("Hq", C.c_int), ("Wq", C.c_int),
+                ("Hout", C.c_int), ("Wout", C.c_int), ("N", C.c_int),
+                ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
+                ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int),
+                ("ph", Phase * 4)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("D", C.c_void_p), ("G", C.c_void_p), ("R", C.c_void_p),
+                ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
+                ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
+                ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]
+
+
+_I, _F, _L, _P, _D = C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_double
+_SIGS = {
+    "awr_version": ([], C.c_int),
+    "awr_last_error": ([], C.c_char_p),
+    "awr_device_info": ([C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I], C.c_int),
+    "awr_head_forward": ([_P, _P, _I, _I, _I, _I, _F, _P, _P, _P], C.c_int),
+    "awr_head_backward": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P], C.c_int),
+    "awr_joint2offset": ([_P, _P, _I, _I, _I, _I, _F, _P, _P], C.c_int),
+    "awr_huber": ([_P, _P, _L, _F, _F, _P, _P, _I, _P], C.c_int),
+    "awr_dense_loss": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _I, _P], C.c_int),
+    "awr_zero_f64": ([_P, _L, _P], C.c_int),
+    "awr_loss_finalize": ([_P, _I, _P, _P], C.c_int),
+    "awr_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P], C.c_int),
+    "awr_sgd_step": ([_P, _P, _P, _L, _F, _F, _F, _L, _F, _P], C.c_int),
+    "awr_pack_weight": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "awr_unpack_wgrad": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
+    "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
+    "awr_debug_force_tile": ([_I, _I], C.c_int),
+    "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P], C.c_int),
+    "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),
+    "awr_channel_stats": ([_P, _L, _I, _P, _P], C.c_int),
+    "awr_bn_apply": ([_P, _P, _P, _P, _I, _P, _L, _I, _P], C.c_int),
+    "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _L, _I, _P, _P], C.c_int),
+    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
+    "awr_relu_bwd": ([_P, _P, _P, _L, _P], C.c_int),
+    "awr_add": ([_P, _P, _P, _L, _P], C.c_int),
+    "awr_bias_grad": ([_P, _L, _I, _P, _I, _P], C.c_int),
+    "awr_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "awr_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_upsample2_add": ([_P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "awr_upsample2_bwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_nhwc_to_nchw": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "awr_nchw_to_nhwc": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+}
+
+EXPORTS = tuple(_SIGS)
+MISSING = []                           # header/library mismatch; tests/test_abi.py requires this to be empty
+for _name, (_args, _ret) in _SIGS.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _fn.argtypes = _args
+    _fn.restype = _ret
+
+
+def last_error():
+    return lib.awr_last_error().decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AwrError("%s failed (%d): %s" % (what or "libawr_hip call", rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/other CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AwrError("AWR HIP path needs CUDA(HIP) tensors; got a %s tensor -- there is no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise AwrError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    if name in MISSING:
+        raise AwrError("libawr_hip.so does not export %s -- rebuild it (__graft_entry__.build())" % name)
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,68 @@
+"""Build libawr_hip.so with hipcc for gfx950 (in-tree, so the .so travels with the repo snapshot).
+
+    python -m awr_amd.build            # or: __graft_entry__.build()
+
+There is deliberately no fallback: if the library is missing and cannot be built, importing the
+product path raises.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libawr_hip.so")
+ARCH = "gfx950"
+
+# per-source extra flags; the head/GT-map kernels must not contract a*b+c (see awr_head.hip)
+SOURCES = {
+    "awr_head.hip": ["-ffp-contract=off"],
+    "awr_elem.hip": [],
+    "awr_conv.hip": [],
+}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: cannot build libawr_hip.so")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "awr_hip.h"))
+    objs = []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics",
+                   "-c", path, "-o", obj] + extra
+            if verbose:
+                print("[awr build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[awr build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

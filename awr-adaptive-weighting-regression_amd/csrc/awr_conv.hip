@@ -1,0 +1,381 @@
+// FP32-MFMA implicit-GEMM convolution family for gfx950 (CDNA4).
+//
+// One gather-GEMM kernel covers conv forward (any k, stride 1/2), transposed-conv forward
+// (4 sub-pixel phases), and both kinds of data gradient; a second kernel covers the weight
+// gradients (split-K over pixels).  Design points (see DESIGN.md "conv kernels"):
+//   * exact-f32 v_mfma_f32_32x32x2_f32 (157.3 TF peak; bit-equal to an fmaf chain) -- the parity
+//     path of north_star (1e-3 mm) cannot use bf16.
+//   * 64-lane wavefronts: a workgroup is 4 waves in a 2x2 grid, each wave owns TMxTN 32x32
+//     accumulator tiles (TM,TN in {1,2}) -> 64..128-wide tiles chosen per layer so that small
+//     spatial layers still fill 256 CUs.
+//   * operands are staged global -> registers -> LDS as K-contiguous rows (NHWC makes every
+//     (pixel, tap) a contiguous Cin run; packed weights are [n][tap][Cin]); rows are padded to
+//     36 floats so the ds_read_b128 fragment reads are bank-conflict free.  Each lane reads a
+//     float4 = 4 consecutive k for its half-wave, feeding 4 back-to-back MFMAs.
+//   * the next K-slice's global loads are issued before the current slice's MFMAs, so HBM/L2
+//     latency hides under the 64-cycle MFMAs.
+//   * fused prologue (per-input-channel affine + ReLU = the previous BatchNorm) and epilogue
+//     (bias, folded BN, residual add, ReLU, per-channel sum / sum-of-squares for the next
+//     BatchNorm) remove whole HBM passes.
+//   * XCD-aware workgroup remap: consecutive tiles of one row-panel land on the same XCD's L2.
+#include "awr_common.h"
+
+namespace awr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;        // K-slice (floats)
+constexpr int LDK = BK + 4;   // padded LDS row (floats) : 144 B, conflict-free for ds_read_b128
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    // bijective "each XCD gets a contiguous chunk" remap (hardware places block b on XCD b % 8)
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+__device__ __forceinline__ float4 affine_relu(float4 v, float4 sc, float4 sh, int relu) {
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[pix(m), n] = sum_{tap, c} in[gather(m, tap), c] * w[n][wt(tap)][c]
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+
+    const awr_phase& ph = a.ph[blockIdx.y];
+    const int M = a.B * a.Hq * a.Wq;
+    const int tilesN = (a.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
+    const int r0 = tid >> 3;            // first row it stages (then +32, +64, ...)
+
+    // decode the A rows this thread stages (fixed for the whole K loop)
+    int a_iy[RA], a_ix[RA];
+    int64_t a_img[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        if (m < M) {
+            const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+            a_iy[i] = qy * a.si;
+            a_ix[i] = qx * a.si;
+            a_img[i] = (int64_t)b * a.Hin * a.Win;
+        } else {
+            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
+            a_ix[i] = 0;
+            a_img[i] = 0;
+        }
+    }
+    const float* wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wrow[i] = a.w + (int64_t)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cslices = a.Cin / BK;
+    const int ksteps = ph.ntaps * cslices;
+    float4 ra[RA], rb[RB];
+
+    auto load_slice = [&](int tap, int c0) {
+        const int dy = ph.dy[tap], dx = ph.dx[tap], wt = ph.wt[tap];
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (a.in_scale) {
+            sc = ld4(a.in_scale + c0 + kc);
+            sh = ld4(a.in_shift + c0 + kc);
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (ok) {
+                v = ld4(a.in + ((a_img[i] + (int64_t)iy * a.Win + ix) * a.Cin + c0 + kc));
+                if (a.in_scale) v = affine_relu(v, sc, sh, a.relu_in);
+                else if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = ld4(wrow[i] + (int64_t)wt * a.Cin + c0);
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) st4(&As[(r0 + 32 * i) * LDK + kc], ra[i]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) st4(&Bs[(r0 + 32 * i) * LDK + kc], rb[i]);
+    };
+
+    int tap = 0, c0 = 0;
+    load_slice(0, 0);
+    store_slice();
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const float* a_frag = &As[(wm * 32 * TM + l31) * LDK + 4 * half];
+    const float* b_frag = &Bs[(wn * 32 * TN + l31) * LDK + 4 * half];
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        if (more) {
+            c0 += BK;
+            if (c0 == a.Cin) { c0 = 0; ++tap; }
+            load_slice(tap, c0);   // global loads in flight while the MFMAs below run
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_slice();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------
+    const bool direct = (a.so == 1);   // out pixel index == m
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = tile_n * BN + wn * 32 * TN + j * 32 + l31;
+        const bool nok = n < a.N;
+        const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+        const float osc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
+        const float osh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tile_m * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M && nok) {
+                    int64_t opix = m;
+                    if (!direct) {
+                        const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+                        opix = ((int64_t)b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
+                    }
+                    float v = acc[i][j][r] + bias;
+                    if (a.out_scale) v = v * osc + osh;
+                    if (a.res) v += a.res[opix * a.N + n];
+                    s1 += v;
+                    s2 += v * v;
+                    if (a.relu_out) v = fmaxf(v, 0.f);
+                    a.out[opix * a.N + n] = v;
+                }
+            }
+        }
+        if (a.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0 && nok) {
+                atomicAdd(a.stats + n, (double)s1);
+                atomicAdd(a.stats + a.N + n, (double)s2);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// R[cd][t][cg] += sum_{m in K-chunk} D[m][cd] * G[gather(m,t)][cg]      (split-K over pixels)
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LDM = BM + 4, LDN = BN + 4;
+    constexpr int FM = BM / 4, FN = BN / 4;          // float4 per pixel row
+    constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows staged per pass
+    constexpr int RA = BK / PM, RB = BK / PN;
+    __shared__ __attribute__((aligned(16))) float Ds[BK * LDM];
+    __shared__ __attribute__((aligned(16))) float Gs[BK * LDN];
+
+    const int M = a.B * a.Hd * a.Wd;
+    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
+    int wg = blockIdx.x;
+    const int tcg = wg % tiles_cg; wg /= tiles_cg;
+    const int tcd = wg % tiles_cd; wg /= tiles_cd;
+    const int t = wg;                                 // tap
+    const int dy = a.dy[t], dx = a.dx[t];
+    const int m_begin = blockIdx.y * chunk;
+    int m_end = m_begin + chunk;
+    if (m_end > M) m_end = M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int da_c = (tid % FM) * 4, da_r = tid / FM;   // D slice: channel offset, first pixel row
+    const int ga_c = (tid % FN) * 4, ga_r = tid / FN;
+    const bool d_cok = tcd * BM + da_c < a.Cd, g_cok = tcg * BN + ga_c < a.Cg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rd[RA], rg[RB];
+    auto load_slice = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + da_r + PM * i;
+            rd[i] = (m < m_end && d_cok) ? ld4(a.D + (int64_t)m * a.Cd + tcd * BM + da_c) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int m = m0 + ga_r + PN * i;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (m < m_end && g_cok) {
+                const int x = m % a.Wd, tt = m / a.Wd, y = tt % a.Hd, b = tt / a.Hd;
+                const int gy = y * a.sg + dy, gx = x * a.sg + dx;
+                if (gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg)
+                    v = ld4(a.G + (((int64_t)b * a.Hg + gy) * a.Wg + gx) * a.Cg + tcg * BN + ga_c);
+            }
+            rg[i] = v;
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) st4(&Ds[(da_r + PM * i) * LDM + da_c], rd[i]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) st4(&Gs[(ga_r + PN * i) * LDN + ga_c], rg[i]);
+    };
+
+    load_slice(m_begin);
+    store_slice();
+    __syncthreads();
+    const float* a_frag = &Ds[half * LDM + wm * 32 * TM + l31];   // A[i = cd][k = pixel]: lane reads Ds[k][i]
+    const float* b_frag = &Gs[half * LDN + wn * 32 * TN + l31];
+
+    for (int m0 = m_begin; m0 < m_end; m0 += BK) {
+        const bool more = m0 + BK < m_end;
+        if (more) load_slice(m0 + BK);
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = a_frag[2 * kp * LDM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = b_frag[2 * kp * LDN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_slice();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + t) * a.ld + cg, acc[i][j][r]);
+            }
+    }
+}
+
+}  // namespace awr
+
+using namespace awr;
+
+static int g_force_tm = 0, g_force_tn = 0;
+
+extern "C" {
+
+int awr_debug_force_tile(int tm, int tn) {
+    AWR_REQUIRE((tm == 0 && tn == 0) || ((tm == 1 || tm == 2) && (tn == 1 || tn == 2)), "force_tile: tm,tn must be 0,0 or in {1,2}");
+    g_force_tm = tm;
+    g_force_tn = tn;
+    return AWR_OK;
+}
+
+int awr_conv_gemm(const awr_conv_args* a, void* stream) {
+    AWR_REQUIRE(a && a->in && a->w && a->out, "conv_gemm: null pointer");
+    AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
+    AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
+    AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
+    AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
+    AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
+    for (int p = 0; p < a->nphase; ++p) {
+        AWR_REQUIRE(a->ph[p].ntaps >= 1 && a->ph[p].ntaps <= 16, "conv_gemm: phase %d has %d taps", p, a->ph[p].ntaps);
+        for (int t = 0; t < a->ph[p].ntaps; ++t) AWR_REQUIRE(a->ph[p].wt[t] >= 0 && a->ph[p].wt[t] < a->T, "conv_gemm: tap index out of range");
+    }
+    const int64_t M = (int64_t)a->B * a->Hq * a->Wq;
+    AWR_REQUIRE(M < (1LL << 31), "conv_gemm: too many output pixels");
+    // tile choice: widest tile that still gives >= 1.5 workgroups per CU (256 CUs); N <= 64 never needs BN = 128
+    const int tn_max = a->N > 64 ? 2 : 1;
+    int TM = 2, TN = tn_max;
+    auto blocks = [&](int tm, int tn) { return ((M + 64 * tm - 1) / (64 * tm)) * ((a->N + 64 * tn - 1) / (64 * tn)) * a->nphase; };
+    if (blocks(TM, TN) < 384 && TN == 2) TN = 1;
+    if (blocks(TM, TN) < 384) { TM = 1; TN = tn_max; }
+    if (blocks(TM, TN) < 384 && TN == 2) TN = 1;
+    if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
+    const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
+    hipStream_t st = as_stream(stream);
+    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, dim3(256), 0, st, *a);
+    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), grid, dim3(256), 0, st, *a);
+    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), grid, dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, dim3(256), 0, st, *a);
+    return check_launch("conv_gemm_kernel");
+}
+
+int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
+    AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
+    AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
+    AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
+    const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
+    AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
+    int TM = a->Cd > 64 ? 2 : 1, TN = a->Cg > 64 ? 2 : 1;
+    if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
+    const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
+    int64_t nsplit = (1536 + tiles - 1) / tiles;
+    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 8 K-slices per workgroup
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int64_t chunk = (M + nsplit - 1) / nsplit;
+    chunk = (chunk + BK - 1) / BK * BK;
+    nsplit = (M + chunk - 1) / chunk;
+    const dim3 grid((unsigned)tiles, (unsigned)nsplit);
+    hipStream_t st = as_stream(stream);
+    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, *a, (int)chunk);
+    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, *a, (int)chunk);
+    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, *a, (int)chunk);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, *a, (int)chunk);
+    return check_launch("conv_wgrad_kernel");
+}
+
+}  // extern "C"

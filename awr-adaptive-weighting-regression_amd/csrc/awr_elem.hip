@@ -1,0 +1,542 @@
+// Element-wise / reduction glue of the backbone (NHWC fp32): weight repack, stem im2col, BatchNorm
+// pieces, pooling, up-sampling and the NCHW<->NHWC bridges at the reference boundary.  All kernels
+// are HBM-bound streaming kernels: 16-byte accesses, channel index derived from the flat float4 index
+// (C % 4 == 0 everywhere), fp64 only for the cross-workgroup statistic accumulators.
+#include <math.h>
+
+#include "awr_common.h"
+
+namespace awr {
+
+// ------------------------------------------------------------------------------------------
+// weight repack
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int d0, int d1, int T, int transpose, int n_pad,
+                                                          int ld, float* __restrict__ out) {
+    const int64_t total = (int64_t)n_pad * T * ld;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % ld);
+    const int t = (int)((idx / ld) % T);
+    const int n = (int)(idx / ((int64_t)ld * T));
+    float v = 0.f;
+    if (!transpose) {
+        if (n < d0 && c < d1) v = w[((int64_t)n * d1 + c) * T + t];
+    } else {
+        if (n < d1 && c < d0) v = w[((int64_t)c * d1 + n) * T + t];
+    }
+    out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ packed, int d0, int d1, int T, int ld,
+                                                           float* __restrict__ grad, int accumulate) {
+    const int64_t total = (int64_t)d0 * d1 * T;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int t = (int)(idx % T);
+    const int b = (int)((idx / T) % d1);
+    const int a = (int)(idx / ((int64_t)T * d1));
+    const float v = packed[((int64_t)a * T + t) * ld + b];
+    grad[idx] = accumulate ? grad[idx] + v : v;
+}
+
+// cols[b][y][x][k] = img[b][y+k/5-2][x+k%5-2] for k < 25, 0 for k in [25,32) and outside the image
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, int B, int H, int W, float* __restrict__ cols) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 = 4 taps
+    const int64_t total = (int64_t)B * H * W * 8;
+    if (idx >= total) return;
+    const int k0 = (int)(idx & 7) * 4;
+    const int64_t pix = idx >> 3;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + i;
+        const int yy = y + k / 5 - 2, xx = x + k % 5 - 2;
+        v[i] = (k < 25 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(b * H + yy) * W + xx] : 0.f;
+    }
+    st4(cols + idx * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ invstd_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / count;
+    double var = stats[C + c] / count - mean * mean;  // biased variance normalises the batch
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (mean_o) mean_o[c] = (float)mean;
+    if (invstd_o) invstd_o[c] = invstd;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;  // running var is unbiased
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+    stats[c] = 0.0;
+    stats[C + c] = 0.0;
+}
+
+__global__ void bn_fold_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
+                                    const float* __restrict__ rvar, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// Column (channel) reductions over an (npix, C) matrix.  256 threads = rpp row-groups x C/4 float4
+// columns; each workgroup walks a contiguous slab of rows; per-thread fp32 partials are merged
+// through LDS and leave the workgroup as one fp64 atomic per channel per statistic.
+template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2: sum x only (bias grad, fp32 out)
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ y,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int64_t npix,
+                                                         int C, int rows_per_block, double* __restrict__ out64, float* __restrict__ out32) {
+    const int C4 = C >> 2;
+    const int rpp = 256 / C4;  // row groups per pass
+    const int cg = threadIdx.x % C4, rg = threadIdx.x / C4;
+    const bool active = rg < rpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > npix) r1 = npix;
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+    if (MODE == 1 && active) {
+        mu = ld4(mean + cg * 4);
+        is = ld4(invstd + cg * 4);
+    }
+    if (active) {
+        for (int64_t r = r0 + rg; r < r1; r += rpp) {
+            const int64_t o = r * C + cg * 4;
+            float4 v = ld4(x + o);
+            if (MODE == 0) {
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            } else if (MODE == 1) {
+                if (act) {
+                    const float4 a = ld4(act + o);
+                    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                }
+                const float4 yy = ld4(y + o);
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * ((yy.x - mu.x) * is.x); s2.y += v.y * ((yy.y - mu.y) * is.y);
+                s2.z += v.z * ((yy.z - mu.z) * is.z); s2.w += v.w * ((yy.w - mu.w) * is.w);
+            } else {
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            }
+        }
+    }
+    __shared__ float4 sh1[256], sh2[256];
+    sh1[threadIdx.x] = s1;
+    sh2[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        for (int g = 0; g < rpp; ++g) {
+            const float4 p = sh1[g * C4 + threadIdx.x], q = sh2[g * C4 + threadIdx.x];
+            a[0] += p.x; a[1] += p.y; a[2] += p.z; a[3] += p.w;
+            b[0] += q.x; b[1] += q.y; b[2] += q.z; b[3] += q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = threadIdx.x * 4 + k;
+            if (MODE == 2) {
+                atomicAdd(out32 + c, (float)a[k]);
+            } else {
+                atomicAdd(out64 + c, a[k]);
+                atomicAdd(out64 + C + c, b[k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int relu, float* __restrict__ out, int64_t n4, int C4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int cg = (int)(i % C4);
+    const float4 v = ld4(x + i * 4), sc = ld4(scale + cg * 4), sh = ld4(shift + cg * 4);
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (res) {
+        const float4 r = ld4(res + i * 4);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    st4(out + i * 4, o);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act, const float* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums, double inv_count,
+                                                           int64_t n4, int C, float* dy, const float* dy_add, float* __restrict__ g_out,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int C4 = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) {  // parameter gradients: dgamma = sum g*xhat, dbeta = sum g
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+        }
+    }
+    if (i >= n4) return;
+    const int cg = (int)(i % C4);
+    float4 g = ld4(dout + i * 4);
+    if (act) {
+        const float4 a = ld4(act + i * 4);
+        g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+    }
+    if (g_out) st4(g_out + i * 4, g);
+    const float4 yy = ld4(y + i * 4), mu = ld4(mean + cg * 4), is = ld4(invstd + cg * 4);
+    const float4 ga = gamma ? ld4(gamma + cg * 4) : make_float4(1, 1, 1, 1);
+    float k1[4], k2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        k1[k] = (float)(sums[cg * 4 + k] * inv_count);
+        k2[k] = (float)(sums[C + cg * 4 + k] * inv_count);
+    }
+    float4 o;
+    o.x = ga.x * is.x * (g.x - k1[0] - (yy.x - mu.x) * is.x * k2[0]);
+    o.y = ga.y * is.y * (g.y - k1[1] - (yy.y - mu.y) * is.y * k2[1]);
+    o.z = ga.z * is.z * (g.z - k1[2] - (yy.z - mu.z) * is.z * k2[2]);
+    o.w = ga.w * is.w * (g.w - k1[3] - (yy.w - mu.w) * is.w * k2[3]);
+    if (dy_add) {
+        const float4 e = ld4(dy_add + i * 4);
+        o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+    }
+    st4(dy + i * 4, o);
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act, float* __restrict__ g, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = ld4(dout + i * 4);
+    const float4 a = ld4(act + i * 4);
+    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    st4(g + i * 4, v);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = ld4(a + i * 4), y = ld4(b + i * 4);
+    st4(out + i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+}
+
+// ------------------------------------------------------------------------------------------
+// pooling / up-sampling (NHWC, one thread = one pixel x 4 channels)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int k, int s, int p, int Ho,
+                                                          int Wo, float* __restrict__ out, uint8_t* __restrict__ arg) {
+    const int C4 = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    if (i >= total) return;
+    const int cg = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+    const int64_t b = pix / ((int64_t)Wo * Ho);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int a[4] = {0, 0, 0, 0};
+    for (int ky = 0; ky < k; ++ky) {
+        const int yy = oy * s - p + ky;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int xx = ox * s - p + kx;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v = ld4(x + ((b * H + yy) * W + xx) * C + cg * 4);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (vv[c] > m[c]) {  // first maximum wins, like ATen's max_pool2d
+                    m[c] = vv[c];
+                    a[c] = ky * k + kx;
+                }
+        }
+    }
+    st4(out + i * 4, make_float4(m[0], m[1], m[2], m[3]));
+    if (arg) *reinterpret_cast<uchar4*>(arg + i * 4) = make_uchar4((uint8_t)a[0], (uint8_t)a[1], (uint8_t)a[2], (uint8_t)a[3]);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg, int B, int H, int W,
+                                                          int C, int k, int s, int p, int Ho, int Wo, float* __restrict__ dx, int accumulate) {
+    const int C4 = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * H * W * C4;
+    if (i >= total) return;
+    const int cg = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float acc[4] = {0, 0, 0, 0};
+    // windows (oy,ox) that contain (y,x):  oy*s - p <= y <= oy*s - p + k - 1
+    int oy0 = (y + p - k + 1 + s - 1) / s;  // ceil((y+p-k+1)/s) for non-negative numerators
+    if (y + p - k + 1 < 0) oy0 = 0;
+    int ox0 = (x + p - k + 1 + s - 1) / s;
+    if (x + p - k + 1 < 0) ox0 = 0;
+    const int oy1 = min((y + p) / s, Ho - 1), ox1 = min((x + p) / s, Wo - 1);
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int local = (y - (oy * s - p)) * k + (x - (ox * s - p));
+            const int64_t o = (((b * Ho + oy) * Wo + ox) * C4 + cg) * 4;
+            const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
+            const float4 d = ld4(dout + o);
+            if (a.x == local) acc[0] += d.x;
+            if (a.y == local) acc[1] += d.y;
+            if (a.z == local) acc[2] += d.z;
+            if (a.w == local) acc[3] += d.w;
+        }
+    if (accumulate) {
+        const float4 e = ld4(dx + i * 4);
+        acc[0] += e.x; acc[1] += e.y; acc[2] += e.z; acc[3] += e.w;
+    }
+    st4(dx + i * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
+__global__ __launch_bounds__(256) void upsample2_add_kernel(const float* __restrict__ up1, const float* __restrict__ low, int B, int Hl, int Wl, int C,
+                                                            float* __restrict__ out) {
+    const int C4 = C >> 2;
+    const int H = Hl * 2, W = Wl * 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * H * W * C4;
+    if (i >= total) return;
+    const int cg = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    const float4 u = ld4(up1 + i * 4), l = ld4(low + (((b * Hl + (y >> 1)) * Wl + (x >> 1)) * C4 + cg) * 4);
+    st4(out + i * 4, make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w));
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dout, int B, int Hl, int Wl, int C, float* __restrict__ dlow,
+                                                            int accumulate) {
+    const int C4 = C >> 2;
+    const int H = Hl * 2, W = Wl * 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * Hl * Wl * C4;
+    if (i >= total) return;
+    const int cg = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int x = (int)(pix % Wl), y = (int)((pix / Wl) % Hl);
+    const int64_t b = pix / ((int64_t)Wl * Hl);
+    float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const float4 d = ld4(dout + (((b * H + 2 * y + dy) * W + 2 * x + dx) * C4 + cg) * 4);
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        }
+    if (accumulate) {
+        const float4 e = ld4(dlow + i * 4);
+        s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
+    }
+    st4(dlow + i * 4, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// NHWC(Cp) <-> NCHW(C) 32x32 LDS-tiled transposes (per image: a (P, Cp) <-> (C, P) matrix)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int P, int Cp, int C, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < P && c < Cp) ? in[((int64_t)b * P + p) * Cp + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < P) out[((int64_t)b * C + c) * P + p] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int P, int Cp, int C, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < P) ? in[((int64_t)b * C + c) * P + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < P && c < Cp) out[((int64_t)b * P + p) * Cp + c] = tile[tx][r];
+    }
+}
+
+static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd, int64_t npix,
+                             int C, double* out64, float* out32, hipStream_t st) {
+    AWR_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "channel reduction: C=%d must be a multiple of 4 in [4,1024]", C);
+    AWR_REQUIRE(npix > 0, "channel reduction: empty tensor");
+    const int rpp = 256 / (C / 4);
+    int64_t rows = (npix + 1023) / 1024;  // <= 1024 workgroups
+    if (rows < 64) rows = 64;
+    rows = (rows + rpp - 1) / rpp * rpp;
+    const unsigned grid = (unsigned)((npix + rows - 1) / rows);
+    if (mode == 0)
+        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+    else if (mode == 1)
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+    else
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+    return check_launch("col_reduce_kernel");
+}
+
+}  // namespace awr
+
+using namespace awr;
+
+extern "C" {
+
+int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_pad, int ld, float* packed, void* stream) {
+    AWR_REQUIRE(w && packed && d0 > 0 && d1 > 0 && T > 0, "pack_weight: bad arguments");
+    const int rows = transpose ? d1 : d0, inner = transpose ? d0 : d1;
+    AWR_REQUIRE(n_pad >= rows && ld >= inner, "pack_weight: n_pad=%d < %d or ld=%d < %d", n_pad, rows, ld, inner);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(nblk((int64_t)n_pad * T * ld)), dim3(256), 0, as_stream(stream), w, d0, d1, T, transpose, n_pad,
+                       ld, packed);
+    return check_launch("pack_weight_kernel");
+}
+
+int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* grad, int accumulate, void* stream) {
+    AWR_REQUIRE(packed && grad && d0 > 0 && d1 > 0 && T > 0 && ld >= d1, "unpack_wgrad: bad arguments");
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblk((int64_t)d0 * d1 * T)), dim3(256), 0, as_stream(stream), packed, d0, d1, T, ld, grad,
+                       accumulate);
+    return check_launch("unpack_wgrad_kernel");
+}
+
+int awr_stem_im2col(const float* img, int B, int H, int W, float* cols, void* stream) {
+    AWR_REQUIRE(img && cols && B > 0 && H > 0 && W > 0, "stem_im2col: bad arguments");
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(nblk((int64_t)B * H * W * 8)), dim3(256), 0, as_stream(stream), img, B, H, W, cols);
+    return check_launch("stem_im2col_kernel");
+}
+
+int awr_bn_finalize(double* stats, int C, int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    AWR_REQUIRE(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, C, (double)count, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    return check_launch("bn_finalize_kernel");
+}
+
+int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                     float* scale, float* shift, void* stream) {
+    AWR_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_fold_eval: bad arguments");
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), C, gamma, beta, running_mean, running_var,
+                       eps, scale, shift);
+    return check_launch("bn_fold_eval_kernel");
+}
+
+int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream) {
+    AWR_REQUIRE(x && stats, "channel_stats: null pointer");
+    return col_reduce_launch(0, x, nullptr, nullptr, nullptr, nullptr, npix, C, stats, nullptr, as_stream(stream));
+}
+
+int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu, float* out, int64_t npix, int C,
+                 void* stream) {
+    AWR_REQUIRE(x && scale && shift && out && npix > 0 && C % 4 == 0, "bn_apply: bad arguments");
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), x, scale, shift, res, relu, out, n4, C / 4);
+    return check_launch("bn_apply_kernel");
+}
+
+int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, int64_t npix, int C,
+                      double* sums, void* stream) {
+    AWR_REQUIRE(dout && y && mean && invstd && sums, "bn_bwd_reduce: null pointer");
+    return col_reduce_launch(1, dout, act, y, mean, invstd, npix, C, sums, nullptr, as_stream(stream));
+}
+
+int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* gamma,
+                     double* sums, int64_t npix, int C, float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate,
+                     void* stream) {
+    AWR_REQUIRE(dout && y && mean && invstd && sums && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, gamma, sums,
+                       1.0 / (double)npix, n4, C, dy, dy_add, g_out, dgamma, dbeta, accumulate);
+    if (int e = check_launch("bn_bwd_apply_kernel")) return e;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, as_stream(stream)) != hipSuccess) {
+        set_error("bn_bwd_apply: hipMemsetAsync failed");
+        return AWR_ERR_HIP;
+    }
+    return AWR_OK;
+}
+
+int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream) {
+    AWR_REQUIRE(dout && act && g && n > 0 && n % 4 == 0, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(n / 4)), dim3(256), 0, as_stream(stream), dout, act, g, n / 4);
+    return check_launch("relu_bwd_kernel");
+}
+
+int awr_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    AWR_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "add: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 4)), dim3(256), 0, as_stream(stream), a, b, out, n / 4);
+    return check_launch("add_kernel");
+}
+
+int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulate, void* stream) {
+    AWR_REQUIRE(dy && db, "bias_grad: null pointer");
+    if (!accumulate && hipMemsetAsync(db, 0, sizeof(float) * C, as_stream(stream)) != hipSuccess) {
+        set_error("bias_grad: hipMemsetAsync failed");
+        return AWR_ERR_HIP;
+    }
+    return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, as_stream(stream));
+}
+
+int awr_maxpool_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* out, uint8_t* argmax, void* stream) {
+    AWR_REQUIRE(x && out && B > 0 && C % 4 == 0 && k >= 1 && k <= 15 && s >= 1 && p >= 0 && p < k, "maxpool_fwd: bad arguments");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream), x, B, H, W, C, k, s, p,
+                       Ho, Wo, out, argmax);
+    return check_launch("maxpool_fwd_kernel");
+}
+
+int awr_maxpool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k, int s, int p, float* dx, int accumulate,
+                    void* stream) {
+    AWR_REQUIRE(dout && argmax && dx && B > 0 && C % 4 == 0 && k >= 1 && s >= 1, "maxpool_bwd: bad arguments");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)B * H * W * (C / 4))), dim3(256), 0, as_stream(stream), dout, argmax, B, H, W, C,
+                       k, s, p, Ho, Wo, dx, accumulate);
+    return check_launch("maxpool_bwd_kernel");
+}
+
+int awr_upsample2_add(const float* up1, const float* low, int B, int Hl, int Wl, int C, float* out, void* stream) {
+    AWR_REQUIRE(up1 && low && out && B > 0 && C % 4 == 0, "upsample2_add: bad arguments");
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3(nblk((int64_t)B * Hl * Wl * C)), dim3(256), 0, as_stream(stream), up1, low, B, Hl, Wl, C, out);
+    return check_launch("upsample2_add_kernel");
+}
+
+int awr_upsample2_bwd(const float* dout, int B, int Hl, int Wl, int C, float* dlow, int accumulate, void* stream) {
+    AWR_REQUIRE(dout && dlow && B > 0 && C % 4 == 0, "upsample2_bwd: bad arguments");
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(nblk((int64_t)B * Hl * Wl * (C / 4))), dim3(256), 0, as_stream(stream), dout, B, Hl, Wl, C, dlow, accumulate);
+    return check_launch("upsample2_bwd_kernel");
+}
+
+int awr_nhwc_to_nchw(const float* in, int B, int P, int Cp, int C, float* out, void* stream) {
+    AWR_REQUIRE(in && out && B > 0 && P > 0 && C > 0 && Cp >= C, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, as_stream(stream), in, P, Cp, C, out);
+    return check_launch("nhwc_to_nchw_kernel");
+}
+
+int awr_nchw_to_nhwc(const float* in, int B, int P, int Cp, int C, float* out, void* stream) {
+    AWR_REQUIRE(in && out && B > 0 && P > 0 && C > 0 && Cp >= C, "nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((P + 31) / 32, (Cp + 31) / 32, B), dim3(256), 0, as_stream(stream), in, P, Cp, C, out);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,467 @@
+// AWR head, GT dense map, Huber losses, Adam/SGD -- the HBM-bound part of the hot path.
+//
+// Every kernel here streams its operands exactly once with 16-byte loads (4 consecutive pixels of
+// one feature-map row per lane), keeps the whole per-(image,joint) reduction in registers / LDS
+// and writes the result once.  Compiled with -ffp-contract=off: the GT map has hard thresholds
+// (heat-map >= 0, depth < 0.99), so its arithmetic is kept operation-for-operation identical to
+// the reference's (util/feature_tool.py:29-35) to avoid mask flips from fused multiply-adds.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "awr_common.h"
+
+namespace awr {
+
+static thread_local char g_err[512] = "ok";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr float kBeta = 30.0f;     // util/feature_tool.py:60
+constexpr float kDepthBg = 0.99f;  // util/feature_tool.py:35, :57
+
+// pixel-centre coordinate in [-1,1]; util/feature_tool.py:23-24, :50-51 (exact in fp32 for F = 2^k)
+__device__ __forceinline__ float grid_coord(int i, int F) { return 2.0f * ((float)i + 0.5f) / (float)F - 1.0f; }
+
+struct Px4 {  // 4 consecutive pixels of one feature row
+    float d[4], cx[4], cy;
+};
+
+__device__ __forceinline__ Px4 load_px4(const float* __restrict__ img, int b, int p0, int F, int H) {
+    Px4 r;
+    const int rs = H / F;
+    const int y = p0 / F, x = p0 - y * F;
+    const float* row = img + ((int64_t)b * H + (int64_t)y * rs) * H;
+    if (rs == 2) {  // the common case: 8 consecutive floats, take the even ones
+        float4 a = ld4(row + 2 * x), c = ld4(row + 2 * x + 4);
+        r.d[0] = a.x; r.d[1] = a.z; r.d[2] = c.x; r.d[3] = c.z;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.d[i] = row[(x + i) * rs];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.cx[i] = grid_coord(x + i, F);
+    r.cy = grid_coord(y, F);
+    return r;
+}
+
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// ------------------------------------------------------------------------------------------
+// head forward: one workgroup per (image, joint); online softmax over all P pixels.
+// ------------------------------------------------------------------------------------------
+struct SoftAcc {
+    float m, s, a0, a1, a2;
+};
+__device__ __forceinline__ SoftAcc combine(const SoftAcc& x, const SoftAcc& y) {
+    SoftAcc r;
+    r.m = fmaxf(x.m, y.m);
+    const float fx = (x.m == -INFINITY) ? 0.f : expf(x.m - r.m);
+    const float fy = (y.m == -INFINITY) ? 0.f : expf(y.m - r.m);
+    r.s = x.s * fx + y.s * fy;
+    r.a0 = x.a0 * fx + y.a0 * fy;
+    r.a1 = x.a1 * fx + y.a1 * fy;
+    r.a2 = x.a2 * fx + y.a2 * fy;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ offset, const float* __restrict__ img,
+                                                       int J, int F, int H, float ks, float* __restrict__ jt,
+                                                       float* __restrict__ stat) {
+    const int bj = blockIdx.x, b = bj / J, j = bj - b * J;
+    const int P = F * F;
+    const float* vec = offset + ((int64_t)b * 4 * J + 3 * j) * P;
+    const float* ht = offset + ((int64_t)b * 4 * J + 3 * J + j) * P;
+    SoftAcc acc = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = threadIdx.x * 4; p0 < P; p0 += 256 * 4) {
+        const Px4 px = load_px4(img, b, p0, F, H);
+        const float4 h4 = ld4(ht + p0), v0 = ld4(vec + p0), v1 = ld4(vec + P + p0), v2 = ld4(vec + 2 * P + p0);
+        float h[4], l[4];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float mk = px.d[i] < kDepthBg ? 1.f : 0.f;
+            h[i] = comp(h4, i) * mk;  // masked pixels keep logit 0 (feature_tool.py:59-60)
+            l[i] = h[i] * kBeta;
+            cm = fmaxf(cm, l[i]);
+        }
+        if (cm > acc.m) {
+            const float sc = (acc.m == -INFINITY) ? 0.f : expf(acc.m - cm);
+            acc.s *= sc; acc.a0 *= sc; acc.a1 *= sc; acc.a2 *= sc;
+            acc.m = cm;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float mk = px.d[i] < kDepthBg ? 1.f : 0.f;
+            const float e = expf(l[i] - acc.m);
+            const float dis = ks - h[i] * ks;  // feature_tool.py:61
+            acc.s += e;
+            acc.a0 += (comp(v0, i) * mk * dis + px.cx[i]) * e;
+            acc.a1 += (comp(v1, i) * mk * dis + px.cy) * e;
+            acc.a2 += (comp(v2, i) * mk * dis + px.d[i]) * e;
+        }
+    }
+    // wave reduction with the softmax-merge operator, then across the 4 waves through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        SoftAcc other;
+        other.m = __shfl_xor(acc.m, o, 64);
+        other.s = __shfl_xor(acc.s, o, 64);
+        other.a0 = __shfl_xor(acc.a0, o, 64);
+        other.a1 = __shfl_xor(acc.a1, o, 64);
+        other.a2 = __shfl_xor(acc.a2, o, 64);
+        acc = combine(acc, other);
+    }
+    __shared__ SoftAcc part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SoftAcc t = combine(combine(part[0], part[1]), combine(part[2], part[3]));
+        float* o = jt + (int64_t)bj * 3;
+        o[0] = t.a0 / t.s;
+        o[1] = t.a1 / t.s;
+        o[2] = t.a2 / t.s;
+        if (stat) {
+            stat[2 * bj] = t.m;
+            stat[2 * bj + 1] = t.s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// head backward: pure streaming given the saved (max, sum-exp) and the forward output.
+//   d/dvec[c,p] = g_c * w_p * dis_p * m_p
+//   d/dht[p]    = m_p * sum_c g_c * ( -ks * w_p * vec_c,p * m_p + 30 * w_p * (val_c,p - out_c) )
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ offset, const float* __restrict__ img,
+                                                       const float* __restrict__ jt, const float* __restrict__ stat,
+                                                       const float* __restrict__ g_jt, int J, int F, int H, float ks,
+                                                       float* __restrict__ g_offset, int accumulate) {
+    const int bj = blockIdx.y, b = bj / J, j = bj - b * J;
+    const int P = F * F;
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= P) return;
+    const int64_t voff = ((int64_t)b * 4 * J + 3 * j) * P + p0, hoff = ((int64_t)b * 4 * J + 3 * J + j) * P + p0;
+    const Px4 px = load_px4(img, b, p0, F, H);
+    const float4 h4 = ld4(offset + hoff), v0 = ld4(offset + voff), v1 = ld4(offset + voff + P), v2 = ld4(offset + voff + 2 * P);
+    const float mx = stat[2 * bj], inv_s = 1.0f / stat[2 * bj + 1];
+    const float g0 = g_jt[bj * 3], g1 = g_jt[bj * 3 + 1], g2 = g_jt[bj * 3 + 2];
+    const float o0 = jt[bj * 3], o1 = jt[bj * 3 + 1], o2 = jt[bj * 3 + 2];
+    float r0[4], r1[4], r2[4], rh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float mk = px.d[i] < kDepthBg ? 1.f : 0.f;
+        const float h = comp(h4, i) * mk;
+        const float w = expf(h * kBeta - mx) * inv_s;
+        const float dis = ks - h * ks;
+        const float a0 = comp(v0, i) * mk, a1 = comp(v1, i) * mk, a2 = comp(v2, i) * mk;
+        const float wd = w * dis * mk;
+        r0[i] = g0 * wd;
+        r1[i] = g1 * wd;
+        r2[i] = g2 * wd;
+        const float t0 = -ks * a0 + kBeta * (a0 * dis + px.cx[i] - o0);
+        const float t1 = -ks * a1 + kBeta * (a1 * dis + px.cy - o1);
+        const float t2 = -ks * a2 + kBeta * (a2 * dis + px.d[i] - o2);
+        rh[i] = mk * w * (g0 * t0 + g1 * t1 + g2 * t2);
+    }
+    float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]), q1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    float4 q2 = make_float4(r2[0], r2[1], r2[2], r2[3]), qh = make_float4(rh[0], rh[1], rh[2], rh[3]);
+    if (accumulate) {
+        const float4 e0 = ld4(g_offset + voff), e1 = ld4(g_offset + voff + P), e2 = ld4(g_offset + voff + 2 * P), eh = ld4(g_offset + hoff);
+        q0.x += e0.x; q0.y += e0.y; q0.z += e0.z; q0.w += e0.w;
+        q1.x += e1.x; q1.y += e1.y; q1.z += e1.z; q1.w += e1.w;
+        q2.x += e2.x; q2.y += e2.y; q2.z += e2.z; q2.w += e2.w;
+        qh.x += eh.x; qh.y += eh.y; qh.z += eh.z; qh.w += eh.w;
+    }
+    st4(g_offset + voff, q0);
+    st4(g_offset + voff + P, q1);
+    st4(g_offset + voff + 2 * P, q2);
+    st4(g_offset + hoff, qh);
+}
+
+// ------------------------------------------------------------------------------------------
+// GT dense map for 4 pixels of joint j (util/feature_tool.py:29-39), operation for operation.
+// ------------------------------------------------------------------------------------------
+struct Gt4 {
+    float u0[4], u1[4], u2[4], hm[4];
+};
+__device__ __forceinline__ Gt4 gt_map4(const Px4& px, float j0, float j1, float j2, float ks) {
+    Gt4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float o0 = j0 - px.cx[i], o1 = j1 - px.cy, o2 = j2 - px.d[i];
+        const float dist = sqrtf(((o0 * o0 + o1 * o1) + o2 * o2) + 1e-8f);
+        const float hm = (ks - dist) / ks;
+        const float mk = (hm >= 0.f ? 1.f : 0.f) * (px.d[i] < kDepthBg ? 1.f : 0.f);
+        r.u0[i] = o0 / dist * mk;
+        r.u1[i] = o1 / dist * mk;
+        r.u2[i] = o2 / dist * mk;
+        r.hm[i] = hm * mk;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void joint2offset_kernel(const float* __restrict__ jt_gt, const float* __restrict__ img, int J,
+                                                           int F, int H, float ks, float* __restrict__ out) {
+    const int bj = blockIdx.y, b = bj / J, j = bj - b * J;
+    const int P = F * F;
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= P) return;
+    const Px4 px = load_px4(img, b, p0, F, H);
+    const Gt4 g = gt_map4(px, jt_gt[bj * 3], jt_gt[bj * 3 + 1], jt_gt[bj * 3 + 2], ks);
+    const int64_t voff = ((int64_t)b * 4 * J + 3 * j) * P + p0, hoff = ((int64_t)b * 4 * J + 3 * J + j) * P + p0;
+    st4(out + voff, make_float4(g.u0[0], g.u0[1], g.u0[2], g.u0[3]));
+    st4(out + voff + P, make_float4(g.u1[0], g.u1[1], g.u1[2], g.u1[3]));
+    st4(out + voff + 2 * P, make_float4(g.u2[0], g.u2[1], g.u2[2], g.u2[3]));
+    st4(out + hoff, make_float4(g.hm[0], g.hm[1], g.hm[2], g.hm[3]));
+}
+
+// Huber pieces (model/loss.py:8-25): value and d/dz
+__device__ __forceinline__ float huber_val(float z, float delta) {
+    const float a = fabsf(z);
+    return a < delta ? 0.5f * z * z : delta * (a - 0.5f * delta);
+}
+__device__ __forceinline__ float huber_grad(float z, float delta) { return fminf(fmaxf(z, -delta), delta); }
+
+__device__ __forceinline__ void block_accumulate(double local, double scale, double* acc) {
+    __shared__ double part[4];
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (part[0] + part[1] + part[2] + part[3]) * scale);
+}
+
+// fused GT map + dense Huber forward/backward: reads pred + depth once, writes the gradient once.
+__global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ pred, const float* __restrict__ jt_gt,
+                                                         const float* __restrict__ img, int J, int F, int H, float ks, float delta,
+                                                         float gscale, double lscale, double* __restrict__ acc,
+                                                         float* __restrict__ g_offset, int accumulate) {
+    const int bj = blockIdx.y, b = bj / J, j = bj - b * J;
+    const int P = F * F;
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    double local = 0.0;
+    if (p0 < P) {
+        const Px4 px = load_px4(img, b, p0, F, H);
+        const Gt4 g = gt_map4(px, jt_gt[bj * 3], jt_gt[bj * 3 + 1], jt_gt[bj * 3 + 2], ks);
+        const int64_t voff = ((int64_t)b * 4 * J + 3 * j) * P + p0, hoff = ((int64_t)b * 4 * J + 3 * J + j) * P + p0;
+        const int64_t offs[4] = {voff, voff + P, voff + 2 * P, hoff};
+        const float* gts[4] = {g.u0, g.u1, g.u2, g.hm};
+        float lsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 pv = ld4(pred + offs[c]);
+            float gr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float z = comp(pv, i) - gts[c][i];
+                lsum += huber_val(z, delta);
+                gr[i] = huber_grad(z, delta) * gscale;
+            }
+            if (g_offset) {
+                float4 q = make_float4(gr[0], gr[1], gr[2], gr[3]);
+                if (accumulate) {
+                    const float4 e = ld4(g_offset + offs[c]);
+                    q.x += e.x; q.y += e.y; q.z += e.z; q.w += e.w;
+                }
+                st4(g_offset + offs[c], q);
+            }
+        }
+        local = (double)lsum;
+    }
+    block_accumulate(local, lscale, acc);
+}
+
+__global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n, float delta,
+                                                    float gscale, double lscale, double* __restrict__ acc, float* __restrict__ gx,
+                                                    int accumulate) {
+    double local = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float z = x[i] - y[i];
+        local += (double)huber_val(z, delta);
+        if (gx) {
+            const float g = huber_grad(z, delta) * gscale;
+            gx[i] = accumulate ? gx[i] + g : g;
+        }
+    }
+    block_accumulate(local, lscale, acc);
+}
+
+__global__ void zero_f64_kernel(double* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+__global__ void loss_finalize_kernel(const double* acc, int n, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < n; ++i) {
+            out[i] = (float)acc[i];
+            t += acc[i];
+        }
+        out[n] = (float)t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// optimisers over flat arenas (torch.optim.Adam / SGD single-tensor update rules)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, int64_t n, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float eps, float wd, float step_size, float bc2_sqrt,
+                                                   float gscale) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 < n4) {
+        float4 pp = ld4(p + i4 * 4), gg = ld4(g + i4 * 4), mm = ld4(m + i4 * 4), vv = ld4(v + i4 * 4);
+        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gr = ga[k] * gscale;
+            if (wd != 0.f) gr = gr + wd * pa[k];
+            ma[k] = ma[k] + (gr - ma[k]) * one_minus_b1;      // exp_avg.lerp_(grad, 1-beta1)
+            va[k] = va[k] * b2 + one_minus_b2 * (gr * gr);    // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+            pa[k] = pa[k] - step_size * (ma[k] / denom);      // param.addcdiv_(exp_avg, denom, -step_size)
+        }
+        st4(p + i4 * 4, pp); st4(m + i4 * 4, mm); st4(v + i4 * 4, vv);
+    }
+    // scalar tail (n not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float gr = g[i] * gscale;
+        if (wd != 0.f) gr = gr + wd * p[i];
+        const float mk = m[i] + (gr - m[i]) * one_minus_b1;
+        const float vk = v[i] * b2 + one_minus_b2 * (gr * gr);
+        m[i] = mk; v[i] = vk;
+        p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
+                                                  float lr, float mom, float wd, int first, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gr = g[i] * gscale;
+    if (wd != 0.f) gr = gr + wd * p[i];
+    const float b = first ? gr : buf[i] * mom + gr;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+}
+
+}  // namespace awr
+
+using namespace awr;
+
+extern "C" {
+
+int awr_version(void) { return 100; }
+const char* awr_last_error(void) { return awr::g_err; }
+
+int awr_device_info(int* n_cu, int* clock_mhz, char* name, int name_len) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("hipGetDeviceProperties failed");
+        return AWR_ERR_HIP;
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    if (name && name_len > 0) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return AWR_OK;
+}
+
+static int check_head_dims(int B, int J, int F, int H) {
+    AWR_REQUIRE(B > 0 && J > 0 && F > 0 && H > 0, "head: B,J,F,H must be positive (got %d,%d,%d,%d)", B, J, F, H);
+    AWR_REQUIRE(F % 4 == 0 && H % F == 0, "head: need F %% 4 == 0 and H %% F == 0 (F=%d, H=%d)", F, H);
+    AWR_REQUIRE((H / F) != 2 || H % 8 == 0, "head: H must be a multiple of 8");
+    return AWR_OK;
+}
+
+int awr_head_forward(const float* offset, const float* img, int B, int J, int F, int H, float ks, float* jt, float* stat,
+                     void* stream) {
+    if (int e = check_head_dims(B, J, F, H)) return e;
+    AWR_REQUIRE(offset && img && jt, "head_forward: null pointer");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B * J), dim3(256), 0, as_stream(stream), offset, img, J, F, H, ks, jt, stat);
+    return check_launch("head_fwd_kernel");
+}
+
+int awr_head_backward(const float* offset, const float* img, const float* jt, const float* stat, const float* g_jt, int B, int J,
+                      int F, int H, float ks, float* g_offset, int accumulate, void* stream) {
+    if (int e = check_head_dims(B, J, F, H)) return e;
+    AWR_REQUIRE(offset && img && jt && stat && g_jt && g_offset, "head_backward: null pointer");
+    const int P = F * F;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((P / 4 + 255) / 256, B * J), dim3(256), 0, as_stream(stream), offset, img, jt, stat,
+                       g_jt, J, F, H, ks, g_offset, accumulate);
+    return check_launch("head_bwd_kernel");
+}
+
+int awr_joint2offset(const float* jt_gt, const float* img, int B, int J, int F, int H, float ks, float* out, void* stream) {
+    if (int e = check_head_dims(B, J, F, H)) return e;
+    AWR_REQUIRE(jt_gt && img && out, "joint2offset: null pointer");
+    const int P = F * F;
+    hipLaunchKernelGGL(joint2offset_kernel, dim3((P / 4 + 255) / 256, B * J), dim3(256), 0, as_stream(stream), jt_gt, img, J, F, H,
+                       ks, out);
+    return check_launch("joint2offset_kernel");
+}
+
+int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* img, int B, int J, int F, int H, float ks, float delta,
+                   float weight, double* acc, float* g_offset, int accumulate, void* stream) {
+    if (int e = check_head_dims(B, J, F, H)) return e;
+    AWR_REQUIRE(offset_pred && jt_gt && img && acc, "dense_loss: null pointer");
+    const int P = F * F;
+    const double n = (double)B * 4.0 * J * P;
+    hipLaunchKernelGGL(dense_loss_kernel, dim3((P / 4 + 255) / 256, B * J), dim3(256), 0, as_stream(stream), offset_pred, jt_gt, img,
+                       J, F, H, ks, delta, (float)((double)weight / n), (double)weight / n, acc, g_offset, accumulate);
+    return check_launch("dense_loss_kernel");
+}
+
+int awr_huber(const float* x, const float* y, int64_t n, float delta, float weight, double* acc, float* gx, int accumulate,
+              void* stream) {
+    AWR_REQUIRE(x && y && acc && n > 0, "huber: bad arguments");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(huber_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, y, n, delta,
+                       (float)((double)weight / (double)n), (double)weight / (double)n, acc, gx, accumulate);
+    return check_launch("huber_kernel");
+}
+
+int awr_zero_f64(double* p, int64_t n, void* stream) {
+    AWR_REQUIRE(p && n > 0, "zero_f64: bad arguments");
+    hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), p, n);
+    return check_launch("zero_f64_kernel");
+}
+
+int awr_loss_finalize(const double* acc, int n, float* out, void* stream) {
+    AWR_REQUIRE(acc && out && n > 0 && n <= 16, "loss_finalize: bad arguments");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), acc, n, out);
+    return check_launch("loss_finalize_kernel");
+}
+
+int awr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, float grad_scale, void* stream) {
+    AWR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    AWR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: arenas must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t n4 = n / 4;
+    const int64_t blocks = (n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n4, n,
+                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, weight_decay, (float)((double)lr / bc1),
+                       (float)sqrt(bc2), grad_scale);
+    return check_launch("adam_kernel");
+}
+
+int awr_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay, int64_t step,
+                 float grad_scale, void* stream) {
+    AWR_REQUIRE(p && g && buf && n > 0 && step >= 1, "sgd_step: bad arguments");
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
+                       weight_decay, step == 1 ? 1 : 0, grad_scale);
+    return check_launch("sgd_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+"""My_SmoothL1Loss: drop-in for the reference's model/loss.py:3-25 (Huber, delta = 0.01, mean over
+all elements) on the HIP path.  `criterion = My_SmoothL1Loss().cuda(); loss = criterion(x, y)`
+returns a 0-dim fp32 tensor that participates in autograd w.r.t. `x` (train.py:72, :125-130)."""
+import torch
+
+from . import _lib as L
+
+DELTA = 0.01
+
+
+class _Huber(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        xx, yy = x.detach().contiguous().float(), y.detach().contiguous().float()
+        n = xx.numel()
+        acc = torch.zeros(1, device=xx.device, dtype=torch.float64)
+        need_grad = x.requires_grad
+        gx = torch.empty_like(xx) if need_grad else None
+        L.call("awr_huber", L.ptr(xx), L.ptr(yy), n, DELTA, 1.0, L.ptr(acc), L.ptr(gx), 0, L.stream())
+        ctx.save_for_backward(gx) if need_grad else None
+        ctx.shape = x.shape
+        return acc[0].float()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return (gx * g).view(ctx.shape), None
+
+
+class My_SmoothL1Loss(torch.nn.Module):
+    def forward(self, x, y):
+        assert x.shape == y.shape      # loss.py:10
+        return _Huber.apply(x, y)

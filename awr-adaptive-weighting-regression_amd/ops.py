@@ -1,0 +1,197 @@
+"""Host-side geometry + thin tensor wrappers over the backbone entry points of libawr_hip.so.
+
+Activations are NHWC fp32 CUDA(HIP) tensors.  A `ConvSpec` describes one reference layer
+(nn.Conv2d or nn.ConvTranspose2d); from it this module derives the three GEMM problems the layer
+needs -- forward, data gradient, weight gradient -- as `awr_conv_args` / `awr_wgrad_args`
+geometries plus the weight-packing recipe for each (see include/awr_hip.h).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+N_ALIGN = 128     # packed weight rows are padded to a multiple of the widest GEMM tile
+K_ALIGN = 32      # GEMM K-slice
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ConvSpec:
+    """kind: 'conv' (nn.Conv2d, weight (Cout,Cin,k,k)) or 'deconv' (nn.ConvTranspose2d k4 s2 p1,
+    weight (Cin,Cout,k,k)).  cin_pad/cout_pad: channel counts of the NHWC tensors (>= logical)."""
+
+    def __init__(self, kind, cin, cout, k, stride, pad, cin_pad=None, cout_pad=None):
+        assert kind in ("conv", "deconv")
+        self.kind, self.cin, self.cout, self.k, self.stride, self.pad = kind, cin, cout, k, stride, pad
+        self.cin_pad = cin_pad or cin
+        self.cout_pad = cout_pad or cout
+        self.T = k * k
+        assert self.cin_pad % K_ALIGN == 0, "GEMM K extent (Cin=%d) must be a multiple of %d" % (self.cin_pad, K_ALIGN)
+        if kind == "deconv":
+            assert stride == 2
+
+    # ---- shapes -----------------------------------------------------------------------------
+    def out_hw(self, h, w):
+        if self.kind == "conv":
+            return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
+        return (h - 1) * self.stride - 2 * self.pad + self.k, (w - 1) * self.stride - 2 * self.pad + self.k
+
+    # ---- tap tables ---------------------------------------------------------------------------
+    def _gather_taps(self):
+        """conv-type gather: one phase, taps (ky-p, kx-p, ky*k+kx)."""
+        return [(0, 0, [(ky - self.pad, kx - self.pad, ky * self.k + kx) for ky in range(self.k) for kx in range(self.k)])]
+
+    def _mirror_taps(self):
+        """stride-1 data gradient: dx[y] = sum_k dy[y + p - k] w[k]."""
+        return [(0, 0, [(self.pad - ky, self.pad - kx, ky * self.k + kx) for ky in range(self.k) for kx in range(self.k)])]
+
+    def _scatter_phases(self):
+        """transposed-type (output stride 2): phase (py,px) takes the taps with (py+p-ky) even."""
+        s, p, k = self.stride, self.pad, self.k
+        phases = []
+        for py in range(s):
+            for px in range(s):
+                taps = [((py + p - ky) // s, (px + p - kx) // s, ky * k + kx)
+                        for ky in range(k) if (py + p - ky) % s == 0
+                        for kx in range(k) if (px + p - kx) % s == 0]
+                if taps:
+                    phases.append((py, px, taps))
+        return phases
+
+    # ---- the three GEMM problems ------------------------------------------------------------------
+    def fwd_problem(self, hin, win):
+        """-> dict(Hin,Win,Cin,Hout,Wout,N,Hq,Wq,so,si,phases,full) for the forward pass."""
+        hout, wout = self.out_hw(hin, win)
+        if self.kind == "conv":
+            return dict(Hin=hin, Win=win, Cin=self.cin_pad, Hout=hout, Wout=wout, N=self.cout_pad, Hq=hout, Wq=wout, so=1,
+                        si=self.stride, phases=self._gather_taps(), full=True)
+        ph = self._scatter_phases()
+        return dict(Hin=hin, Win=win, Cin=self.cin_pad, Hout=hout, Wout=wout, N=self.cout_pad, Hq=hout // 2, Wq=wout // 2, so=2, si=1,
+                    phases=ph, full=len(ph) == 4)
+
+    def dgrad_problem(self, hin, win):
+        """gradient w.r.t. the layer input: reads dY (B,Hout,Wout,cout_pad), writes dX (B,hin,win,cin_pad)."""
+        hout, wout = self.out_hw(hin, win)
+        base = dict(Hin=hout, Win=wout, Cin=self.cout_pad, Hout=hin, Wout=win, N=self.cin_pad)
+        if self.kind == "deconv":      # adjoint of a transposed conv is a strided conv
+            return dict(base, Hq=hin, Wq=win, so=1, si=self.stride, phases=self._gather_taps(), full=True)
+        if self.stride == 1:
+            return dict(base, Hq=hin, Wq=win, so=1, si=1, phases=self._mirror_taps(), full=True)
+        assert hin % 2 == 0 and win % 2 == 0
+        ph = self._scatter_phases()
+        return dict(base, Hq=hin // 2, Wq=win // 2, so=2, si=1, phases=ph, full=len(ph) == 4)
+
+    # weight packing recipes: (d0, d1, T, transpose, rows, ld) for awr_pack_weight
+    def fwd_pack(self):
+        if self.kind == "conv":
+            return (self.cout, self.cin, self.T, 0, round_up(self.cout_pad, N_ALIGN), self.cin_pad)
+        return (self.cin, self.cout, self.T, 1, round_up(self.cout_pad, N_ALIGN), self.cin_pad)
+
+    def dgrad_pack(self):
+        if self.kind == "conv":
+            return (self.cout, self.cin, self.T, 1, round_up(self.cin_pad, N_ALIGN), self.cout_pad)
+        return (self.cin, self.cout, self.T, 0, round_up(self.cin_pad, N_ALIGN), self.cout_pad)
+
+    def wgrad_problem(self, hin, win):
+        """R[d0][t][d1] in the weight's own (d0,d1) order.  conv: D=dY, G=X; deconv: D=X, G=dY."""
+        hout, wout = self.out_hw(hin, win)
+        taps = [(ky - self.pad, kx - self.pad) for ky in range(self.k) for kx in range(self.k)]
+        if self.kind == "conv":
+            return dict(D="dy", Hd=hout, Wd=wout, Cd=self.cout_pad, Hg=hin, Wg=win, Cg=self.cin_pad, sg=self.stride, taps=taps,
+                        d0=self.cout, d1=self.cin)
+        return dict(D="x", Hd=hin, Wd=win, Cd=self.cin_pad, Hg=hout, Wg=wout, Cg=self.cout_pad, sg=self.stride, taps=taps,
+                    d0=self.cin, d1=self.cout)
+
+
+def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, out_scale=None, out_shift=None, res=None,
+                   stats=None, relu_in=False, relu_out=False, T=None):
+    a = L.ConvArgs()
+    a.in_, a.w, a.out = L.ptr(x), L.ptr(w), L.ptr(out)
+    a.in_scale, a.in_shift, a.bias = L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias)
+    a.out_scale, a.out_shift, a.res, a.stats = L.ptr(out_scale), L.ptr(out_shift), L.ptr(res), L.ptr(stats)
+    a.B, a.Hin, a.Win, a.Cin = B, prob["Hin"], prob["Win"], prob["Cin"]
+    a.Hq, a.Wq, a.Hout, a.Wout, a.N = prob["Hq"], prob["Wq"], prob["Hout"], prob["Wout"], prob["N"]
+    a.so, a.si, a.T = prob["so"], prob["si"], T
+    a.relu_in, a.relu_out = int(relu_in), int(relu_out)
+    a.nphase = len(prob["phases"])
+    for i, (py, px, taps) in enumerate(prob["phases"]):
+        ph = a.ph[i]
+        ph.py, ph.px, ph.ntaps = py, px, len(taps)
+        for t, (dy, dx, wt) in enumerate(taps):
+            ph.dy[t], ph.dx[t], ph.wt[t] = dy, dx, wt
+    return a
+
+
+def make_wgrad_args(prob, B, D, G, R, ld):
+    a = L.WgradArgs()
+    a.D, a.G, a.R = L.ptr(D), L.ptr(G), L.ptr(R)
+    a.B, a.Hd, a.Wd, a.Cd = B, prob["Hd"], prob["Wd"], prob["Cd"]
+    a.Hg, a.Wg, a.Cg, a.sg, a.T, a.ld = prob["Hg"], prob["Wg"], prob["Cg"], prob["sg"], len(prob["taps"]), ld
+    for t, (dy, dx) in enumerate(prob["taps"]):
+        a.dy[t], a.dx[t] = dy, dx
+    return a
+
+
+# ---------------------------------------------------------------------------------------------
+# eager wrappers (allocate outputs; used by tests and by the drop-in modules' slow path)
+# ---------------------------------------------------------------------------------------------
+def pack_weight(w, recipe, out=None, row_offset=0, rows=None):
+    d0, d1, T, tr, n_rows, ld = recipe
+    if out is None:
+        out = torch.empty(n_rows, T, ld, device=w.device, dtype=torch.float32)
+    rows = n_rows if rows is None else rows
+    dst = out.view(-1)[row_offset * T * ld:]
+    L.call("awr_pack_weight", L.ptr(w), d0, d1, T, tr, rows, ld, dst.data_ptr(), L.stream())
+    return out
+
+
+def conv_forward(spec, x, wp, **kw):
+    B, H, W, _ = x.shape
+    prob = spec.fwd_problem(H, W)
+    out = kw.pop("out", None)
+    if out is None:
+        out = (torch.empty if prob["full"] or kw.get("res") is not None else torch.zeros)(
+            B, prob["Hout"], prob["Wout"], prob["N"], device=x.device, dtype=torch.float32)
+    a = make_conv_args(prob, B, x, wp, out, T=spec.T, **kw)
+    L.call("awr_conv_gemm", C.byref(a), L.stream())
+    return out
+
+
+def conv_dgrad(spec, dy, wp, hin, win, **kw):
+    B = dy.shape[0]
+    prob = spec.dgrad_problem(hin, win)
+    out = kw.pop("out", None)
+    if out is None:
+        out = (torch.empty if prob["full"] else torch.zeros)(B, hin, win, prob["N"], device=dy.device, dtype=torch.float32)
+        if not prob["full"] and kw.get("res") is None:
+            kw["res"] = out
+    a = make_conv_args(prob, B, dy, wp, out, T=spec.T, **kw)
+    L.call("awr_conv_gemm", C.byref(a), L.stream())
+    return out
+
+
+def conv_wgrad(spec, x, dy, grad=None, accumulate=False):
+    """Returns the gradient in checkpoint layout (same shape as the layer's weight)."""
+    B, H, W, _ = x.shape
+    prob = spec.wgrad_problem(H, W)
+    ld = prob["Cg"]
+    R = torch.zeros(prob["Cd"], len(prob["taps"]), ld, device=x.device, dtype=torch.float32)
+    D, G = (dy, x) if prob["D"] == "dy" else (x, dy)
+    a = make_wgrad_args(prob, B, D, G, R, ld)
+    L.call("awr_conv_wgrad", C.byref(a), L.stream())
+    if grad is None:
+        grad = torch.empty(prob["d0"], prob["d1"], spec.k, spec.k, device=x.device, dtype=torch.float32)
+    L.call("awr_unpack_wgrad", L.ptr(R), prob["d0"], prob["d1"], spec.T, ld, L.ptr(grad), int(accumulate), L.stream())
+    return grad
+
+
+def nhwc(x):
+    """(B,C,H,W) -> contiguous (B,H,W,C) [test helper]"""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()

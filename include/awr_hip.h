@@ -1,0 +1,211 @@
+/*
+ * awr_hip.h -- C ABI of libawr_hip.so: the MI355X (gfx950) implementation of the AWR hot path.
+ *
+ * The reference (Elody-07/AWR-Adaptive-Weighting-Regression) has no FFI layer: its hot path is
+ * plain Python over torch ops.  Each entry point below therefore cites the reference Python
+ * interface it replaces (file:line under the reference tree).  The Python host side in
+ * awr-adaptive-weighting-regression_amd/ binds these with ctypes and mirrors the reference's
+ * call surface (get_deconv_net, PoseNet, FeatureModule, My_SmoothL1Loss, Trainer step).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code otherwise; awr_last_error() returns a
+ *     thread-local description.  Nothing throws across the ABI.
+ *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every buffer.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  One call = kernels enqueued
+ *     on that stream; no call synchronises the device.
+ *   - activations inside the backbone are NHWC; the reference-facing tensors (depth image, dense
+ *     offset map, joints) keep the reference's NCHW / (B,J,3) layouts.
+ */
+#ifndef AWR_HIP_H
+#define AWR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWR_OK 0
+#define AWR_ERR_ARG (-1)
+#define AWR_ERR_HIP (-2)
+#define AWR_ERR_UNSUPPORTED (-3)
+
+int awr_version(void);
+const char* awr_last_error(void);
+/* number of compute units / device name of the current device (diagnostics for bench.py) */
+int awr_device_info(int* n_cu, int* clock_mhz, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * AWR head.  offset: (B,4J,F,F) NCHW, channels [0,3J) unit offsets (joint-major, xyz-minor),
+ * [3J,4J) closeness heat maps.  img: (B,1,H,H) normalised depth; the head samples img[b,0,y*H/F,
+ * x*H/F] (nearest F.interpolate).  jt: (B,J,3).
+ * -----------------------------------------------------------------------------------------*/
+
+/* replaces FeatureModule.offset2joint_softmax (util/feature_tool.py:41-65).
+ * stat (optional, B*J*2): per (b,j) softmax max-logit and sum-exp, consumed by the backward. */
+int awr_head_forward(const float* offset, const float* img, int B, int J, int F, int H, float ks,
+                     float* jt, float* stat, void* stream);
+
+/* replaces autograd's backward of offset2joint_softmax (implicit in train.py:130).
+ * g_offset (B,4J,F,F) = d(sum(jt*g_jt))/d(offset); accumulate!=0 adds into g_offset. */
+int awr_head_backward(const float* offset, const float* img, const float* jt, const float* stat,
+                      const float* g_jt, int B, int J, int F, int H, float ks, float* g_offset,
+                      int accumulate, void* stream);
+
+/* replaces FeatureModule.joint2offset (util/feature_tool.py:12-39): GT dense map (B,4J,F,F). */
+int awr_joint2offset(const float* jt_gt, const float* img, int B, int J, int F, int H, float ks,
+                     float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.  My_SmoothL1Loss (model/loss.py:8-25) == Huber(delta) averaged over all elements.
+ * Partial sums are accumulated in a device double (`acc`); the caller zeroes it (awr_zero_f64)
+ * and reads it through awr_loss_finalize.
+ * -----------------------------------------------------------------------------------------*/
+
+/* acc[0] += weight * mean(huber(x-y)); gx (optional) = weight * clamp(x-y,+-delta)/n
+ * (accumulate!=0 adds into gx).  Replaces criterion(x, y) + its autograd (train.py:125-130). */
+int awr_huber(const float* x, const float* y, int64_t n, float delta, float weight, double* acc,
+              float* gx, int accumulate, void* stream);
+
+/* Fused GT-map synthesis + dense Huber forward + backward: never materialises the GT map.
+ * Equivalent to weight*criterion(offset_pred, FM.joint2offset(jt_gt, img, ks, F)) and its
+ * gradient w.r.t. offset_pred (train.py:113, :126, :130).  g_offset optional. */
+int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* img, int B, int J,
+                   int F, int H, float ks, float delta, float weight, double* acc, float* g_offset,
+                   int accumulate, void* stream);
+
+int awr_zero_f64(double* p, int64_t n, void* stream);
+/* out[i] = (float)acc[i] for i<n, out[n] = sum -- e.g. {coord, dense, total} */
+int awr_loss_finalize(const double* acc, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: torch.optim.Adam defaults semantics (train.py:66-67, :131) over flat arenas.
+ * g is multiplied by grad_scale first (1/world_size after the RCCL sum all-reduce).
+ * -----------------------------------------------------------------------------------------*/
+int awr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream);
+/* SGD with momentum (train.py:68-69): buf = mom*buf + g (buf = g on step 1); p -= lr*buf */
+int awr_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                 float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone building blocks (replace the torch.nn modules used by model/resnet_deconv.py:19-215
+ * and model/hourglass.py:6-165 and their autograd).  Activations NHWC fp32.
+ * -----------------------------------------------------------------------------------------*/
+
+/* Weight repack between the checkpoint layout W[d0][d1][T] (Conv2d: O,I,kh*kw; ConvTranspose2d:
+ * I,O,kh*kw) and the GEMM layout P[n][T][ld] (K-contiguous rows, zero padded: n < n_pad rows,
+ * ld >= inner extent).  transpose==0: P[d0][t][d1] = W[d0][d1][t]; transpose!=0: P[d1][t][d0]. */
+int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_pad, int ld,
+                    float* packed, void* stream);
+/* grad[d0][d1][t] (+)= P[d0][t][d1] (P has row length ld): wgrad GEMM output -> checkpoint layout */
+int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* grad, int accumulate,
+                     void* stream);
+
+/* Geometry of one implicit-GEMM convolution-like gather:
+ *   out[b, qy*so+py, qx*so+px, n] = sum_{tap in phase} sum_c in[b, qy*si+dy, qx*si+dx, c] * P[n][wt][c]
+ * conv kxk stride s pad p      : so=1, si=s, one phase, taps (dy,dx,wt)=(ky-p,kx-p,ky*k+kx)
+ * transposed conv k4 s2 p1     : so=2, si=1, four phases (py,px), taps with (py+p-ky) even,
+ *                                dy=(py+p-ky)/2 (likewise x), wt=ky*k+kx
+ * Built by the host (see awr_conv_geom_* helpers in the Python/C++ host code). */
+typedef struct awr_phase {
+    int py, px, ntaps;
+    int8_t dy[16], dx[16], wt[16];
+} awr_phase;
+
+typedef struct awr_conv_args {
+    const float* in;        /* (B,Hin,Win,Cin) */
+    const float* w;         /* packed P[n_pad][T][Cin] */
+    float* out;             /* (B,Hout,Wout,N) */
+    const float* in_scale;  /* optional per-input-channel affine applied while loading ...     */
+    const float* in_shift;  /* ... in-bounds pixels only (padding stays 0)                       */
+    const float* bias;      /* optional per-output-channel bias                                  */
+    const float* out_scale; /* optional per-output-channel affine after bias (folded eval BN)    */
+    const float* out_shift;
+    const float* res;       /* optional tensor added element-wise, same shape as out            */
+    double* stats;          /* optional [2][N]: += sum and sum of squares of the stored value
+                               (taken after bias/affine/res, before relu_out)                    */
+    int B, Hin, Win, Cin;
+    int Hq, Wq;             /* per-phase output grid */
+    int Hout, Wout, N;
+    int so, si, T;
+    int relu_in, relu_out;
+    int nphase;
+    awr_phase ph[4];
+} awr_conv_args;
+
+/* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
+ * Replaces nn.Conv2d / nn.ConvTranspose2d forward and their dgrad. */
+int awr_conv_gemm(const awr_conv_args* a, void* stream);
+/* test hook: force the (TM,TN) in {1,2}^2 workgroup tile of awr_conv_gemm / awr_conv_wgrad
+ * (0,0 = automatic choice).  Not for production use. */
+int awr_debug_force_tile(int tm, int tn);
+
+/* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
+ * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).
+ * conv wgrad: D=dY, G=X, (dy,dx)=(ky-p,kx-p), sg=stride -> R == packed [Cout][T][Cin].
+ * deconv wgrad: D=X, G=dY, sg=2 -> R == [Cin][T][Cout].  R (row length ld>=Cg) must be zeroed by
+ * the caller; split-K partial sums are combined with fp32 atomics. */
+typedef struct awr_wgrad_args {
+    const float* D;
+    const float* G;
+    float* R;
+    int B, Hd, Wd, Cd, Hg, Wg, Cg, sg, T, ld;
+    int8_t dy[16], dx[16];
+} awr_wgrad_args;
+int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
+
+/* 5x5 stem (Cin=1): im2col of the depth image into (B,H,W,32) rows (25 taps + 7 zeros) so the
+ * stem conv and its wgrad run on the same MFMA GEMMs (resnet_deconv.py:32, hourglass.py:112). */
+int awr_stem_im2col(const float* img, int B, int H, int W, float* cols, void* stream);
+
+/* BatchNorm2d (training): stats -> (scale, shift, mean, invstd) + running-stat update
+ * (momentum, unbiased running var); zeroes `stats` afterwards.  nn.BatchNorm2d forward, train. */
+int awr_bn_finalize(double* stats, int C, int64_t count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
+int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* per-channel sum / sum of squares of an NHWC tensor (for BNs whose input is not a conv output) */
+int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream);
+/* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
+int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,
+                 float* out, int64_t npix, int C, void* stream);
+/* backward pass 1: g = dout * (act>0 if act) ; sums[0][c] += sum g ; sums[1][c] += sum g*xhat */
+int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean,
+                      const float* invstd, int64_t npix, int C, double* sums, void* stream);
+/* backward pass 2: dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) [+ dy_add]; optional g_out = g
+ * (residual branch); dgamma/dbeta (+)= sums (accumulate); zeroes sums afterwards.  dy may alias
+ * dy_add or dout. */
+int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean,
+                     const float* invstd, const float* gamma, double* sums, int64_t npix, int C,
+                     float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta,
+                     int accumulate, void* stream);
+/* plain ReLU backward / mask: g = dout * (act > 0) */
+int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream);
+/* out = a + b (n elements); out may alias a */
+int awr_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* per-channel bias gradient: db[c] (+)= sum over pixels dy[pix][c] */
+int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulate, void* stream);
+
+/* MaxPool2d(k,s,p) NHWC forward (+ uint8 argmax) and backward; nn.MaxPool2d(3,2,1)/(2,2). */
+int awr_maxpool_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* out,
+                    uint8_t* argmax, void* stream);
+int awr_maxpool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k,
+                    int s, int p, float* dx, int accumulate, void* stream);
+/* hourglass.py:88: out = up1 + nearest_upsample2(low)  and its backward (dlow = 2x2 sums of dout) */
+int awr_upsample2_add(const float* up1, const float* low, int B, int Hl, int Wl, int C, float* out,
+                      void* stream);
+int awr_upsample2_bwd(const float* dout, int B, int Hl, int Wl, int C, float* dlow, int accumulate,
+                      void* stream);
+
+/* layout bridges at the reference boundary: NHWC (C padded to Cp) <-> NCHW (C channels) */
+int awr_nhwc_to_nchw(const float* in, int B, int P, int Cp, int C, float* out, void* stream);
+int awr_nchw_to_nhwc(const float* in, int B, int P, int Cp, int C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWR_HIP_H */

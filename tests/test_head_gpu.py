@@ -1,0 +1,165 @@
+"""GPU parity: HIP head / GT-map / loss / optimiser kernels (through the C ABI) vs the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import awr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+
+
+def DP(L, t, dev):
+    """device pointer of a host tensor; the device copy is kept alive until the module is torn down
+    (a temporary freed right after data_ptr() would be recycled by the caching allocator)."""
+    d = t.to(dev)
+    _KEEP.append(d)
+    return L.ptr(d)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import awr_amd
+    return awr_amd
+
+
+def _hashed(shape, stream, scale):
+    return torch.from_numpy((O._hash_uniform(int(np.prod(shape)), stream, 99) * np.float32(2 * scale)).reshape(shape).copy())
+
+
+CASES = [(2, 14, 128, 0.4), (3, 14, 128, 1.0), (2, 21, 256, 0.4), (1, 14, 64, 0.4), (2, 16, 128, 0.7)]
+
+
+@pytest.mark.parametrize("B,J,H,ks", CASES)
+def test_joint2offset_bit_exact(amd, dev, B, J, H, ks):
+    img, jt = O.synth_batch(B, H, J, seed=21)
+    F = H // 2
+    out = amd.FeatureModule().joint2offset(jt.to(dev), img.to(dev), ks, F).cpu()
+    ref = O.joint2offset(jt, img, ks, F)
+    nbad = int((out != ref).sum())
+    assert float((out - ref).abs().max()) <= 1e-6, "max diff %g, %d elements differ" % (float((out - ref).abs().max()), nbad)
+
+
+@pytest.mark.parametrize("B,J,H,ks", CASES)
+def test_head_forward_backward(amd, dev, B, J, H, ks):
+    img, _ = O.synth_batch(B, H, J, seed=22)
+    F = H // 2
+    off = _hashed((B, 4 * J, F, F), 3, 0.6)
+    g_jt = _hashed((B, J, 3), 4, 1.0)
+    x = off.to(dev).requires_grad_(True)
+    jt = amd.FeatureModule().offset2joint_softmax(x, img.to(dev), ks)
+    ref = O.offset2joint_softmax(off, img, ks)
+    d = float((jt.detach().cpu() - ref).abs().max())
+    # tolerance: 1e-3 mm of a 150 mm half-cube = 6.7e-6 normalised (north_star); we hold 3e-6
+    assert d <= 3e-6, d
+    (jt * g_jt.to(dev)).sum().backward()
+    gref = O.head_backward(off, img, ks, g_jt)
+    gd = float((x.grad.cpu() - gref).abs().max())
+    assert gd <= 3e-6 * float(gref.abs().max()) + 1e-9, (gd, float(gref.abs().max()))
+
+
+def test_head_golden(amd, dev, golden_dir):
+    for tag in ("j14_ks04", "j14_ks10", "j21_h256"):
+        g = np.load(os.path.join(golden_dir, "head_%s.npz" % tag))
+        img = torch.from_numpy(g["img"])
+        J, ks = int(g["J"]), float(g["ks"])
+        F = img.shape[-1] // 2
+        off = _hashed((2, 4 * J, F, F), int(g["offset_stream"]), float(g["offset_scale"])).to(dev).requires_grad_(True)
+        jt = amd.FeatureModule().offset2joint_softmax(off, img.to(dev), ks)
+        np.testing.assert_allclose(jt.detach().cpu().numpy(), g["jt"], rtol=0, atol=3e-6)
+        (jt * torch.from_numpy(g["g_jt"]).to(dev)).sum().backward()
+        scale = float(np.abs(g["g_val"]).max())
+        np.testing.assert_allclose(off.grad.cpu().reshape(-1).numpy()[g["g_idx"]], g["g_val"], rtol=0, atol=3e-6 * scale + 1e-9)
+
+
+def test_roundtrip_property_full_size(amd, dev):
+    """joint2offset -> offset2joint_softmax recovers joints that lie on the hand surface (the head's
+    defining property), at BASELINE's full batch 256."""
+    B, J = 256, 14
+    img, _ = O.synth_batch(B, 128, J, seed=5)
+    d = img[:, 0, ::2, ::2]
+    ys = torch.randint(20, 44, (B, J)); xs = torch.randint(20, 44, (B, J))
+    a = 2.0 * (torch.arange(64).float() + 0.5) / 64 - 1.0
+    dep = d[torch.arange(B).view(B, 1), ys, xs]
+    jt = torch.stack([a[xs], a[ys], dep], -1)
+    fg = dep < 0.99
+    fm = amd.FeatureModule()
+    gt = fm.joint2offset(jt.to(dev), img.to(dev), 0.4, 64)
+    back = fm.offset2joint_softmax(gt, img.to(dev), 0.4).cpu()
+    ref = O.offset2joint_softmax(O.joint2offset(jt, img, 0.4, 64), img, 0.4)
+    assert float((back - ref).abs().max()) <= 3e-6
+    assert float((back - jt)[fg].abs().max()) < 0.05
+
+
+def test_huber_and_dense_loss(amd, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "huber.npz"))
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    y = torch.from_numpy(g["y"]).to(dev)
+    crit = amd.My_SmoothL1Loss().cuda()
+    loss = crit(x, y)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-7 * max(1.0, float(g["loss"]))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=0, atol=1e-9)
+    # fused GT-map + dense Huber vs oracle (loss and gradient), incl. accumulate
+    from awr_amd import _lib as L
+    for (B, J, H, ks) in [(2, 14, 128, 0.4), (2, 14, 128, 1.0), (1, 21, 256, 0.4)]:
+        img, jt = O.synth_batch(B, H, J, seed=23)
+        F = H // 2
+        pred = _hashed((B, 4 * J, F, F), 6, 0.05).requires_grad_(True)
+        lref = 0.7 * O.huber(pred, O.joint2offset(jt, img, ks, F))
+        (gref,) = torch.autograd.grad(lref, pred)
+        acc = torch.zeros(2, device=dev, dtype=torch.float64)
+        gout = torch.empty((B, 4 * J, F, F), device=dev)
+        p, j_, i_ = pred.detach().to(dev), jt.to(dev), img.to(dev)
+        L.call("awr_dense_loss", L.ptr(p), L.ptr(j_), L.ptr(i_), B, J, F, H, ks, 0.01, 0.7, L.ptr(acc), L.ptr(gout), 0, L.stream())
+        out = torch.empty(3, device=dev)
+        L.call("awr_loss_finalize", L.ptr(acc), 2, L.ptr(out), L.stream())
+        assert abs(float(out[0]) - float(lref)) <= 2e-6 * max(1e-3, float(lref)), (float(out[0]), float(lref))
+        assert float(out[2]) == float(out[0])
+        assert float((gout.cpu() - gref).abs().max()) <= 1e-12 + 1e-6 * float(gref.abs().max())
+        acc2 = torch.zeros(2, device=dev, dtype=torch.float64)      # accumulate=1 adds onto the existing gradient
+        L.call("awr_dense_loss", L.ptr(p), L.ptr(j_), L.ptr(i_), B, J, F, H, ks, 0.01, 0.7, L.ptr(acc2), L.ptr(gout), 1, L.stream())
+        assert float((gout.cpu() - 2 * gref).abs().max()) <= 1e-12 + 1e-6 * float(gref.abs().max())
+
+
+@pytest.mark.parametrize("n", [7, 4096, 1000003])
+def test_adam_and_sgd(dev, n):
+    from awr_amd import _lib as L
+    g0 = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g0); p_ref = p.clone()
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=g0) * 0.01
+        O.adam_update(p_ref, g, m, v, step, lr=1e-3, wd=0.0)
+        L.call("awr_adam_step", L.ptr(pd), DP(L, g, dev), L.ptr(md), L.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, 1.0, L.stream())
+    assert float((pd.cpu() - p_ref).abs().max()) <= 5e-7      # 1 ulp at |p| ~ 4
+    assert float((md.cpu() - m).abs().max()) <= 1e-8 and float((vd.cpu() - v).abs().max()) <= 1e-10
+    # SGD momentum vs torch.optim.SGD
+    q = torch.randn(n, generator=g0).requires_grad_(True)
+    qd, bd = q.detach().clone().to(dev), torch.zeros(n, device=dev)
+    opt = torch.optim.SGD([q], lr=0.01, momentum=0.9)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=g0)
+        q.grad = g.clone(); opt.step()
+        L.call("awr_sgd_step", L.ptr(qd), DP(L, g, dev), L.ptr(bd), n, 0.01, 0.9, 0.0, step, 1.0, L.stream())
+    assert float((qd.cpu() - q.detach()).abs().max()) <= 1e-6
+
+
+def test_errors_are_loud(amd, dev):
+    from awr_amd import _lib as L
+    fm = amd.FeatureModule()
+    with pytest.raises(L.AwrError):
+        fm.joint2offset(torch.zeros(1, 14, 3), torch.zeros(1, 1, 128, 128), 0.4, 64)      # CPU tensors: no fallback
+    with pytest.raises(L.AwrError):
+        fm.joint2offset(torch.zeros(1, 14, 3, device=dev), torch.zeros(1, 1, 128, 128, device=dev), 0.4, 63)  # F % 4 != 0

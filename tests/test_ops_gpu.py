@@ -1,0 +1,277 @@
+"""GPU parity of the backbone building blocks (implicit-GEMM conv family, BatchNorm pieces, pooling,
+layout bridges) through the C ABI, against float64 torch-CPU evaluations of the same operators."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+
+
+def DP(L, t, dev):
+    """device pointer of a host tensor; the device copy is kept alive until the module is torn down
+    (a temporary freed right after data_ptr() would be recycled by the caching allocator)."""
+    d = t.to(dev)
+    _KEEP.append(d)
+    return L.ptr(d)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import awr_amd  # noqa: F401
+    from awr_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def L():
+    import awr_amd  # noqa: F401
+    from awr_amd import _lib
+    return _lib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def rel_err(a, ref):
+    ref = ref.double()
+    return float((a.double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+# kind, cin, cout, k, stride, pad, B, H
+CONV_CASES = [
+    ("conv", 64, 64, 3, 1, 1, 2, 32),
+    ("conv", 64, 128, 3, 2, 1, 3, 20),      # ragged M (not a tile multiple)
+    ("conv", 128, 256, 3, 2, 1, 2, 16),
+    ("conv", 512, 512, 3, 1, 1, 2, 8),      # K = 4608
+    ("conv", 64, 128, 1, 2, 0, 2, 16),      # downsample 1x1 s2
+    ("conv", 256, 64, 1, 1, 0, 2, 16),
+    ("conv", 128, 128, 3, 1, 1, 5, 4),      # tiny spatial (hourglass bottom)
+    ("deconv", 128, 64, 4, 2, 1, 2, 8),
+    ("deconv", 512, 256, 4, 2, 1, 1, 8),
+]
+
+
+def _torch_fwd(kind, x, w, b, stride, pad):
+    return (TF.conv2d if kind == "conv" else TF.conv_transpose2d)(x, w, b, stride, pad)
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, H):
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w = rnd(*wshape, seed=1, scale=(cin * k * k) ** -0.5)
+    x = rnd(B, cin, H, H, seed=2)
+    bias = rnd(cout, seed=3)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = _torch_fwd(kind, xd, wd, bias.double(), stride, pad)
+    gy = rnd(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [xd, wd], gy.double())
+
+    wg = w.to(dev)
+    wp = ops.pack_weight(wg, spec.fwd_pack())
+    y = ops.conv_forward(spec, ops.nhwc(x).to(dev), wp, bias=bias.to(dev))
+    # fp32 MFMA == k-ordered fmaf chain: rounding error grows ~ sqrt(K) * 2^-24 relative to the row scale
+    tol = 5e-6
+    assert rel_err(ops.nchw(y).cpu(), y_ref.detach()) < tol
+    wpd = ops.pack_weight(wg, spec.dgrad_pack())
+    gx = ops.conv_dgrad(spec, ops.nhwc(gy).to(dev), wpd, H, H)
+    assert rel_err(ops.nchw(gx).cpu(), gx_ref) < tol
+    gw = ops.conv_wgrad(spec, ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev))
+    assert rel_err(gw.cpu(), gw_ref) < 1e-5
+    # accumulate paths: dgrad onto an existing gradient, wgrad onto an existing gradient
+    base = rnd(B, cin, H, H, seed=5)
+    acc = ops.nhwc(base).to(dev)
+    ops.conv_dgrad(spec, ops.nhwc(gy).to(dev), wpd, H, H, out=acc, res=acc)
+    assert rel_err(ops.nchw(acc).cpu(), gx_ref + base.double()) < tol
+    gw2 = ops.conv_wgrad(spec, ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev), grad=gw.clone(), accumulate=True)
+    assert rel_err(gw2.cpu(), 2 * gw_ref) < 1e-5
+
+
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
+                                                              ("deconv", 64, 96, 4, 2, 1, 3, 10)])
+def test_conv_every_tile_shape(ops, L, dev, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """All four workgroup tiles (64/128 x 64/128) on ragged M and N (not multiples of any tile)."""
+    L.call("awr_debug_force_tile", tm, tn)
+    try:
+        test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, H)
+    finally:
+        L.call("awr_debug_force_tile", 0, 0)
+
+
+def test_conv_fused_prologue_epilogue_stats(ops, dev):
+    """conv( relu(x*s+t) ) * so + to + res -> relu, with per-channel statistics of the pre-ReLU value."""
+    B, H, cin, cout = 2, 16, 64, 96           # N = 96: not a multiple of the 64/128 tile
+    spec = ops.ConvSpec("conv", cin, cout, 3, 1, 1)
+    x, w = rnd(B, cin, H, H, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    s, t = rnd(cin, seed=3) + 1.5, rnd(cin, seed=4)
+    so, to, bias = rnd(cout, seed=5) + 1.5, rnd(cout, seed=6), rnd(cout, seed=7)
+    res = rnd(B, cout, H, H, seed=8)
+    a = TF.relu(x.double() * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1))
+    pre = (TF.conv2d(a, w.double(), bias.double(), 1, 1)) * so.double().view(1, -1, 1, 1) + to.double().view(1, -1, 1, 1) + res.double()
+    ref = TF.relu(pre)
+    stats = torch.zeros(2, cout, device=dev, dtype=torch.float64)
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    y = ops.conv_forward(spec, ops.nhwc(x).to(dev), wp, in_scale=s.to(dev), in_shift=t.to(dev), relu_in=True, bias=bias.to(dev),
+                         out_scale=so.to(dev), out_shift=to.to(dev), res=ops.nhwc(res).to(dev), relu_out=True, stats=stats)
+    assert rel_err(ops.nchw(y).cpu(), ref) < 2e-6
+    assert rel_err(stats[0].cpu(), pre.sum((0, 2, 3))) < 1e-5
+    assert rel_err(stats[1].cpu(), (pre * pre).sum((0, 2, 3))) < 1e-5
+
+
+def test_stem_im2col_gemm(ops, L, dev):
+    """5x5 stem (Cin=1) as im2col + the same MFMA GEMM; forward and weight gradient."""
+    B, H = 2, 32
+    img, w = rnd(B, 1, H, H, seed=1), rnd(64, 1, 5, 5, seed=2, scale=0.2)
+    wd = w.double().requires_grad_(True)
+    ref = TF.conv2d(img.double(), wd, None, 1, 2)
+    gy = rnd(*ref.shape, seed=3)
+    (gw_ref,) = torch.autograd.grad(ref, wd, gy.double())
+    cols = torch.empty(B, H, H, 32, device=dev)
+    L.call("awr_stem_im2col", DP(L, img, dev), B, H, H, L.ptr(cols), L.stream())
+    spec = ops.ConvSpec("conv", 25, 64, 1, 1, 0, cin_pad=32)
+    wp = ops.pack_weight(w.to(dev).view(64, 25, 1, 1), spec.fwd_pack())
+    y = ops.conv_forward(spec, cols, wp)
+    assert rel_err(ops.nchw(y).cpu(), ref.detach()) < 2e-6
+    gw = ops.conv_wgrad(spec, cols, ops.nhwc(gy).to(dev))
+    assert rel_err(gw.cpu().view(64, 1, 5, 5), gw_ref) < 5e-6
+
+
+@pytest.mark.parametrize("B,H,C", [(2, 16, 64), (3, 10, 96), (2, 8, 512), (4, 32, 128)])
+def test_batchnorm_train_forward_backward(L, dev, B, H, C):
+    x = rnd(B, C, H, H, seed=1) * 2 + 0.3
+    gamma, beta = rnd(C, seed=2) + 1.5, rnd(C, seed=3)
+    res = rnd(B, C, H, H, seed=4)
+    rm, rv = rnd(C, seed=5), rnd(C, seed=6) + 1.5
+    xd, gd, bd = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y_ref = TF.relu(TF.batch_norm(xd, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5) + res.double())
+    gout = rnd(B, C, H, H, seed=7)
+    gx_ref, gg_ref, gb_ref = torch.autograd.grad(y_ref, [xd, gd, bd], gout.double())
+
+    from awr_amd import ops
+    npix = B * H * H
+    xg = ops.nhwc(x).to(dev)
+    stats = torch.zeros(2, C, device=dev, dtype=torch.float64)
+    L.call("awr_channel_stats", L.ptr(xg), npix, C, L.ptr(stats), L.stream())
+    scale, shift, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
+    rmg, rvg = rm.to(dev), rv.to(dev)
+    L.call("awr_bn_finalize", L.ptr(stats), C, npix, DP(L, gamma, dev), DP(L, beta, dev), L.ptr(rmg), L.ptr(rvg), 0.1, 1e-5,
+           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.stream())
+    assert float(stats.abs().max()) == 0.0          # finalize re-arms the accumulator
+    out = torch.empty_like(xg)
+    resg = ops.nhwc(res).to(dev)
+    L.call("awr_bn_apply", L.ptr(xg), L.ptr(scale), L.ptr(shift), L.ptr(resg), 1, L.ptr(out), npix, C, L.stream())
+    assert rel_err(ops.nchw(out).cpu(), y_ref.detach()) < 3e-6
+    assert rel_err(rmg.cpu(), rm_ref) < 1e-6 and rel_err(rvg.cpu(), rv_ref) < 1e-6
+    # backward
+    sums = torch.zeros(2, C, device=dev, dtype=torch.float64)
+    goutg = ops.nhwc(gout).to(dev)
+    L.call("awr_bn_bwd_reduce", L.ptr(goutg), L.ptr(out), L.ptr(xg), L.ptr(mean), L.ptr(invstd), npix, C, L.ptr(sums), L.stream())
+    dy, g = torch.empty_like(xg), torch.empty_like(xg)
+    dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    L.call("awr_bn_bwd_apply", L.ptr(goutg), L.ptr(out), L.ptr(xg), L.ptr(mean), L.ptr(invstd), DP(L, gamma, dev), L.ptr(sums), npix, C,
+           L.ptr(dy), None, L.ptr(g), L.ptr(dgam), L.ptr(dbet), 0, L.stream())
+    assert rel_err(ops.nchw(dy).cpu(), gx_ref) < 2e-5
+    assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
+    assert rel_err(ops.nchw(g).cpu(), gout.double() * (y_ref.detach() > 0)) < 1e-6
+    assert float(sums.abs().max()) == 0.0
+
+
+def test_bn_fold_eval(L, dev):
+    C = 64
+    g, b, m, v = rnd(C, seed=1) + 1.5, rnd(C, seed=2), rnd(C, seed=3), rnd(C, seed=4) + 1.5
+    sc, sh = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    L.call("awr_bn_fold_eval", C, DP(L, g, dev), DP(L, b, dev), DP(L, m, dev), DP(L, v, dev), 1e-5, L.ptr(sc), L.ptr(sh), L.stream())
+    x = rnd(2, C, 4, 4, seed=5)
+    ref = TF.batch_norm(x.double(), m.double(), v.double(), g.double(), b.double(), False, 0.1, 1e-5)
+    got = x.to(dev) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    assert rel_err(got.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("k,s,p,B,H,C", [(3, 2, 1, 2, 16, 64), (2, 2, 0, 3, 8, 128), (3, 2, 1, 1, 128, 64)])
+def test_maxpool(L, dev, k, s, p, B, H, C):
+    from awr_amd import ops
+    x = rnd(B, C, H, H, seed=1)
+    x[:, :, ::3, ::3] = 0.0
+    x = TF.relu(x)            # many exact ties at 0, like the post-ReLU stem output
+    xd = x.double().requires_grad_(True)
+    ref = TF.max_pool2d(xd, k, s, p)
+    gout = rnd(*ref.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(ref, xd, gout.double())
+    Ho = ref.shape[-1]
+    xg = ops.nhwc(x).to(dev)
+    out = torch.empty(B, Ho, Ho, C, device=dev)
+    arg = torch.empty(B, Ho, Ho, C, device=dev, dtype=torch.uint8)
+    L.call("awr_maxpool_fwd", L.ptr(xg), B, H, H, C, k, s, p, L.ptr(out), L.ptr(arg), L.stream())
+    assert rel_err(ops.nchw(out).cpu(), ref.detach()) == 0.0
+    dx = torch.empty_like(xg)
+    L.call("awr_maxpool_bwd", DP(L, ops.nhwc(gout), dev), L.ptr(arg), B, H, H, C, k, s, p, L.ptr(dx), 0, L.stream())
+    got = ops.nchw(dx).cpu().double()
+    # ties: ATen and this kernel both route to the first maximum in scan order
+    assert rel_err(got, gx_ref) < 1e-6
+    L.call("awr_maxpool_bwd", DP(L, ops.nhwc(gout), dev), L.ptr(arg), B, H, H, C, k, s, p, L.ptr(dx), 1, L.stream())
+    assert rel_err(ops.nchw(dx).cpu(), 2 * gx_ref) < 1e-6
+
+
+def test_upsample_add_and_misc(L, dev):
+    from awr_amd import ops
+    B, Hl, C = 2, 8, 64
+    up1, low = rnd(B, C, 2 * Hl, 2 * Hl, seed=1), rnd(B, C, Hl, Hl, seed=2)
+    ref = up1 + TF.interpolate(low, scale_factor=2, mode="nearest")
+    out = torch.empty(B, 2 * Hl, 2 * Hl, C, device=dev)
+    L.call("awr_upsample2_add", DP(L, ops.nhwc(up1), dev), DP(L, ops.nhwc(low), dev), B, Hl, Hl, C, L.ptr(out), L.stream())
+    assert rel_err(ops.nchw(out).cpu(), ref) < 1e-7
+    gout = rnd(B, C, 2 * Hl, 2 * Hl, seed=3)
+    dlow = torch.empty(B, Hl, Hl, C, device=dev)
+    L.call("awr_upsample2_bwd", DP(L, ops.nhwc(gout), dev), B, Hl, Hl, C, L.ptr(dlow), 0, L.stream())
+    ref_d = gout.view(B, C, Hl, 2, Hl, 2).sum((3, 5))
+    assert rel_err(ops.nchw(dlow).cpu(), ref_d) < 1e-6
+    # relu_bwd / add / bias_grad
+    a, d = rnd(B, Hl, Hl, C, seed=4), rnd(B, Hl, Hl, C, seed=5)
+    g = torch.empty(B, Hl, Hl, C, device=dev)
+    L.call("awr_relu_bwd", DP(L, d, dev), DP(L, a, dev), L.ptr(g), a.numel(), L.stream())
+    assert rel_err(g.cpu(), d * (a > 0)) == 0.0
+    L.call("awr_add", DP(L, d, dev), DP(L, a, dev), L.ptr(g), a.numel(), L.stream())
+    assert rel_err(g.cpu(), d + a) == 0.0
+    db = torch.empty(C, device=dev)
+    L.call("awr_bias_grad", DP(L, d, dev), B * Hl * Hl, C, L.ptr(db), 0, L.stream())
+    assert rel_err(db.cpu(), d.double().sum((0, 1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("B,P,C,Cp", [(2, 4096, 56, 64), (1, 16384, 84, 96), (3, 100, 56, 64)])
+def test_layout_bridges(L, dev, B, P, C, Cp):
+    x = rnd(B, P, Cp, seed=1)
+    out = torch.empty(B, C, P, device=dev)
+    L.call("awr_nhwc_to_nchw", DP(L, x, dev), B, P, Cp, C, L.ptr(out), L.stream())
+    assert torch.equal(out.cpu(), x[:, :, :C].permute(0, 2, 1).contiguous())
+    back = torch.full((B, P, Cp), 7.0, device=dev)
+    L.call("awr_nchw_to_nhwc", L.ptr(out), B, P, Cp, C, L.ptr(back), L.stream())
+    exp = x.clone()
+    exp[:, :, C:] = 0.0
+    assert torch.equal(back.cpu(), exp)
+
+
+def test_pack_unpack_roundtrip(ops, L, dev):
+    w = rnd(96, 64, 3, 3, seed=1)
+    spec = ops.ConvSpec("conv", 64, 96, 3, 1, 1)
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    assert wp.shape == (128, 9, 64)
+    assert torch.equal(wp[:96].cpu(), w.view(96, 64, 9).permute(0, 2, 1).contiguous())
+    assert float(wp[96:].abs().max()) == 0.0
+    g = torch.empty(96, 64, 3, 3, device=dev)
+    L.call("awr_unpack_wgrad", L.ptr(wp), 96, 64, 9, 64, L.ptr(g), 0, L.stream())
+    assert torch.equal(g.cpu(), w)
+    wpt = ops.pack_weight(w.to(dev), spec.dgrad_pack())
+    assert torch.equal(wpt[:64, :, :96].cpu(), w.view(96, 64, 9).permute(1, 2, 0).contiguous())
