@@ -1,0 +1,397 @@
+"""Static execution plans for the AWR backbones on libawr_hip.so.
+
+A `Plan` is built once per (network, batch, image size, mode).  Building it walks the network
+description (resnet_deconv.py / hourglass.py), allocates every activation / gradient buffer in HBM
+up front and records two flat lists of pre-bound C-ABI calls: `fwd_ops` and `bwd_ops`.  Running a
+plan is just replaying a list of ctypes calls on the current HIP stream -- no allocation, no Python
+graph walking, no host synchronisation -- so a whole train step can be captured in one hipGraph.
+
+The backward list is derived at build time by walking the recorded nodes in reverse (a tiny static
+autograd): every node knows how to emit the kernels of its own gradient, and `Plan._gtarget`
+decides whether a contribution writes a fresh gradient buffer or accumulates into an existing one.
+Identity skip connections alias the upstream gradient buffer instead of copying it.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, N_ALIGN
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class T:
+    """Plan-time tensor handle: an NHWC fp32 buffer plus (later) its gradient buffer."""
+    __slots__ = ("buf", "grad", "needs_grad", "stats", "name")
+
+    def __init__(self, buf, needs_grad=True, name=""):
+        self.buf, self.grad, self.needs_grad, self.stats, self.name = buf, None, needs_grad, None, name
+
+    @property
+    def shape(self):
+        return tuple(self.buf.shape)
+
+    @property
+    def npix(self):
+        s = self.buf.shape
+        return s[0] * s[1] * s[2]
+
+
+class ConvLayer:
+    """One nn.Conv2d / nn.ConvTranspose2d of the checkpoint: weight (+bias) views in the parameter
+    arena, gradient views in the gradient arena, packed GEMM copies of the weight."""
+
+    def __init__(self, spec, w, gw, bias=None, gbias=None, name=""):
+        self.spec, self.w, self.gw, self.bias, self.gbias, self.name = spec, w, gw, bias, gbias, name
+        self.p_fwd = self.p_dgrad = None
+
+    def alloc_packed(self, need_dgrad):
+        dev = self.w.device
+        if self.p_fwd is None:
+            _, _, T_, _, rows, ld = self.spec.fwd_pack()
+            self.p_fwd = torch.empty(rows, T_, ld, device=dev, dtype=torch.float32)
+        if need_dgrad and self.p_dgrad is None:
+            _, _, T_, _, rows, ld = self.spec.dgrad_pack()
+            self.p_dgrad = torch.empty(rows, T_, ld, device=dev, dtype=torch.float32)
+
+    def pack_calls(self):
+        """(fn, args) tuples that refresh the packed copies from the arena."""
+        calls = []
+        for recipe, dst in ((self.spec.fwd_pack(), self.p_fwd), (self.spec.dgrad_pack(), self.p_dgrad)):
+            if dst is not None:
+                d0, d1, T_, tr, rows, ld = recipe
+                calls.append(("awr_pack_weight", (L.ptr(self.w), d0, d1, T_, tr, rows, ld, L.ptr(dst))))
+        return calls
+
+    def bias_ptr(self):
+        return self.bias
+
+    def wgrad_unpack_calls(self, R, ld):
+        prob_d0, prob_d1 = (self.spec.cout, self.spec.cin) if self.spec.kind == "conv" else (self.spec.cin, self.spec.cout)
+        return [("awr_unpack_wgrad", (L.ptr(R), prob_d0, prob_d1, self.spec.T, ld, L.ptr(self.gw), 0))]
+
+    def bias_grad_target(self):
+        return self.gbias
+
+
+class HeadLayer(ConvLayer):
+    """final1 (256->3J) and final2 (256->J) 1x1 convs fused into one 256->Cp GEMM (Cp = 4J rounded up
+    to 32; extra rows are zero).  resnet_deconv.py:52-53,:133-136 / hourglass.py:137-138,:153-157."""
+
+    def __init__(self, cin, J, w1, gw1, b1, gb1, w2, gw2, b2, gb2, name=""):
+        self.J, self.cin = J, cin
+        self.cp = round_up(4 * J, 32)
+        spec = ConvSpec("conv", cin, 4 * J, 1, 1, 0, cout_pad=self.cp)
+        super().__init__(spec, w1, gw1, None, None, name)
+        self.w1, self.gw1, self.b1, self.gb1, self.w2, self.gw2, self.b2, self.gb2 = w1, gw1, b1, gb1, w2, gw2, b2, gb2
+        self.bias_cat = torch.zeros(self.cp, device=w1.device, dtype=torch.float32)
+        self.gbias_cat = torch.zeros(self.cp, device=w1.device, dtype=torch.float32)
+
+    def pack_calls(self):
+        J, cin = self.J, self.cin
+        calls = []
+        rows = self.p_fwd.shape[0]
+        calls.append(("awr_pack_weight", (L.ptr(self.w1), 3 * J, cin, 1, 0, 3 * J, cin, self.p_fwd.data_ptr())))
+        calls.append(("awr_pack_weight", (L.ptr(self.w2), J, cin, 1, 0, rows - 3 * J, cin, self.p_fwd.data_ptr() + 3 * J * cin * 4)))
+        if self.p_dgrad is not None:   # P[cin][1][cp]: columns [0,3J) from w1, [3J,4J) from w2 -> pack into a (cp, cin) staging then transpose
+            calls.append(("awr_pack_weight", (self.p_fwd.data_ptr(), self.cp, cin, 1, 1, self.p_dgrad.shape[0], self.cp, L.ptr(self.p_dgrad))))
+        calls.append(("__copy__", (self.bias_cat[:3 * J], self.b1)))
+        calls.append(("__copy__", (self.bias_cat[3 * J:4 * J], self.b2)))
+        return calls
+
+    def bias_ptr(self):
+        return self.bias_cat
+
+    def wgrad_unpack_calls(self, R, ld):
+        J, cin = self.J, self.cin
+        return [("awr_unpack_wgrad", (R.data_ptr(), 3 * J, cin, 1, ld, L.ptr(self.gw1), 0)),
+                ("awr_unpack_wgrad", (R.data_ptr() + 3 * J * ld * 4, J, cin, 1, ld, L.ptr(self.gw2), 0))]
+
+    def bias_grad_target(self):
+        return self.gbias_cat
+
+    def bias_grad_post(self):
+        J = self.J
+        return [("__copy__", (self.gb1, self.gbias_cat[:3 * J])), ("__copy__", (self.gb2, self.gbias_cat[3 * J:4 * J]))]
+
+
+class BNLayer:
+    def __init__(self, C_, gamma, beta, ggamma, gbeta, rmean, rvar, counter, name=""):
+        self.C, self.gamma, self.beta, self.ggamma, self.gbeta = C_, gamma, beta, ggamma, gbeta
+        self.rmean, self.rvar, self.counter, self.name = rmean, rvar, counter, name
+
+
+class Plan:
+    def __init__(self, B, device, training, need_input_grad=False, bn_repeat=1):
+        self.B, self.dev, self.training = B, device, training
+        self.fwd_ops, self.bwd_ops, self.pack_ops = [], [], []
+        self.nodes = []             # backward emitters, in forward order
+        self.layers = []            # ConvLayers whose packed copies this plan refreshes
+        self.bns = []               # BNLayers updated by a training forward (for the counters)
+        self.bn_repeat = bn_repeat  # hourglass quirk: the reference runs `stacks` forwards per step (train.py:116-117)
+        self.outputs = []           # (nchw_out_buffer, nhwc_T, layer) per stage
+        self.grad_outs = []         # NCHW gradient input buffers per stage
+        self.bytes = 0
+        self._built_bwd = False
+        self._bufs = []
+        self._keep = []             # ctypes argument structs referenced by the op lists
+        self._head_states = []
+
+    # ---- allocation -----------------------------------------------------------------------------------
+    def alloc(self, *shape, dtype=torch.float32, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
+        self.bytes += t.numel() * t.element_size()
+        self._bufs.append(t)        # the op lists hold raw device pointers: the plan owns every buffer for its lifetime
+        return t
+
+    def new(self, B, H, W, C_, needs_grad=True, name=""):
+        return T(self.alloc(B, H, W, C_), needs_grad, name)
+
+    def _f(self, name, *args):
+        self.fwd_ops.append((getattr(L.lib, name), args + (None,), name))
+
+    def _b(self, name, *args):
+        self.bwd_ops.append((getattr(L.lib, name), args + (None,), name))
+
+    def _gtarget(self, t):
+        """-> (gradient buffer, accumulate?)  and marks the gradient as live."""
+        if t.grad is None:
+            t.grad = self.alloc(*t.shape)
+            return t.grad, False
+        return t.grad, True
+
+    def _contribute_identity(self, t, src_grad):
+        """grad(t) += src_grad where src_grad is a finished gradient buffer: alias when first."""
+        if not t.needs_grad:
+            return
+        if t.grad is None:
+            t.grad = src_grad
+        else:
+            self._b("awr_add", L.ptr(t.grad), L.ptr(src_grad), L.ptr(t.grad), t.grad.numel())
+
+    def use_layer(self, layer):
+        if layer not in self.layers:
+            layer.alloc_packed(need_dgrad=self.training)
+            self.layers.append(layer)
+
+    # ---- ops -------------------------------------------------------------------------------------------
+    def im2col5(self, img_buf, H, W):
+        """Stem im2col of the (B,1,H,W) depth image (== (B,H,W,1)); no gradient flows to the image."""
+        cols = self.new(self.B, H, W, 32, needs_grad=False, name="stem_cols")
+        self._f("awr_stem_im2col", L.ptr(img_buf), self.B, H, W, L.ptr(cols.buf))
+        return cols
+
+    def conv(self, x, layer, in_affine=None, relu_in=False, out_affine=None, res=None, relu_out=False, want_stats=False,
+             use_bias=True):
+        """y = conv(x) [+bias] [*s+t] [+res] [relu].  in_affine/out_affine: (scale, shift) device vectors."""
+        self.use_layer(layer)
+        spec = layer.spec
+        B, H, W, _ = x.shape
+        prob = spec.fwd_problem(H, W)
+        assert prob["full"], "forward transposed conv must cover all phases"
+        y = self.new(B, prob["Hout"], prob["Wout"], prob["N"], name=layer.name + ".out")
+        if want_stats:
+            y.stats = self.alloc(2, prob["N"], dtype=torch.float64, zero=True)
+        bias = layer.bias_ptr() if use_bias else None
+        a = make_conv_args(prob, B, x.buf, layer.p_fwd, y.buf, in_scale=in_affine[0] if in_affine else None,
+                           in_shift=in_affine[1] if in_affine else None, bias=bias,
+                           out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
+                           res=res.buf if res is not None else None, stats=y.stats, relu_in=relu_in, relu_out=relu_out, T=spec.T)
+        self.fwd_ops.append((L.lib.awr_conv_gemm, (C.byref(a), None), "awr_conv_gemm:" + layer.name))
+        self._keep.append(a)
+        if self.training:
+            assert in_affine is None and out_affine is None and not relu_in and not relu_out, "fused affine/ReLU are inference-only"
+            self.nodes.append(lambda: self._conv_bwd(x, y, layer, res, bias is not None))
+        return y
+
+    def _conv_bwd(self, x, y, layer, res, has_bias):
+        spec = layer.spec
+        B, H, W, _ = x.shape
+        dy = y.grad
+        assert dy is not None, "no gradient reached %s" % y.name
+        if has_bias:
+            tgt = layer.bias_grad_target()
+            self._b("awr_bias_grad", L.ptr(dy), y.npix, y.shape[3], L.ptr(tgt), 0)
+            if hasattr(layer, "bias_grad_post"):
+                for _, (dst, src) in layer.bias_grad_post():
+                    self.bwd_ops.append((None, (dst, src), "__copy__"))
+        # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
+        wp = spec.wgrad_problem(H, W)
+        ld = wp["Cg"]
+        R = self.alloc(wp["Cd"], len(wp["taps"]), ld)
+        D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
+        wa = make_wgrad_args(wp, B, D, G, R, ld)
+        self._keep.append(wa)
+        self.bwd_ops.append((None, (R,), "__zero__"))
+        self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
+        for name, args in layer.wgrad_unpack_calls(R, ld):
+            self._b(name, *args)
+        # data gradient
+        if x.needs_grad:
+            dp = spec.dgrad_problem(H, W)
+            gx, acc = self._gtarget(x)
+            if not dp["full"] and not acc:
+                self.bwd_ops.append((None, (gx,), "__zero__"))
+                acc = True
+            da = make_conv_args(dp, B, dy, layer.p_dgrad, gx, res=gx if acc else None, T=spec.T)
+            self._keep.append(da)
+            self.bwd_ops.append((L.lib.awr_conv_gemm, (C.byref(da), None), "awr_conv_dgrad:" + layer.name))
+        if res is not None:
+            self._contribute_identity(res, dy)
+
+    def fold_bn(self, bn):
+        """Inference: per-channel (scale, shift) of an eval-mode BatchNorm, refreshed with the weights."""
+        sc, sh = self.alloc(bn.C), self.alloc(bn.C)
+        self.pack_ops.append((L.lib.awr_bn_fold_eval, (bn.C, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), BN_EPS,
+                                                        L.ptr(sc), L.ptr(sh), None), "awr_bn_fold_eval"))
+        return sc, sh
+
+    def bn_act(self, y, bn, relu, res=None):
+        """Training-mode BatchNorm (+residual) (+ReLU): a = [relu](bn(y) [+ res])."""
+        assert self.training
+        B, H, W, C_ = y.shape
+        if y.stats is None:
+            y.stats = self.alloc(2, C_, dtype=torch.float64, zero=True)
+            self._f("awr_channel_stats", L.ptr(y.buf), y.npix, C_, L.ptr(y.stats))
+            own_stats = y.stats
+        else:
+            own_stats = y.stats
+        # several BNs may normalise the same tensor (hourglass): finalize zeroes the accumulator, so keep a copy
+        y.stats = None
+        sc, sh, mean, invstd = (self.alloc(C_) for _ in range(4))
+        mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
+        self._f("awr_bn_finalize", L.ptr(own_stats), C_, y.npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom,
+                BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd))
+        self.bns.append(bn)
+        a = self.new(B, H, W, C_, name=bn.name + ".act")
+        self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
+                y.npix, C_)
+        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd))
+        return a
+
+    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd):
+        da = a.grad
+        assert da is not None, "no gradient reached %s" % a.name
+        C_ = y.shape[3]
+        sums = self.alloc(2, C_, dtype=torch.float64, zero=True)
+        act = L.ptr(a.buf) if relu else None
+        self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), y.npix, C_, L.ptr(sums))
+        gy, acc = self._gtarget(y) if y.needs_grad else (self.alloc(*y.shape), False)
+        g_out, post_add = None, None
+        if res is not None and res.needs_grad:
+            if relu:
+                if res.grad is None:
+                    res.grad = self.alloc(*res.shape)
+                    g_out = res.grad
+                else:
+                    g_out = self.alloc(*res.shape)
+                    post_add = g_out
+            else:
+                pass  # handled below: identity of da
+        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), L.ptr(sums), y.npix, C_,
+                L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
+        if post_add is not None:
+            self._b("awr_add", L.ptr(res.grad), L.ptr(post_add), L.ptr(res.grad), post_add.numel())
+        if res is not None and res.needs_grad and not relu:
+            self._contribute_identity(res, da)
+
+    def maxpool(self, x, k, s, p):
+        B, H, W, C_ = x.shape
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = self.new(B, Ho, Wo, C_, name=x.name + ".pool")
+        arg = self.alloc(B, Ho, Wo, C_, dtype=torch.uint8) if self.training else None
+        self._f("awr_maxpool_fwd", L.ptr(x.buf), B, H, W, C_, k, s, p, L.ptr(y.buf), L.ptr(arg))
+        if self.training:
+            def bwd():
+                if not x.needs_grad:
+                    return
+                gx, acc = self._gtarget(x)
+                self._b("awr_maxpool_bwd", L.ptr(y.grad), L.ptr(arg), B, H, W, C_, k, s, p, L.ptr(gx), int(acc))
+            self.nodes.append(bwd)
+        return y
+
+    def upsample_add(self, up1, low):
+        """out = up1 + nearest_upsample_x2(low)   (hourglass.py:77,:88)"""
+        B, Hl, Wl, C_ = low.shape
+        y = self.new(B, 2 * Hl, 2 * Wl, C_, name=up1.name + ".upadd")
+        self._f("awr_upsample2_add", L.ptr(up1.buf), L.ptr(low.buf), B, Hl, Wl, C_, L.ptr(y.buf))
+        if self.training:
+            def bwd():
+                gl, acc = self._gtarget(low)
+                self._b("awr_upsample2_bwd", L.ptr(y.grad), B, Hl, Wl, C_, L.ptr(gl), int(acc))
+                self._contribute_identity(up1, y.grad)
+            self.nodes.append(bwd)
+        return y
+
+    def head_out(self, pred, J):
+        """NHWC (B,F,F,Cp) dense map -> the reference's NCHW (B,4J,F,F) tensor (+ gradient bridge)."""
+        B, F, _, Cp = pred.shape
+        out = self.alloc(B, 4 * J, F, F)
+        self._f("awr_nhwc_to_nchw", L.ptr(pred.buf), B, F * F, Cp, 4 * J, L.ptr(out))
+        gout = None
+        if self.training:
+            gout = self.alloc(B, 4 * J, F, F, zero=True)
+            state = {"used": False}
+
+            def bwd():
+                if not state["used"]:
+                    return            # no loss on this stage (hourglass: only the last stage is supervised, train.py:116-121)
+                g, acc = self._gtarget(pred)
+                if acc:
+                    tmp = self.alloc(*pred.shape)
+                    self._b("awr_nchw_to_nhwc", L.ptr(gout), B, F * F, Cp, 4 * J, L.ptr(tmp))
+                    self._b("awr_add", L.ptr(g), L.ptr(tmp), L.ptr(g), g.numel())
+                else:
+                    self._b("awr_nchw_to_nhwc", L.ptr(gout), B, F * F, Cp, 4 * J, L.ptr(g))
+            self.nodes.append(bwd)
+            self._head_states.append(state)
+        self.outputs.append(out)
+        self.grad_outs.append(gout)
+        return out
+
+    # ---- finishing ------------------------------------------------------------------------------------------
+    def build_backward(self, supervised_stages):
+        assert self.training and not self._built_bwd
+        for i, st in enumerate(self._head_states):
+            st["used"] = i in supervised_stages
+        for emit in reversed(self.nodes):
+            emit()
+        self._built_bwd = True
+
+    def refresh_weights(self):
+        """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena."""
+        s = L.stream()
+        for layer in self.layers:
+            for name, args in layer.pack_calls():
+                if name == "__copy__":
+                    args[0].copy_(args[1])
+                else:
+                    L.check(getattr(L.lib, name)(*args, s), name)
+        for fn, args, name in self.pack_ops:
+            L.check(fn(*args[:-1], s), name)
+
+    @staticmethod
+    def _run(ops):
+        s = L.stream()
+        for fn, args, name in ops:
+            if fn is None:
+                if name == "__zero__":
+                    args[0].zero_()
+                else:
+                    args[0].copy_(args[1])
+                continue
+            rc = fn(*args[:-1], s)
+            if rc != 0:
+                raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
+
+    def forward(self):
+        self._run(self.fwd_ops)
+        if self.training:
+            for bn in self.bns:
+                bn.counter += self.bn_repeat
+
+    def backward(self):
+        assert self._built_bwd
+        self._run(self.bwd_ops)

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/awr_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import awr_amd  # noqa: F401
+    from awr_amd import build
+    if not os.path.exists(build.LIB):
+        build.build_lib(verbose=False)
+    from awr_amd import _lib
+    return _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "awr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(awr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    assert not lib.MISSING, lib.MISSING
+    for s in syms:
+        assert hasattr(lib.lib, s), "libawr_hip.so does not export %s" % s
+        assert s in lib.EXPORTS, "%s is declared in the header but not bound in _lib.py" % s
+    for s in lib.EXPORTS:
+        assert s in syms, "%s is bound but not declared in include/awr_hip.h" % s
+
+
+def test_version_and_error_string(lib):
+    assert lib.lib.awr_version() >= 100
+    assert isinstance(lib.last_error(), str)
+
+
+def test_argument_validation_without_gpu(lib):
+    # argument checks run before any HIP call, so they are testable on a CPU-only box
+    rc = lib.lib.awr_head_forward(None, None, 1, 14, 63, 128, 0.4, None, None, None)
+    assert rc == -1 and "F % 4" in lib.last_error()
+    rc = lib.lib.awr_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None)
+    assert rc == -1
+    rc = lib.lib.awr_debug_force_tile(3, 1)
+    assert rc == -1
+    assert lib.lib.awr_debug_force_tile(0, 0) == 0
+
+
+def test_struct_layout_matches_header(lib):
+    import ctypes as C
+    # awr_phase: 3 ints + 3x16 int8 = 60 bytes; awr_conv_args: 10 pointers + 15 ints + 4 phases
+    assert C.sizeof(lib.Phase) == 60
+    assert C.sizeof(lib.ConvArgs) == 10 * 8 + 15 * 4 + 4 * 60 + 4   # trailing pad to 8-byte alignment
+    assert C.sizeof(lib.WgradArgs) == 3 * 8 + 10 * 4 + 32
+
+
+def test_product_path_fails_loudly_on_cpu_tensors(lib):
+    import torch
+    import awr_amd
+    with pytest.raises(lib.AwrError):
+        awr_amd.FeatureModule().offset2joint_softmax(torch.zeros(1, 56, 64, 64), torch.zeros(1, 1, 128, 128), 0.4)
+    net = awr_amd.get_deconv_net(18, 14, 2)
+    with pytest.raises(lib.AwrError):
+        net(torch.zeros(1, 1, 128, 128))

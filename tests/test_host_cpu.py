@@ -1,0 +1,145 @@
+"""CPU: host-side logic -- conv geometry / tap tables (emulated gather-GEMM vs torch convs),
+weight packing recipes, checkpoint layout and arena plumbing of the drop-in modules."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import awr_oracle as O
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import awr_amd
+    return awr_amd
+
+
+def emulate_pack(w, recipe):
+    d0, d1, T, tr, rows, ld = recipe
+    w3 = w.reshape(d0, d1, T)
+    out = torch.zeros(rows, T, ld, dtype=w.dtype)
+    if tr:
+        out[:d1, :, :d0] = w3.permute(1, 2, 0)
+    else:
+        out[:d0, :, :d1] = w3.permute(0, 2, 1)
+    return out
+
+
+def emulate_gemm(prob, x, wp):
+    """Pure-torch statement of awr_conv_gemm's contract (include/awr_hip.h): x NHWC, wp [n][T][Cin]."""
+    B = x.shape[0]
+    out = torch.zeros(B, prob["Hout"], prob["Wout"], prob["N"], dtype=x.dtype)
+    xp = x
+    for py, px, taps in prob["phases"]:
+        for qy in range(prob["Hq"]):
+            for qx in range(prob["Wq"]):
+                acc = torch.zeros(B, prob["N"], dtype=x.dtype)
+                for dy, dx, wt in taps:
+                    iy, ix = qy * prob["si"] + dy, qx * prob["si"] + dx
+                    if 0 <= iy < prob["Hin"] and 0 <= ix < prob["Win"]:
+                        acc += xp[:, iy, ix, :] @ wp[:prob["N"], wt, :].T
+                out[:, qy * prob["so"] + py, qx * prob["so"] + px, :] = acc
+    return out
+
+
+CASES = [("conv", 4, 6, 3, 1, 1, 6), ("conv", 4, 6, 3, 2, 1, 8), ("conv", 4, 6, 1, 2, 0, 8), ("conv", 4, 6, 1, 1, 0, 5),
+         ("conv", 3, 5, 5, 1, 2, 7), ("deconv", 4, 6, 4, 2, 1, 4)]
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,H", CASES)
+def test_geometry_forward_and_dgrad(amd, kind, cin, cout, k, s, p, H):
+    from awr_amd import ops
+    ops_K = ops.K_ALIGN
+    ops.K_ALIGN = 1                      # the 32-channel granularity is a kernel constraint, not a geometry one
+    try:
+        spec = ops.ConvSpec(kind, cin, cout, k, s, p)
+    finally:
+        ops.K_ALIGN = ops_K
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k), generator=g, dtype=torch.float64)
+    x = torch.randn(2, cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    y_ref = (TF.conv2d if kind == "conv" else TF.conv_transpose2d)(x, w, None, s, p)
+    gy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xn = x.detach().permute(0, 2, 3, 1)
+    y = emulate_gemm(spec.fwd_problem(H, H), xn, emulate_pack(w, spec.fwd_pack()))
+    assert torch.allclose(y.permute(0, 3, 1, 2), y_ref.detach(), atol=1e-10)
+    dp = spec.dgrad_problem(H, H)
+    gx = emulate_gemm(dp, gy.permute(0, 2, 3, 1), emulate_pack(w, spec.dgrad_pack()))
+    assert torch.allclose(gx.permute(0, 3, 1, 2), gx_ref, atol=1e-10)
+    # wgrad contract: R[d0][t][d1] = sum_m D[m][d0] * G[gather(m,t)][d1]
+    wp = spec.wgrad_problem(H, H)
+    D, G = (gy, x.detach()) if wp["D"] == "dy" else (x.detach(), gy)
+    Dn, Gn = D.permute(0, 2, 3, 1), G.permute(0, 2, 3, 1)
+    R = torch.zeros(wp["Cd"], len(wp["taps"]), wp["Cg"], dtype=torch.float64)
+    for t, (dy, dx) in enumerate(wp["taps"]):
+        for yy in range(wp["Hd"]):
+            for xx in range(wp["Wd"]):
+                gy_, gx_ = yy * wp["sg"] + dy, xx * wp["sg"] + dx
+                if 0 <= gy_ < wp["Hg"] and 0 <= gx_ < wp["Wg"]:
+                    R[:, t, :] += Dn[:, yy, xx, :].T @ Gn[:, gy_, gx_, :]
+    wd = w.clone().requires_grad_(True)
+    (gw_ref,) = torch.autograd.grad((TF.conv2d if kind == "conv" else TF.conv_transpose2d)(x.detach(), wd, None, s, p), wd, gy)
+    assert torch.allclose(R.permute(0, 2, 1).reshape(gw_ref.shape), gw_ref, atol=1e-9)
+
+
+def test_scatter_phases_partition_the_taps(amd):
+    from awr_amd.ops import ConvSpec
+    spec = ConvSpec("deconv", 32, 32, 4, 2, 1)
+    ph = spec._scatter_phases()
+    assert len(ph) == 4 and all(len(t) == 4 for _, _, t in ph)
+    assert sorted(wt for _, _, taps in ph for _, _, wt in taps) == list(range(16))
+    spec1 = ConvSpec("conv", 32, 32, 1, 2, 0)
+    assert [(py, px, len(t)) for py, px, t in spec1._scatter_phases()] == [(0, 0, 1)]     # only even pixels get gradient
+    assert not spec1.dgrad_problem(8, 8)["full"]
+    spec3 = ConvSpec("conv", 32, 32, 3, 2, 1)
+    assert sorted(len(t) for _, _, t in spec3._scatter_phases()) == [1, 2, 2, 4]
+
+
+@pytest.mark.parametrize("net,J", [("resnet_18", 14), ("hourglass_1", 14), ("hourglass_2", 21)])
+def test_module_checkpoint_layout(amd, golden_dir, net, J):
+    man = json.load(open(os.path.join(golden_dir, "statedict_manifest.json")))["%s_J%d" % (net, J)]
+    m = amd.get_deconv_net(18, J, 2) if net.startswith("resnet") else amd.PoseNet(net, J)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [e[0] for e in man]
+    assert [list(v.shape) for v in sd.values()] == [e[1] for e in man]
+    assert [str(v.dtype).replace("torch.", "") for v in sd.values()] == [e[2] for e in man]
+    # strict load of a reference-layout state dict; values land in the flat arena
+    ref = O.procedural_state(O.manifest_for(net, J), seed=3)
+    m.load_state_dict(ref, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    n_params = sum(v.numel() for k, v in ref.items() if v.dtype == torch.float32 and "running" not in k)
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    assert m.flat_params().numel() >= n_params
+    # parameters are views of one arena: writing through the arena is visible in state_dict()
+    m.flat_params().mul_(2.0)
+    k0 = next(iter(ref))
+    assert torch.equal(m.state_dict()[k0], ref[k0] * 2)
+    # stock optimiser over net.parameters() round-trips its state (train.py:67, :84, :168)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.load_state_dict(opt.state_dict())
+
+
+def test_hourglass_unused_parameters_sit_at_the_arena_tail(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "hourglass_1_train.npz"))
+    m = amd.PoseNet("hourglass_1", 14)
+    assert sorted(m._unused) == sorted(str(k) for k in g["nograd"])        # same 30 tensors the reference never trains
+    lo = min(m._poff[k][0] for k in m._unused)
+    assert lo >= m.n_active and all(m._poff[k][0] < m.n_active for k in m._poff if k not in m._unused)
+    assert sum(m._poff[k][1] for k in m._unused) == 986880
+
+
+def test_reference_init_distributions(amd):
+    torch.manual_seed(0)
+    m = amd.get_deconv_net(18, 14, 2)
+    sd = m.state_dict()
+    assert abs(float(sd["layer1.0.conv1.weight"].std()) - (2.0 / (9 * 64)) ** 0.5) < 2e-3     # resnet_deconv.py:95-97
+    assert abs(float(sd["deconv_layers.0.weight"].std()) - 0.001) < 1e-4                       # :103-104
+    assert float(sd["final1.bias"].abs().max()) == 0 and float(sd["pre.1.weight"].min()) == 1  # :110, :99
+    h = amd.PoseNet("hourglass_1", 14).state_dict()
+    w = h["pre.1.conv2.conv.weight"]
+    assert float(w.abs().max()) <= 1.0 / (w.shape[1] * 9) ** 0.5 + 1e-7                       # kaiming_uniform(a=sqrt(5))

@@ -1,0 +1,231 @@
+"""GPU parity of the full backbones and the fused train step (HIP path through the C ABI) against
+the oracle and the committed golden vectors (procedural weights, so nothing large is shipped)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import awr_oracle as O
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+
+
+def report(name, value):
+    REPORT[name] = float(value)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(REPORT, open(os.path.join(out, "parity_report.json"), "w"), indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import awr_amd
+    return awr_amd
+
+
+def make_net(amd, net, J, sd):
+    m = amd.get_deconv_net(18, J, 2) if net.startswith("resnet") else amd.PoseNet(net, J)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def smp_index(n, i):
+    return int(np.minimum(((O._hash_uniform(1, 1000 + 40 + i, 7).astype(np.float64) + 0.5) * n).astype(np.int64), n - 1)[0])
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1", "hourglass_2"])
+def test_backbone_forward_golden(amd, dev, golden_dir, net):
+    g = np.load(os.path.join(golden_dir, "%s_fwd.npz" % net))
+    img = torch.from_numpy(g["img"])
+    J, ks = int(g["J"]), float(g["ks"])
+    man = O.manifest_for(net, J)
+    fm = amd.FeatureModule()
+    for mode in ("eval", "train"):
+        sd = O.procedural_state(man, seed=0)
+        m = make_net(amd, net, J, sd)
+        m.train(mode == "train")
+        with torch.no_grad():
+            outs = m(img.to(dev))
+        outs = outs if isinstance(outs, list) else [outs]
+        oracle = O.backbone_forward(net, O.procedural_state(man, seed=0), img, training=(mode == "train"))
+        for s, o in enumerate(outs):
+            ref = g["%s_s%d_val" % (mode, s)]
+            got = o.cpu().reshape(-1).numpy()[g["%s_s%d_idx" % (mode, s)]]
+            scale = max(1.0, float(np.abs(ref).max()))
+            err = float(np.abs(got - ref).max()) / scale
+            full = float((o.cpu() - oracle[s]).abs().max()) / scale
+            report("%s/%s/stage%d/dense_map_rel_err" % (net, mode, s), full)
+            assert err <= 2e-4 and full <= 2e-4, (err, full)
+            jt = fm.offset2joint_softmax(o, img.to(dev), ks).cpu().numpy()
+            djt = float(np.abs(jt - g["%s_s%d_jt" % (mode, s)]).max())
+            report("%s/%s/stage%d/joint_err_mm" % (net, mode, s), djt * 150.0)
+            assert djt * 150.0 <= 0.05, djt          # mm on a 300 mm cube; north_star asks 0.05 mm on NYU
+        if mode == "train":
+            got_sd = m.state_dict()
+            for i, k in enumerate(g["bn_keys"]):
+                np.testing.assert_allclose(got_sd[str(k)].cpu().numpy(), g["bn_%d" % i], rtol=2e-4, atol=2e-5)
+            assert int(got_sd["pre.1.num_batches_tracked" if net.startswith("resnet") else "pre.0.bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
+@pytest.mark.parametrize("tag,cw", [("c0", 0.0), ("c1", 1.0)])
+def test_fused_train_step_golden(amd, dev, golden_dir, net, tag, cw):
+    from awr_amd.trainer import TrainEngine
+    g = np.load(os.path.join(golden_dir, "%s_train.npz" % net))
+    img, jt_gt = torch.from_numpy(g["img"]), torch.from_numpy(g["jt_gt"])
+    J, ks = int(g["J"]), float(g["ks"])
+    man = O.manifest_for(net, J)
+    pkeys = [str(k) for k in g["pkeys"]]
+    sd = O.procedural_state(man, seed=1)
+    m = make_net(amd, net, J, sd)
+    eng = TrainEngine(m, img.shape[0], 128, ks, coord_weight=cw, dense_weight=1.0, lr=1e-3, use_graph=False)
+    losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+    l0 = float(losses[2])
+    ref0 = float(g[tag + "_loss0"])
+    report("%s/%s/loss0_rel_err" % (net, tag), abs(l0 - ref0) / abs(ref0))
+    assert abs(l0 - ref0) <= 2e-4 * abs(ref0), (l0, ref0)
+    assert abs(float(losses[0]) - float(g[tag + "_lcoord0"])) <= 2e-4 * max(1e-6, abs(float(g[tag + "_lcoord0"]))) + 1e-9
+    djt = float(np.abs(jt.cpu().numpy() - g[tag + "_jt0"]).max())
+    report("%s/%s/train_joint_err_mm" % (net, tag), djt * 150)
+    assert djt * 150 <= 0.05
+    # gradients: L2 norm per parameter tensor + one sampled element each (golden = reference autograd)
+    # A conv bias that feeds a BatchNorm has an analytically ZERO gradient (BN removes the mean); both sides
+    # then hold rounding noise, so errors are measured against the largest gradient norm in the network.
+    worst, worst_key = 0.0, ""
+    gmax = float(np.max(g[tag + "_grad_l2"]))
+    for i, k in enumerate(pkeys):
+        ref = float(g[tag + "_grad_l2"][i])
+        if ref < 0:
+            assert k in m._unused
+            continue
+        gv = m.grad_view(k).cpu()
+        err = abs(float(gv.double().norm()) - ref)
+        rel = err / (ref + 1e-5 * gmax)
+        if rel > worst:
+            worst, worst_key = rel, k
+        assert rel <= 5e-3, (k, float(gv.double().norm()), ref)
+        smp = float(gv.reshape(-1)[smp_index(gv.numel(), i)])
+        assert abs(smp - float(g[tag + "_grad_smp"][i])) <= 5e-3 * float(gv.abs().max()) + 1e-6 * gmax, k
+    report("%s/%s/worst_grad_norm_rel_err" % (net, tag), worst)
+    print("worst grad-norm error: %s %.3e" % (worst_key, worst))
+    # parameters after 1 and 2 Adam steps (sampled), loss of the second step
+    sd1 = m.state_dict()
+    p1 = np.array([float(sd1[k].reshape(-1)[smp_index(sd1[k].numel(), i)]) for i, k in enumerate(pkeys)], np.float32)
+    report("%s/%s/param_abs_err_step1" % (net, tag), float(np.abs(p1 - g[tag + "_param_smp1"]).max()))
+    np.testing.assert_allclose(p1, g[tag + "_param_smp1"], rtol=0, atol=2.5e-4)      # one Adam step moves a weight by <= lr = 1e-3
+    losses, _ = eng.step(img.to(dev), jt_gt.to(dev))
+    ref1 = float(g[tag + "_loss1"])
+    report("%s/%s/loss1_rel_err" % (net, tag), abs(float(losses[2]) - ref1) / abs(ref1))
+    assert abs(float(losses[2]) - ref1) <= 2e-2 * abs(ref1)
+    sd2 = m.state_dict()
+    p2 = np.array([float(sd2[k].reshape(-1)[smp_index(sd2[k].numel(), i)]) for i, k in enumerate(pkeys)], np.float32)
+    # Adam's first steps move every weight by ~lr whatever the gradient magnitude, so elements whose gradient is
+    # rounding noise may flip direction: bound the bulk tightly and the worst case by 2 steps * lr.
+    d2 = np.abs(p2 - g[tag + "_param_smp2"])
+    assert np.quantile(d2, 0.9) <= 1e-4 and d2.max() <= 2.1e-3, (np.quantile(d2, 0.9), d2.max())
+    for k in m._unused:                                                               # never touched, like torch's `grad is None`
+        assert torch.equal(sd2[k].cpu(), O.procedural_state(man, seed=1)[k])
+
+
+@pytest.mark.parametrize("net,B", [("resnet_18", 3), ("hourglass_1", 2), ("hourglass_2", 1)])
+def test_dropin_autograd_path_vs_oracle(amd, dev, net, B):
+    """The reference's own step, written with the drop-in objects (train.py:113-131): net(x) ->
+    FeatureModule -> My_SmoothL1Loss -> loss.backward() -> stock torch.optim.Adam."""
+    J = 14
+    ks = 1.0 if net.startswith("resnet") else 0.4
+    img, jt_gt = O.synth_batch(B, 128, J, seed=31)
+    man = O.manifest_for(net, J)
+    sd = O.procedural_state(man, seed=2)
+    m = make_net(amd, net, J, sd)
+    m.train()
+    fm, crit = amd.FeatureModule(), amd.My_SmoothL1Loss().cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x, jg = img.to(dev), jt_gt.to(dev)
+    gt = fm.joint2offset(jg, x, ks, 64)
+    stacks = 1 if net.startswith("resnet") else int(net.split("_")[-1])
+    for stage in range(stacks):
+        pred = m(x)
+        pred = pred[stage] if isinstance(pred, list) else pred
+        jt = fm.offset2joint_softmax(pred, x, ks)
+        loss = 1.0 * crit(jt, jg) + 1.0 * crit(pred, gt)
+    opt.zero_grad()
+    loss.backward()
+    sdo = O.procedural_state(man, seed=2)
+    lo, lc, ld, grads, jt_o = O.loss_and_grads(net, sdo, img, jt_gt, ks, 1.0, 1.0)
+    assert abs(float(loss) - float(lo)) <= 2e-4 * abs(float(lo))
+    named = dict(m.named_parameters())
+    worst = 0.0
+    gmax = max(float(gr.abs().max()) for gr in grads.values() if gr is not None)
+    for k, gr in grads.items():
+        if gr is None:
+            assert named[k].grad is None, k
+            continue
+        # (biases feeding a BatchNorm have zero true gradient: measure against the global gradient scale)
+        d = float((named[k].grad.cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-3 * gmax)
+        worst = max(worst, d)
+    report("%s/dropin/worst_grad_rel_err" % net, worst)
+    assert worst <= 2e-2, worst
+    opt.step()
+    # BN buffers followed the reference quirk: `stacks` momentum updates per iteration
+    got = m.state_dict()
+    bnk = [k for k, _, kind in man if kind in ("bn_mean", "bn_var")]
+    for k in (bnk[0], bnk[-1]):
+        np.testing.assert_allclose(got[k].cpu().numpy(), sdo[k].numpy(), rtol=5e-4, atol=5e-5)
+    cnt = [k for k, _, kind in man if kind == "counter"][0]
+    assert int(got[cnt]) == stacks
+
+
+def test_inference_engine_and_graph_replay(amd, dev):
+    from awr_amd.trainer import InferEngine, TrainEngine
+    J = 14
+    img, jt_gt = O.synth_batch(4, 128, J, seed=41)
+    man = O.manifest_for("resnet_18", J)
+    sd = O.procedural_state(man, seed=4)
+    m = make_net(amd, "resnet_18", J, sd)
+    inf = InferEngine(m, 4, 128, 1.0, use_graph=True)
+    ref = O.offset2joint_softmax(O.resnet18_forward(O.procedural_state(man, seed=4), img), img, 1.0)
+    for it in range(4):                      # iterations 0-1 eager, 2 captures, 3 replays
+        jt = inf(img.to(dev))
+        assert float((jt.cpu() - ref).abs().max()) * 150 <= 0.05, it
+    # graph-captured train step == eager train step (same inputs, fresh nets)
+    res = []
+    for use_graph in (False, True):
+        mm = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=4))
+        eng = TrainEngine(mm, 4, 128, 1.0, coord_weight=1.0, dense_weight=1.0, use_graph=use_graph)
+        ls = [float(eng.step(img.to(dev), jt_gt.to(dev))[0][2]) for _ in range(4)]
+        res.append((ls, mm.flat_params().clone()))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-3), (res[0][0], res[1][0])
+    dpar = (res[0][1] - res[1][1]).abs()          # split-K atomics make runs differ in the last bits; Adam amplifies noise-level grads
+    assert float(torch.quantile(dpar[:1000000], 0.99)) <= 1e-4 and float(dpar.max()) <= 4.1e-3
+    assert res[0][0][3] < res[0][0][0]       # and the loss goes down
+
+
+def test_roundtrip_save_load_checkpoint(amd, dev, tmp_path):
+    """train.py:165-170 / test.py:45-49: {'model','optimizer','best_records'} round trip."""
+    from awr_amd.trainer import TrainEngine
+    J = 14
+    img, jt_gt = O.synth_batch(2, 128, J, seed=51)
+    m = make_net(amd, "hourglass_1", J, O.procedural_state(O.manifest_for("hourglass_1", J), seed=5))
+    eng = TrainEngine(m, 2, 128, 0.4, use_graph=False)
+    eng.step(img.to(dev), jt_gt.to(dev))
+    path = os.path.join(tmp_path, "epoch_1.pth")
+    torch.save({"model": m.state_dict(), "optimizer": eng.optimizer_state_dict(), "best_records": {"epoch": 1, "MPE": 1e10, "AUC": 0}}, path)
+    pth = torch.load(path, weights_only=False)
+    m2 = amd.PoseNet("hourglass_1", J).cuda()
+    m2.load_state_dict(pth["model"])
+    assert torch.equal(m2.flat_params()[:m2.n_params], m.flat_params()[:m.n_params])
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    opt.load_state_dict(pth["optimizer"])                      # stock optimizer accepts the engine's state
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        a, b = m(img.to(dev))[0], m2(img.to(dev))[0]
+    assert torch.equal(a, b)
