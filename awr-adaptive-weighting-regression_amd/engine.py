@@ -136,8 +136,18 @@ class Plan:
         self.bytes = 0
         self._built_bwd = False
         self._bufs = []
+        self.macs = {}              # op name -> algorithmic MACs of that GEMM launch (bench.py roofline)
         self._keep = []             # ctypes argument structs referenced by the op lists
         self._head_states = []
+
+    @staticmethod
+    def _gemm_macs(fwd_prob, B, spec):
+        """ALGORITHMIC multiply-accumulates of one conv-like layer (logical channels, zero padding counted as
+        work, the usual 2*MAC convention): forward, data-gradient and weight-gradient all cost the same."""
+        taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(len(fwd_prob["phases"]) if fwd_prob["so"] > 1 else 1)
+        if fwd_prob["so"] > 1:      # transposed conv: each output pixel sees k*k/so^2 taps
+            taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(fwd_prob["so"] ** 2)
+        return B * fwd_prob["Hout"] * fwd_prob["Wout"] * spec.cout * taps_per_out * spec.cin
 
     # ---- allocation -----------------------------------------------------------------------------------
     def alloc(self, *shape, dtype=torch.float32, zero=False):
@@ -200,6 +210,7 @@ class Plan:
                            out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
                            res=res.buf if res is not None else None, stats=y.stats, relu_in=relu_in, relu_out=relu_out, T=spec.T)
         self.fwd_ops.append((L.lib.awr_conv_gemm, (C.byref(a), None), "awr_conv_gemm:" + layer.name))
+        self.macs["awr_conv_gemm:" + layer.name] = self._gemm_macs(prob, B, spec)
         self._keep.append(a)
         if self.training:
             assert in_affine is None and out_affine is None and not relu_in and not relu_out, "fused affine/ReLU are inference-only"
@@ -226,6 +237,7 @@ class Plan:
         self._keep.append(wa)
         self.bwd_ops.append((None, (R,), "__zero__"))
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
+        self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         for name, args in layer.wgrad_unpack_calls(R, ld):
             self._b(name, *args)
         # data gradient
@@ -238,6 +250,7 @@ class Plan:
             da = make_conv_args(dp, B, dy, layer.p_dgrad, gx, res=gx if acc else None, T=spec.T)
             self._keep.append(da)
             self.bwd_ops.append((L.lib.awr_conv_gemm, (C.byref(da), None), "awr_conv_dgrad:" + layer.name))
+            self.macs["awr_conv_dgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         if res is not None:
             self._contribute_identity(res, dy)
 
@@ -372,9 +385,11 @@ class Plan:
         for fn, args, name in self.pack_ops:
             L.check(fn(*args[:-1], s), name)
 
-    @staticmethod
-    def _run(ops):
+    timer = None     # optional KernelTimer (bench.py): brackets every GEMM-family launch with HIP events
+
+    def _run(self, ops):
         s = L.stream()
+        timer = self.timer
         for fn, args, name in ops:
             if fn is None:
                 if name == "__zero__":
@@ -382,7 +397,12 @@ class Plan:
                 else:
                     args[0].copy_(args[1])
                 continue
-            rc = fn(*args[:-1], s)
+            if timer is not None and name.startswith("awr_conv_"):
+                timer.begin(name)
+                rc = fn(*args[:-1], s)
+                timer.end()
+            else:
+                rc = fn(*args[:-1], s)
             if rc != 0:
                 raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
 

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- the AWR hot path on MI355X: depth-images/sec of the full train step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--net resnet_18|hourglass_1] [--graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): ResNet18-deconv, 128x128 depth crops, J=14, batch 64 per GPU, one full
+reference iteration per step (GT map + forward + head + dense/joint Huber + backward + Adam; train.py:107-131)
+on synthetic crops with reference-initialised weights.  N > 1 = one process per GPU, each
+stepping its own batch-64 shard (weak scaling) with an RCCL all-reduce of the flat gradient arena.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
+implicit-GEMM conv kernels inside the timed steps; `cpu_baseline` times the oracle (the CPU restatement
+of the reference step, proven bit-identical to the reference in tools/gen_golden.py) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+class KernelTimer:
+    """HIP-event pairs around individual kernel launches on the current stream."""
+
+    def __init__(self):
+        self.pairs, self._cur = [], None
+
+    def begin(self, name):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._cur = (name, e0)
+
+    def end(self):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.pairs.append((self._cur[0], self._cur[1], e1))
+
+    def collect(self):
+        out = {}
+        for name, e0, e1 in self.pairs:
+            d = out.setdefault(name, [0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 1
+        return out
+
+
+def cpu_baseline(net, ks, batch, target_seconds=20.0):
+    """Oracle train step on the host cores (kind 'port'); a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import awr_oracle as O
+    threads = torch.get_num_threads()
+    b = min(batch, 16)
+    img, jt = O.synth_batch(b, 128, 14, seed=1234)
+    sd = O.reference_init_state(net, 14, seed=0)
+    ost = {"step": 0, "m": {}, "v": {}}
+    O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > target_seconds or n >= 20:
+            break
+    return {"value": round(n * b / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d oracle train steps (torch-CPU fp32 restatement of train.py:107-131), batch %d, %s, %.1f s" % (n, b, net, el)}
+
+
+def parity_mm(net_name, ks, dev):
+    """mean / max 3D joint difference (mm, 300 mm cube => x150) between the HIP path and the oracle, eval mode."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import awr_oracle as O
+    import awr_amd
+    from awr_amd.trainer import InferEngine
+    img, _ = O.synth_batch(4, 128, 14, seed=99)
+    sd = O.procedural_state(O.manifest_for(net_name, 14), seed=0)
+    m = awr_amd.get_deconv_net(18, 14, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, 14)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    jt = InferEngine(m, 4, 128, ks, use_graph=False)(img.to(dev)).cpu()
+    with torch.no_grad():
+        ref = O.offset2joint_softmax(O.backbone_forward(net_name, sd, img)[-1], img, ks)
+    d = (jt - ref).norm(dim=-1) * 150.0
+    return float(d.mean()), float(d.max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE configs[1]: 64)")
+    ap.add_argument("--net", default="resnet_18")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (roofline then comes from a separate eager pass)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--coord-weight", type=float, default=0.0, help="reference default config.py:41")
+    ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    import awr_amd
+    from awr_amd import _lib as L
+    from awr_amd.trainer import TrainEngine
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import awr_oracle as O          # synthetic-input generator + cpu_baseline only; never on the measured path
+
+    ks = 1.0 if args.net.startswith("resnet") else 0.4          # config.py:42
+    torch.manual_seed(0)
+    net = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
+    eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
+                      use_graph=args.graph)
+    img, jt = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)
+    img, jt = img.to(dev), jt.to(dev)           # inputs resident in HBM before the timed region
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(max(args.warmup, 3 if args.graph else 0)):
+        eng.step(img, jt)
+    timer = None
+    if not args.graph:
+        timer = KernelTimer()
+        eng.plan.timer = timer
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(img, jt)
+    sync()
+    elapsed = time.perf_counter() - t0
+    eng.plan.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0])
+    loss = float(eng.losses[2])
+
+    if args.graph:                   # separate eager pass for the per-kernel events
+        timer = KernelTimer()
+        eng.use_graph, eng.graph = False, None
+        eng.plan.timer = timer
+        for _ in range(3):
+            eng.step(img, jt)
+        torch.cuda.synchronize()
+        eng.plan.timer = None
+    per = timer.collect()
+    macs = eng.plan.macs
+    fam = {"conv_gemm_kernel(fwd+dgrad)": ("awr_conv_gemm:", "awr_conv_dgrad:"), "conv_wgrad_kernel": ("awr_conv_wgrad:",)}
+    kern = {}
+    for label, prefixes in fam.items():
+        fl = sum(2.0 * macs[n] * c for n, (sec, c) in per.items() if n.startswith(prefixes))
+        sec = sum(s for n, (s, c) in per.items() if n.startswith(prefixes))
+        cnt = sum(c for n, (s, c) in per.items() if n.startswith(prefixes))
+        kern[label] = {"tflops": fl / sec / 1e12 if sec else 0.0, "seconds": sec, "launches": cnt, "avg_us": 1e6 * sec / max(cnt, 1), "flops": fl}
+    if args.per_layer and rank == 0:
+        with open(args.per_layer, "w") as f:
+            f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
+            for n, (sec, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * macs[n], 2e-12 * macs[n] * c / sec))
+    dom = max(kern, key=lambda k: kern[k]["seconds"])
+    tot_fl = sum(k["flops"] for k in kern.values())
+    tot_sec = sum(k["seconds"] for k in kern.values())
+    nsteps_timed = next(iter(per.values()))[1] if per else 1
+    roofline = {
+        "bound": "mfma", "kernel": dom, "achieved": round(kern[dom]["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "avg_launch_us": round(kern[dom]["avg_us"], 2), "launches_per_step": kern[dom]["launches"] // max(nsteps_timed, 1),
+        "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2) if tot_sec else 0.0,
+        "gemm_seconds_per_step": round(tot_sec / max(nsteps_timed, 1), 6),
+        "algorithmic_gflop_per_image": round(tot_fl / max(nsteps_timed, 1) / args.batch / 1e9, 3),
+        "other_kernels": {k: {"tflops": round(v["tflops"], 2), "avg_us": round(v["avg_us"], 2)} for k, v in kern.items() if k != dom},
+        "step_mfma_frac": round((tot_fl / max(nsteps_timed, 1)) / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+    }
+
+    if rank == 0:
+        n_cu, mhz = L.C.c_int(0), L.C.c_int(0)
+        L.lib.awr_device_info(L.C.byref(n_cu), L.C.byref(mhz), None, 0)
+        out = {
+            "metric": "depth-images/sec (train step)", "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-deconv NYU-shape 128x128 J=14 train step (GT-map+fwd+head+Huber+bwd+Adam), batch %d/GPU" % (args.net, args.batch)
+                       if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
+                       "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
+                       "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": bool(args.graph),
+                       "device_cus": n_cu.value, "final_loss": loss},
+            "roofline": roofline,
+        }
+        if world == 1:
+            mean_mm, max_mm = parity_mm(args.net, ks, dev)
+            out["joint_err_mm_vs_oracle"] = {"mean": round(mean_mm, 6), "max": round(max_mm, 6)}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.net, ks, args.batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

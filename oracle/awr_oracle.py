@@ -39,6 +39,15 @@ HUBER_DELTA = 0.01     # loss.py:12-13
 SOFTMAX_BETA = 30.0    # feature_tool.py:60
 DEPTH_BG = 0.99        # feature_tool.py:35, :57
 
+# Test-only switch: evaluate the same formulas without the reference's `.float()` casts so that float64
+# inputs stay float64 end to end.  Used to measure how ill-conditioned a gradient is (fp32-vs-fp64 gap
+# of the oracle itself) before judging the HIP path's deviation from the fp32 oracle.
+HIGH_PRECISION = False
+
+
+def _fl(t):
+    return t if HIGH_PRECISION else t.float()
+
 
 # --------------------------------------------------------------------------
 # state-dict manifests (checkpoint layout)
@@ -321,7 +330,7 @@ def _down_depth(img, F):
 
 def _grid(F, device=None):
     """Pixel-centre grid in [-1,1]; feature_tool.py:23-24, :50-51."""
-    a = 2.0 * (torch.arange(F, device=device).float() + 0.5) / F - 1.0
+    a = 2.0 * (torch.arange(F, device=device).to(torch.float64 if HIGH_PRECISION else torch.float32) + 0.5) / F - 1.0
     return a.view(1, F).expand(F, F), a.view(F, 1).expand(F, F)       # (x varies along W, y along H)
 
 
@@ -335,8 +344,8 @@ def joint2offset(jt_uvd, img, ks, F):
     dist = torch.sqrt((off * off).sum(2) + 1e-8)                       # :31
     unit = off / dist.unsqueeze(2)                                     # :33
     hm = (ks - dist) / ks                                              # :34
-    mask = (hm >= 0).float() * (d < DEPTH_BG).float().unsqueeze(1)     # :35
-    return torch.cat([(unit * mask.unsqueeze(2)).reshape(B, 3 * J, F, F), hm * mask], 1).float()
+    mask = (hm >= 0).to(hm.dtype) * (d < DEPTH_BG).to(hm.dtype).unsqueeze(1)     # :35
+    return _fl(torch.cat([(unit * mask.unsqueeze(2)).reshape(B, 3 * J, F, F), hm * mask], 1))
 
 
 def offset2joint_softmax(offset, img, ks):
@@ -346,13 +355,13 @@ def offset2joint_softmax(offset, img, ks):
     d = _down_depth(img, F)[:, 0].reshape(B, 1, F * F)                 # (B,1,P)
     gx, gy = _grid(F, offset.device)
     coord = torch.stack([gx.reshape(1, -1).expand(B, -1), gy.reshape(1, -1).expand(B, -1), d[:, 0]], 1)  # (B,3,P)
-    m = (d < DEPTH_BG).float()                                         # :57
+    m = (d < DEPTH_BG).to(offset.dtype)                                # :57
     vec = offset[:, :3 * J].reshape(B, J, 3, F * F) * m.unsqueeze(1)   # :58
     h = offset[:, 3 * J:].reshape(B, J, F * F) * m                     # :59
     w = torch.softmax(h * SOFTMAX_BETA, -1)                            # :60  (masked pixels keep logit 0)
     dis = ks - h * ks                                                  # :61
     val = vec * dis.unsqueeze(2) + coord.unsqueeze(1)                  # :63
-    return (val * w.unsqueeze(2)).sum(-1).float()
+    return _fl((val * w.unsqueeze(2)).sum(-1))
 
 
 def head_backward(offset, img, ks, g_jt):
@@ -364,7 +373,7 @@ def head_backward(offset, img, ks, g_jt):
     d = _down_depth(img, F)[:, 0].reshape(B, 1, P)
     gx, gy = _grid(F, offset.device)
     coord = torch.stack([gx.reshape(1, -1).expand(B, -1), gy.reshape(1, -1).expand(B, -1), d[:, 0]], 1).unsqueeze(1)
-    m = (d < DEPTH_BG).float()
+    m = (d < DEPTH_BG).to(offset.dtype)
     vec = offset[:, :3 * J].reshape(B, J, 3, P)
     h = offset[:, 3 * J:].reshape(B, J, P) * m
     w = torch.softmax(h * SOFTMAX_BETA, -1)
@@ -382,9 +391,9 @@ def huber(x, y, delta=HUBER_DELTA):
     """My_SmoothL1Loss.forward; loss.py:8-25.  Mean over ALL elements of
     0.5 z^2 (|z|<delta) / delta(|z|-delta/2) otherwise."""
     assert x.shape == y.shape
-    z = (x - y).float()
+    z = _fl(x - y)
     a = z.abs()
-    small = (a < delta).float()
+    small = (a < delta).to(z.dtype)
     return (0.5 * z * z * small).mean() + (delta * (a - 0.5 * delta) * (1.0 - small)).mean()
 
 
