@@ -26,6 +26,30 @@ from . import _lib as L
 HUBER_DELTA = 0.01
 
 
+class GradSync:
+    """Data-parallel plumbing over flat arenas: parameter/buffer broadcast from rank 0 and a bucketed SUM
+    all-reduce of the gradient arena [0, n).  Device-agnostic (RCCL on the GPUs, gloo in the CPU tests); the
+    1/world averaging is folded into the optimiser kernel (`grad_scale`)."""
+
+    def __init__(self, n, process_group=None, n_buckets=4, min_bucket=1 << 20):
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        nb = max(1, min(n_buckets, n // min_bucket or 1))
+        edges = [round(i * n / nb / 4) * 4 for i in range(nb)] + [n]
+        self.buckets = [(edges[i], edges[i + 1]) for i in range(nb) if edges[i + 1] > edges[i]]
+        self.grad_scale = 1.0 / self.world
+
+    def broadcast(self, *tensors):
+        if self.world > 1:
+            for t in tensors:
+                torch.distributed.broadcast(t, 0, group=self.pg)
+
+    def allreduce(self, flat_grad):
+        if self.world > 1:
+            for lo, hi in self.buckets:
+                torch.distributed.all_reduce(flat_grad[lo:hi], group=self.pg)
+
+
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4):
@@ -34,8 +58,6 @@ class TrainEngine:
         self.net, self.B, self.H = net, batch_size, img_size
         self.ks, self.cw, self.dw = float(kernel_size), float(coord_weight), float(dense_weight)
         self.lr, self.wd, self.opt, self.momentum = float(lr), float(weight_decay), optimizer, float(momentum)
-        self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.J = net.J
         self.F = img_size // 2
         dev = net.device
@@ -55,13 +77,10 @@ class TrainEngine:
         self.use_graph = use_graph
         self.graph = None
         self._warm = 0
-        # gradient buckets for the all-reduce: contiguous slices of the flat arena
-        nb = max(1, min(n_buckets, n // (1 << 20) or 1))
-        edges = [round(i * n / nb / 4) * 4 for i in range(nb)] + [n]
-        self.buckets = [(edges[i], edges[i + 1]) for i in range(nb) if edges[i + 1] > edges[i]]
+        self.sync = GradSync(n, process_group, n_buckets)
+        self.world = self.sync.world
         if self.world > 1:      # identical initial parameters and BN buffers on every rank
-            torch.distributed.broadcast(net.flat_params(), 0, group=self.pg)
-            torch.distributed.broadcast(net._barena, 0, group=self.pg)
+            self.sync.broadcast(net.flat_params(), net._barena)
             net.weights_changed()
 
     # ---- the captured part: repack -> forward -> head + losses -> backward -------------------------------
@@ -91,7 +110,7 @@ class TrainEngine:
         net = self.net
         n = net.n_active
         s = L.stream()
-        scale = 1.0 / self.world
+        scale = self.sync.grad_scale
         if self.opt == "adam":
             L.call("awr_adam_step", L.ptr(net.flat_params()), L.ptr(net.flat_grads()), L.ptr(self.m), L.ptr(self.v), n, self.lr, 0.9, 0.999,
                    1e-8, self.wd, self.step_count, scale, s)
@@ -100,9 +119,7 @@ class TrainEngine:
                    self.step_count, scale, s)
 
     def _allreduce(self):
-        g = self.net.flat_grads()
-        for lo, hi in self.buckets:
-            torch.distributed.all_reduce(g[lo:hi], group=self.pg)
+        self.sync.allreduce(self.net.flat_grads()[:self.net.n_active])
 
     def step(self, img, jt_uvd_gt):
         """One optimisation step on this rank's shard.  Returns (losses[coord,dense,total], jt_uvd_pred)
