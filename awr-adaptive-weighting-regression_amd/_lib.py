@@ -32,8 +32,7 @@ lib = _load()
 
 
 class Phase(C.Structure):
-    _fields_ = [("py", C.c_int), ("px", C.c_int), ("ntaps", C.c_int),
-                ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16), ("wt", C.c_int8 * 16)]
+    _fields_ = [("py", C.c_int), ("px", C.c_int), ("ntaps", C.c_int), ("tap", C.c_int32 * 16)]
 
 
 class ConvArgs(C.Structure):

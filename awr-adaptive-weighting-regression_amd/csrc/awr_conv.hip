@@ -33,6 +33,21 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// Buffer addressing (T8): a 128-bit resource + a 32-bit byte offset per lane.  Out-of-range offsets return 0
+// in hardware, which is exactly the zero padding / ragged-tile behaviour the gather needs: an invalid row
+// simply gets offset 0xFFFFFFFF -- no branch, no select, and (crucially) no s_waitcnt before the MFMAs.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);   // buffer_load_dwordx4 ... offen
+    static_assert(sizeof(v) == 16, "b128");
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+constexpr unsigned OOB = 0xFFFFFFFFu;
+
 __device__ __forceinline__ float4 affine_relu(float4 v, float4 sc, float4 sh, int relu) {
     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -59,9 +74,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
     const int r0 = tid >> 3;            // first row it stages (then +32, +64, ...)
 
-    // decode the A rows this thread stages (fixed for the whole K loop)
+    // decode the A rows this thread stages (fixed for the whole K loop); byte offsets are 32-bit (tensors < 4 GB)
     int a_iy[RA], a_ix[RA];
-    int64_t a_img[RA];
+    unsigned a_img[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = tile_m * BM + r0 + 32 * i;
@@ -69,16 +84,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
             a_iy[i] = qy * a.si;
             a_ix[i] = qx * a.si;
-            a_img[i] = (int64_t)b * a.Hin * a.Win;
+            a_img[i] = (unsigned)b * a.Hin * a.Win;
         } else {
             a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
             a_ix[i] = 0;
             a_img[i] = 0;
         }
     }
-    const float* wrow[RB];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, OOB);
+    unsigned w_off[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) wrow[i] = a.w + (int64_t)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc;
+    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc) * 4u;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -91,30 +108,41 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     const int cslices = a.Cin / BK;
     const int ksteps = ph.ntaps * cslices;
     float4 ra[RA], rb[RB];
+    unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
+    int c0_staged = 0;
 
+    // issue the global loads of one K-slice; nothing here waits for memory
     auto load_slice = [&](int tap, int c0) {
-        const int dy = ph.dy[tap], dx = ph.dx[tap], wt = ph.wt[tap];
-        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-        if (a.in_scale) {
-            sc = ld4(a.in_scale + c0 + kc);
-            sh = ld4(a.in_shift + c0 + kc);
-        }
+        const int tp = ph.tap[tap];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
+        unsigned mask = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (ok) {
-                v = ld4(a.in + ((a_img[i] + (int64_t)iy * a.Win + ix) * a.Cin + c0 + kc));
-                if (a.in_scale) v = affine_relu(v, sc, sh, a.relu_in);
-                else if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            ra[i] = v;
+            const unsigned off = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + c0 + kc) * 4u;
+            ra[i] = buf_ld4(rs_in, ok ? off : OOB);
+            mask |= ok ? (1u << i) : 0u;
         }
+        const unsigned wtap = ((unsigned)wt * a.Cin + c0) * 4u;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = ld4(wrow[i] + (int64_t)wt * a.Cin + c0);
+        for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + wtap);
+        okmask = mask;
+        c0_staged = c0;
     };
+    // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
     auto store_slice = [&]() {
+        if (a.in_scale) {
+            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
+        } else if (a.relu_in) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f); ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) st4(&As[(r0 + 32 * i) * LDK + kc], ra[i]);
 #pragma unroll
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
     const int tcg = wg % tiles_cg; wg /= tiles_cg;
     const int tcd = wg % tiles_cd; wg /= tiles_cd;
     const int t = wg;                                 // tap
-    const int dy = a.dy[t], dx = a.dx[t];
+    const int dy = a.dy[t], dx = a.dx[t];   // scalar (uniform) loads from the kernel arguments
     const int m_begin = blockIdx.y * chunk;
     int m_end = m_begin + chunk;
     if (m_end > M) m_end = M;
@@ -241,23 +269,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 rd[RA], rg[RB];
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)M * a.Cd * 4u);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
+    const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
     auto load_slice = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = m0 + da_r + PM * i;
-            rd[i] = (m < m_end && d_cok) ? ld4(a.D + (int64_t)m * a.Cd + tcd * BM + da_c) : make_float4(0, 0, 0, 0);
+            rd[i] = buf_ld4(rs_d, (m < m_end && d_cok) ? (unsigned)m * a.Cd * 4u + d_col : OOB);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int m = m0 + ga_r + PN * i;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (m < m_end && g_cok) {
-                const int x = m % a.Wd, tt = m / a.Wd, y = tt % a.Hd, b = tt / a.Hd;
-                const int gy = y * a.sg + dy, gx = x * a.sg + dx;
-                if (gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg)
-                    v = ld4(a.G + (((int64_t)b * a.Hg + gy) * a.Wg + gx) * a.Cg + tcg * BN + ga_c);
-            }
-            rg[i] = v;
+            const int x = m % a.Wd, tt = m / a.Wd, y = tt % a.Hd, b = tt / a.Hd;
+            const int gy = y * a.sg + dy, gx = x * a.sg + dx;
+            const bool ok = m < m_end && g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
+            rg[i] = buf_ld4(rs_g, ok ? ((unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg) * 4u + g_col : OOB);
         }
     };
     auto store_slice = [&]() {
@@ -332,10 +359,12 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
     for (int p = 0; p < a->nphase; ++p) {
         AWR_REQUIRE(a->ph[p].ntaps >= 1 && a->ph[p].ntaps <= 16, "conv_gemm: phase %d has %d taps", p, a->ph[p].ntaps);
-        for (int t = 0; t < a->ph[p].ntaps; ++t) AWR_REQUIRE(a->ph[p].wt[t] >= 0 && a->ph[p].wt[t] < a->T, "conv_gemm: tap index out of range");
+        for (int t = 0; t < a->ph[p].ntaps; ++t) AWR_REQUIRE((a->ph[p].tap[t] >> 16) >= 0 && (a->ph[p].tap[t] >> 16) < a->T, "conv_gemm: tap index out of range");
     }
     const int64_t M = (int64_t)a->B * a->Hq * a->Wq;
     AWR_REQUIRE(M < (1LL << 31), "conv_gemm: too many output pixels");
+    AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31),
+                "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
     // tile choice: widest tile that still gives >= 1.5 workgroups per CU (256 CUs); N <= 64 never needs BN = 128
     const int tn_max = a->N > 64 ? 2 : 1;
     int TM = 2, TN = tn_max;
@@ -359,6 +388,8 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
+    AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
+                "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
     int TM = a->Cd > 64 ? 2 : 1, TN = a->Cg > 64 ? 2 : 1;
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;

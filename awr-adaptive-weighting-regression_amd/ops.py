@@ -121,7 +121,7 @@ def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, 
         ph = a.ph[i]
         ph.py, ph.px, ph.ntaps = py, px, len(taps)
         for t, (dy, dx, wt) in enumerate(taps):
-            ph.dy[t], ph.dx[t], ph.wt[t] = dy, dx, wt
+            ph.tap[t] = (dy & 0xff) | ((dx & 0xff) << 8) | (wt << 16)
     return a
 
 

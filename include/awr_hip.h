@@ -108,10 +108,11 @@ int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* 
  * conv kxk stride s pad p      : so=1, si=s, one phase, taps (dy,dx,wt)=(ky-p,kx-p,ky*k+kx)
  * transposed conv k4 s2 p1     : so=2, si=1, four phases (py,px), taps with (py+p-ky) even,
  *                                dy=(py+p-ky)/2 (likewise x), wt=ky*k+kx
+ * Tensors must stay below 4 GB (the kernels use 32-bit buffer offsets with hardware bounds checking).
  * Built by the host (see awr_conv_geom_* helpers in the Python/C++ host code). */
 typedef struct awr_phase {
     int py, px, ntaps;
-    int8_t dy[16], dx[16], wt[16];
+    int32_t tap[16];   /* (dy & 0xff) | (dx & 0xff) << 8 | wt << 16 : one scalar load per K-slice */
 } awr_phase;
 
 typedef struct awr_conv_args {

@@ -53,9 +53,9 @@ def test_argument_validation_without_gpu(lib):
 
 def test_struct_layout_matches_header(lib):
     import ctypes as C
-    # awr_phase: 3 ints + 3x16 int8 = 60 bytes; awr_conv_args: 10 pointers + 15 ints + 4 phases
-    assert C.sizeof(lib.Phase) == 60
-    assert C.sizeof(lib.ConvArgs) == 10 * 8 + 15 * 4 + 4 * 60 + 4   # trailing pad to 8-byte alignment
+    # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 10 pointers + 15 ints + 4 phases
+    assert C.sizeof(lib.Phase) == 76
+    assert C.sizeof(lib.ConvArgs) == 10 * 8 + 15 * 4 + 4 * 76 + 4   # trailing pad to 8-byte alignment
     assert C.sizeof(lib.WgradArgs) == 3 * 8 + 10 * 4 + 32
 
 
