@@ -111,23 +111,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
     int c0_staged = 0;
 
-    // issue the global loads of one K-slice; nothing here waits for memory
-    auto load_slice = [&](int tap, int c0) {
+    // Per tap (every Cin/32 K-slices): bounds test + base byte offset of each staged row.  Per K-slice: one add
+    // per row.  Keeping the per-slice VALU work tiny matters: the two waves that share a SIMD's MFMA pipe drift
+    // into lock-step, so every VALU cycle spent between MFMA bursts is a cycle the matrix pipe idles.
+    unsigned a_off[RA], tapmask = 0, wtap = 0;
+    auto set_tap = [&](int tap) {
         const int tp = ph.tap[tap];
         const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
-        unsigned mask = 0;
+        tapmask = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const unsigned off = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + c0 + kc) * 4u;
-            ra[i] = buf_ld4(rs_in, ok ? off : OOB);
-            mask |= ok ? (1u << i) : 0u;
+            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
+            tapmask |= ok ? (1u << i) : 0u;
         }
-        const unsigned wtap = ((unsigned)wt * a.Cin + c0) * 4u;
+        wtap = (unsigned)wt * a.Cin * 4u;
+    };
+    // issue the global loads of one K-slice; nothing here waits for memory
+    auto load_slice = [&](int c0) {
+        const unsigned cb = (unsigned)c0 * 4u;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + wtap);
-        okmask = mask;
+        for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + (wtap + cb));
+        okmask = tapmask;
         c0_staged = c0;
     };
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     };
 
     int tap = 0, c0 = 0;
-    load_slice(0, 0);
+    set_tap(0);
+    load_slice(0);
     store_slice();
     __syncthreads();
 
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         const bool more = ks + 1 < ksteps;
         if (more) {
             c0 += BK;
-            if (c0 == a.Cin) { c0 = 0; ++tap; }
-            load_slice(tap, c0);   // global loads in flight while the MFMAs below run
+            if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
+            load_slice(c0);        // global loads in flight while the MFMAs below run
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------
     const bool direct = (a.so == 1);   // out pixel index == m
+    float cs1[TN], cs2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = tile_n * BN + wn * 32 * TN + j * 32 + l31;
@@ -203,10 +213,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = tile_m * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < M && nok) {
-                    int64_t opix = m;
+                    int opix = m;
                     if (!direct) {
                         const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
-                        opix = ((int64_t)b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
+                        opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
                     }
                     float v = acc[i][j][r] + bias;
                     if (a.out_scale) v = v * osc + osh;
@@ -218,12 +228,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
                 }
             }
         }
-        if (a.stats) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (half == 0 && nok) {
-                atomicAdd(a.stats + n, (double)s1);
-                atomicAdd(a.stats + a.N + n, (double)s2);
+        cs1[j] = s1 + __shfl_xor(s1, 32, 64);
+        cs2[j] = s2 + __shfl_xor(s2, 32, 64);
+    }
+    if (a.stats) {
+        // BatchNorm statistics: combine the two M-waves of the workgroup in LDS, then ONE fp64 atomic per column and
+        // statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands of workgroups hit the same C channels;
+        // without the slots the atomics serialise in L2 and cost more than the GEMM epilogue itself).
+        float* red = As;     // the K loop is over: LDS is free
+        __syncthreads();
+        if (wm == 1 && half == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                red[(wn * TN + j) * 64 + l31] = cs1[j];
+                red[(wn * TN + j) * 64 + 32 + l31] = cs2[j];
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && half == 0) {
+            double* st = a.stats + (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * a.N;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = tile_n * BN + wn * 32 * TN + j * 32 + l31;
+                if (n < a.N) {
+                    atomicAdd(st + n, (double)(cs1[j] + red[(wn * TN + j) * 64 + l31]));
+                    atomicAdd(st + a.N + n, (double)(cs2[j] + red[(wn * TN + j) * 64 + 32 + l31]));
+                }
             }
         }
     }
@@ -365,13 +395,13 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(M < (1LL << 31), "conv_gemm: too many output pixels");
     AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31),
                 "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
-    // tile choice: widest tile that still gives >= 1.5 workgroups per CU (256 CUs); N <= 64 never needs BN = 128
-    const int tn_max = a->N > 64 ? 2 : 1;
-    int TM = 2, TN = tn_max;
+    // Tile choice (measured, tools/microbench_gemm.py): 64-row tiles win on every ResNet18/Hourglass layer shape --
+    // 3-4 workgroups per CU de-synchronise prologue/epilogue bubbles that two lock-stepped 128x128 workgroups
+    // expose, and the extra L2 traffic is free at FP32-MFMA rates.  128 columns when N allows and the grid stays
+    // >= 2 workgroups per CU, else 64x64.
     auto blocks = [&](int tm, int tn) { return ((M + 64 * tm - 1) / (64 * tm)) * ((a->N + 64 * tn - 1) / (64 * tn)) * a->nphase; };
-    if (blocks(TM, TN) < 384 && TN == 2) TN = 1;
-    if (blocks(TM, TN) < 384) { TM = 1; TN = tn_max; }
-    if (blocks(TM, TN) < 384 && TN == 2) TN = 1;
+    int TM = 1, TN = (a->N > 64 && blocks(1, 2) >= 512) ? 2 : 1;
+    if (a->Cin * a->ph[0].ntaps <= 64) TM = 2;     // one or two K-slices (the im2col'd stem): store-bound, amortise the epilogue
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     hipStream_t st = as_stream(stream);
@@ -390,7 +420,7 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
                 "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
-    int TM = a->Cd > 64 ? 2 : 1, TN = a->Cg > 64 ? 2 : 1;
+    int TM = a->Cd > 64 ? 2 : 1, TN = 1;      // 128x64 (cd x cg) measured best for >= 128-channel layers
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
     int64_t nsplit = (1536 + tiles - 1) / tiles;

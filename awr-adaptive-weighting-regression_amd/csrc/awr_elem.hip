@@ -68,8 +68,15 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double cou
                                    float* __restrict__ invstd_o) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = stats[c] / count;
-    double var = stats[C + c] / count - mean * mean;  // biased variance normalises the batch
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {   // producers spread their atomics over the slots
+        s1 += stats[(size_t)k * 2 * C + c];
+        s2 += stats[(size_t)k * 2 * C + C + c];
+        stats[(size_t)k * 2 * C + c] = 0.0;
+        stats[(size_t)k * 2 * C + C + c] = 0.0;
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;  // biased variance normalises the batch
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -83,8 +90,6 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double cou
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;  // running var is unbiased
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
-    stats[c] = 0.0;
-    stats[C + c] = 0.0;
 }
 
 __global__ void bn_fold_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
@@ -154,8 +159,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             if (MODE == 2) {
                 atomicAdd(out32 + c, (float)a[k]);
             } else {
-                atomicAdd(out64 + c, a[k]);
-                atomicAdd(out64 + C + c, b[k]);
+                double* o = out64 + (MODE == 0 ? (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * C : 0);
+                atomicAdd(o + c, a[k]);
+                atomicAdd(o + C + c, b[k]);
             }
         }
     }

@@ -20,6 +20,7 @@ from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, N_ALIGN
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+STAT_SLOTS = 16     # AWR_STAT_SLOTS in include/awr_hip.h
 
 
 class T:
@@ -203,7 +204,7 @@ class Plan:
         assert prob["full"], "forward transposed conv must cover all phases"
         y = self.new(B, prob["Hout"], prob["Wout"], prob["N"], name=layer.name + ".out")
         if want_stats:
-            y.stats = self.alloc(2, prob["N"], dtype=torch.float64, zero=True)
+            y.stats = self.alloc(STAT_SLOTS, 2, prob["N"], dtype=torch.float64, zero=True)
         bias = layer.bias_ptr() if use_bias else None
         a = make_conv_args(prob, B, x.buf, layer.p_fwd, y.buf, in_scale=in_affine[0] if in_affine else None,
                            in_shift=in_affine[1] if in_affine else None, bias=bias,
@@ -266,7 +267,7 @@ class Plan:
         assert self.training
         B, H, W, C_ = y.shape
         if y.stats is None:
-            y.stats = self.alloc(2, C_, dtype=torch.float64, zero=True)
+            y.stats = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
             self._f("awr_channel_stats", L.ptr(y.buf), y.npix, C_, L.ptr(y.stats))
             own_stats = y.stats
         else:

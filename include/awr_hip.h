@@ -30,6 +30,10 @@ extern "C" {
 #define AWR_ERR_HIP (-2)
 #define AWR_ERR_UNSUPPORTED (-3)
 
+/* BatchNorm statistic accumulators are [AWR_STAT_SLOTS][2][C] doubles: producers spread their atomics over
+ * the slots (less L2 serialisation), awr_bn_finalize sums the slots and zeroes them. */
+#define AWR_STAT_SLOTS 16
+
 int awr_version(void);
 const char* awr_last_error(void);
 /* number of compute units / device name of the current device (diagnostics for bench.py) */
@@ -125,8 +129,8 @@ typedef struct awr_conv_args {
     const float* out_scale; /* optional per-output-channel affine after bias (folded eval BN)    */
     const float* out_shift;
     const float* res;       /* optional tensor added element-wise, same shape as out            */
-    double* stats;          /* optional [2][N]: += sum and sum of squares of the stored value
-                               (taken after bias/affine/res, before relu_out)                    */
+    double* stats;          /* optional [AWR_STAT_SLOTS][2][N]: += sum and sum of squares of the stored
+                               value (taken after bias/affine/res, before relu_out)              */
     int B, Hin, Win, Cin;
     int Hq, Wq;             /* per-phase output grid */
     int Hout, Wout, N;
@@ -169,7 +173,8 @@ int awr_bn_finalize(double* stats, int C, int64_t count, const float* gamma, con
 /* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, float* scale, float* shift, void* stream);
-/* per-channel sum / sum of squares of an NHWC tensor (for BNs whose input is not a conv output) */
+/* per-channel sum / sum of squares of an NHWC tensor (for BNs whose input is not a conv output);
+ * stats is [AWR_STAT_SLOTS][2][C] like the conv epilogue's */
 int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream);
 /* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,

@@ -121,13 +121,13 @@ def test_conv_fused_prologue_epilogue_stats(ops, dev):
     a = TF.relu(x.double() * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1))
     pre = (TF.conv2d(a, w.double(), bias.double(), 1, 1)) * so.double().view(1, -1, 1, 1) + to.double().view(1, -1, 1, 1) + res.double()
     ref = TF.relu(pre)
-    stats = torch.zeros(2, cout, device=dev, dtype=torch.float64)
+    stats = torch.zeros(16, 2, cout, device=dev, dtype=torch.float64)
     wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
     y = ops.conv_forward(spec, ops.nhwc(x).to(dev), wp, in_scale=s.to(dev), in_shift=t.to(dev), relu_in=True, bias=bias.to(dev),
                          out_scale=so.to(dev), out_shift=to.to(dev), res=ops.nhwc(res).to(dev), relu_out=True, stats=stats)
     assert rel_err(ops.nchw(y).cpu(), ref) < 2e-6
-    assert rel_err(stats[0].cpu(), pre.sum((0, 2, 3))) < 1e-5
-    assert rel_err(stats[1].cpu(), (pre * pre).sum((0, 2, 3))) < 1e-5
+    assert rel_err(stats.sum(0)[0].cpu(), pre.sum((0, 2, 3))) < 1e-5          # [AWR_STAT_SLOTS][2][N]
+    assert rel_err(stats.sum(0)[1].cpu(), (pre * pre).sum((0, 2, 3))) < 1e-5
 
 
 def test_stem_im2col_gemm(ops, L, dev):
@@ -163,7 +163,7 @@ def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     from awr_amd import ops
     npix = B * H * H
     xg = ops.nhwc(x).to(dev)
-    stats = torch.zeros(2, C, device=dev, dtype=torch.float64)
+    stats = torch.zeros(16, 2, C, device=dev, dtype=torch.float64)
     L.call("awr_channel_stats", L.ptr(xg), npix, C, L.ptr(stats), L.stream())
     scale, shift, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
     rmg, rvg = rm.to(dev), rv.to(dev)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Microbenchmark of awr_conv_gemm / awr_conv_wgrad on single layers (GPU box only).
+
+    python tools/microbench_gemm.py ksweep      # time vs number of K-slices at fixed M,N: fixed cost per workgroup
+    python tools/microbench_gemm.py layers      # the ResNet18 layer shapes at --batch
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import awr_amd  # noqa: E402,F401
+from awr_amd import _lib as L  # noqa: E402
+from awr_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def run_fwd(spec, B, H, tile=None, stats=False):
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, H, H, spec.cin_pad, device=dev)
+    wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == "conv" else (spec.cin, spec.cout, spec.k, spec.k)
+    w = torch.randn(*wshape, device=dev) * 0.05
+    wp = ops.pack_weight(w, spec.fwd_pack())
+    prob = spec.fwd_problem(H, H)
+    out = torch.empty(B, prob["Hout"], prob["Wout"], prob["N"], device=dev)
+    st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64) if stats else None
+    a = ops.make_conv_args(prob, B, x, wp, out, stats=st, T=spec.T)
+    if tile:
+        L.call("awr_debug_force_tile", *tile)
+    s = L.stream()
+    t = timeit(lambda: L.check(L.lib.awr_conv_gemm(C.byref(a), s)))
+    L.call("awr_debug_force_tile", 0, 0)
+    macs = B * prob["Hout"] * prob["Wout"] * spec.cout * spec.cin * (spec.T if spec.kind == "conv" else spec.T / 4)
+    return t, 2 * macs / t / 1e12
+
+
+def run_wgrad(spec, B, H, tile=None):
+    dev = torch.device("cuda:0")
+    prob = spec.wgrad_problem(H, H)
+    ho, wo = spec.out_hw(H, H)
+    x = torch.randn(B, H, H, spec.cin_pad, device=dev)
+    dy = torch.randn(B, ho, wo, spec.cout_pad, device=dev)
+    D, G = (dy, x) if prob["D"] == "dy" else (x, dy)
+    R = torch.zeros(prob["Cd"], len(prob["taps"]), prob["Cg"], device=dev)
+    a = ops.make_wgrad_args(prob, B, D, G, R, prob["Cg"])
+    if tile:
+        L.call("awr_debug_force_tile", *tile)
+    s = L.stream()
+    t = timeit(lambda: L.check(L.lib.awr_conv_wgrad(C.byref(a), s)))
+    L.call("awr_debug_force_tile", 0, 0)
+    macs = B * ho * wo * spec.cout * spec.cin * (spec.T if spec.kind == "conv" else spec.T / 4)
+    return t, 2 * macs / t / 1e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mode", choices=["ksweep", "layers"])
+    ap.add_argument("--batch", type=int, default=64)
+    args = ap.parse_args()
+    if args.mode == "ksweep":
+        print("1x1 conv, M = 64*64*64 = 262144 rows; time = a + b * (K/32)")
+        for tile, cout in (((2, 2), 128), ((2, 1), 64), ((1, 1), 64)):
+            pts = []
+            for nk in (1, 2, 4, 8, 16, 32, 64):
+                t, tf = run_fwd(ops.ConvSpec("conv", 32 * nk, cout, 1, 1, 0), 64, 64, tile)
+                pts.append((nk, t))
+                print("tile %s N=%3d  K-slices %3d : %8.1f us  %6.1f TF" % (tile, cout, nk, t * 1e6, tf))
+            (n0, t0), (n1, t1) = pts[-2], pts[-1]
+            b = (t1 - t0) / (n1 - n0)
+            print("   -> per-slice %.2f us, fixed %.1f us  (= %.1f slices)" % (b * 1e6, (t1 - b * n1) * 1e6, (t1 - b * n1) / b))
+    else:
+        B = args.batch
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8),
+                  ("deconv 512->256 @8", ops.ConvSpec("deconv", 512, 256, 4, 2, 1), 8), ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32)]
+        for name, spec, H in shapes:
+            best = []
+            for tile in ((2, 2), (2, 1), (1, 2), (1, 1)):
+                if spec.cout <= 64 and tile[1] == 2:
+                    continue
+                t, tf = run_fwd(spec, B, H, tile)
+                tw, tfw = run_wgrad(spec, B, H, tile)
+                best.append("%s fwd %.0fus %.0fTF | wgrad %.0fus %.0fTF" % (tile, t * 1e6, tf, tw * 1e6, tfw))
+            t, tf = run_fwd(spec, B, H)
+            print("%-28s auto fwd %.0f TF" % (name, tf))
+            for b_ in best:
+                print("      " + b_)
+
+
+if __name__ == "__main__":
+    main()
