@@ -78,8 +78,8 @@ _SIGS = {
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),
     "awr_channel_stats": ([_P, _L, _I, _P, _P], C.c_int),
     "awr_bn_apply": ([_P, _P, _P, _P, _I, _P, _L, _I, _P], C.c_int),
-    "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _L, _I, _P, _P], C.c_int),
-    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
+    "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P], C.c_int),
+    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
     "awr_relu_bwd": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_add": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_bias_grad": ([_P, _L, _I, _P, _I, _P], C.c_int),

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
 // R[cd][t][cg] += sum_{m in K-chunk} D[m][cd] * G[gather(m,t)][cg]      (split-K over pixels)
 // ------------------------------------------------------------------------------------------
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LDM = BM + 4, LDN = BN + 4;
     constexpr int FM = BM / 4, FN = BN / 4;          // float4 per pixel row
@@ -311,7 +311,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int m = m0 + ga_r + PN * i;
-            const int x = m % a.Wd, tt = m / a.Wd, y = tt % a.Hd, b = tt / a.Hd;
+            int x, y, b;
+            if (wshift >= 0) {      // power-of-two feature maps (every layer of both backbones): no integer division per slice
+                x = m & (a.Wd - 1);
+                const int tt = m >> wshift;
+                y = tt & (a.Hd - 1);
+                b = tt >> hshift;
+            } else {
+                x = m % a.Wd;
+                const int tt = m / a.Wd;
+                y = tt % a.Hd;
+                b = tt / a.Hd;
+            }
             const int gy = y * a.sg + dy, gx = x * a.sg + dx;
             const bool ok = m < m_end && g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
             rg[i] = buf_ld4(rs_g, ok ? ((unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg) * 4u + g_col : OOB);
@@ -432,10 +443,13 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     nsplit = (M + chunk - 1) / chunk;
     const dim3 grid((unsigned)tiles, (unsigned)nsplit);
     hipStream_t st = as_stream(stream);
-    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, *a, (int)chunk);
-    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, *a, (int)chunk);
-    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, *a, (int)chunk);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, *a, (int)chunk);
+    auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    int wshift = log2i(a->Wd), hshift = log2i(a->Hd);
+    if (wshift < 0 || hshift < 0) wshift = hshift = -1;
+    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
+    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
+    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
     return check_launch("conv_wgrad_kernel");
 }
 

@@ -106,7 +106,8 @@ __global__ void bn_fold_eval_kernel(int C, const float* __restrict__ gamma, cons
 // through LDS and leave the workgroup as one fp64 atomic per channel per statistic.
 template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2: sum x only (bias grad, fp32 out)
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ y,
-                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int64_t npix,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ msc, const float* __restrict__ msh, int64_t npix,
                                                          int C, int rows_per_block, double* __restrict__ out64, float* __restrict__ out32) {
     const int C4 = C >> 2;
     const int rpp = 256 / C4;  // row groups per pass
@@ -117,9 +118,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     if (r1 > npix) r1 = npix;
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+    float4 ks = make_float4(0, 0, 0, 0), kt = make_float4(0, 0, 0, 0);
     if (MODE == 1 && active) {
         mu = ld4(mean + cg * 4);
         is = ld4(invstd + cg * 4);
+        if (msc) {
+            ks = ld4(msc + cg * 4);
+            kt = ld4(msh + cg * 4);
+        }
     }
     if (active) {
         for (int64_t r = r0 + rg; r < r1; r += rpp) {
@@ -129,11 +135,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
             } else if (MODE == 1) {
+                const float4 yy = ld4(y + o);
                 if (act) {
                     const float4 a = ld4(act + o);
                     v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                } else if (msc) {   // ReLU mask recomputed exactly as bn_apply computed the activation: relu(y*scale+shift) > 0
+                    v.x = yy.x * ks.x + kt.x > 0.f ? v.x : 0.f; v.y = yy.y * ks.y + kt.y > 0.f ? v.y : 0.f;
+                    v.z = yy.z * ks.z + kt.z > 0.f ? v.z : 0.f; v.w = yy.w * ks.w + kt.w > 0.f ? v.w : 0.f;
                 }
-                const float4 yy = ld4(y + o);
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x += v.x * ((yy.x - mu.x) * is.x); s2.y += v.y * ((yy.y - mu.y) * is.y);
                 s2.z += v.z * ((yy.z - mu.z) * is.z); s2.w += v.w * ((yy.w - mu.w) * is.w);
@@ -186,7 +195,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act, const float* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, const double* __restrict__ sums, double inv_count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ msc,
+                                                           const float* __restrict__ msh, const double* __restrict__ sums, double inv_count,
                                                            int64_t n4, int C, float* dy, const float* dy_add, float* __restrict__ g_out,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     const int C4 = C >> 2;
@@ -200,12 +210,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
     if (i >= n4) return;
     const int cg = (int)(i % C4);
     float4 g = ld4(dout + i * 4);
+    const float4 yy = ld4(y + i * 4), mu = ld4(mean + cg * 4), is = ld4(invstd + cg * 4);
     if (act) {
         const float4 a = ld4(act + i * 4);
         g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+    } else if (msc) {
+        const float4 ks = ld4(msc + cg * 4), kt = ld4(msh + cg * 4);
+        g.x = yy.x * ks.x + kt.x > 0.f ? g.x : 0.f; g.y = yy.y * ks.y + kt.y > 0.f ? g.y : 0.f;
+        g.z = yy.z * ks.z + kt.z > 0.f ? g.z : 0.f; g.w = yy.w * ks.w + kt.w > 0.f ? g.w : 0.f;
     }
     if (g_out) st4(g_out + i * 4, g);
-    const float4 yy = ld4(y + i * 4), mu = ld4(mean + cg * 4), is = ld4(invstd + cg * 4);
     const float4 ga = gamma ? ld4(gamma + cg * 4) : make_float4(1, 1, 1, 1);
     float k1[4], k2[4];
 #pragma unroll
@@ -387,8 +401,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
-static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd, int64_t npix,
-                             int C, double* out64, float* out32, hipStream_t st) {
+static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd,
+                             const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, hipStream_t st) {
     AWR_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "channel reduction: C=%d must be a multiple of 4 in [4,1024]", C);
     AWR_REQUIRE(npix > 0, "channel reduction: empty tensor");
     const int rpp = 256 / (C / 4);
@@ -397,11 +411,11 @@ static int col_reduce_launch(int mode, const float* x, const float* act, const f
     rows = (rows + rpp - 1) / rpp * rpp;
     const unsigned grid = (unsigned)((npix + rows - 1) / rows);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
     else if (mode == 1)
-        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
     return check_launch("col_reduce_kernel");
 }
 
@@ -451,7 +465,7 @@ int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* 
 
 int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream) {
     AWR_REQUIRE(x && stats, "channel_stats: null pointer");
-    return col_reduce_launch(0, x, nullptr, nullptr, nullptr, nullptr, npix, C, stats, nullptr, as_stream(stream));
+    return col_reduce_launch(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, stats, nullptr, as_stream(stream));
 }
 
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu, float* out, int64_t npix, int C,
@@ -462,18 +476,19 @@ int awr_bn_apply(const float* x, const float* scale, const float* shift, const f
     return check_launch("bn_apply_kernel");
 }
 
-int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, int64_t npix, int C,
-                      double* sums, void* stream) {
+int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* mask_scale,
+                      const float* mask_shift, int64_t npix, int C, double* sums, void* stream) {
     AWR_REQUIRE(dout && y && mean && invstd && sums, "bn_bwd_reduce: null pointer");
-    return col_reduce_launch(1, dout, act, y, mean, invstd, npix, C, sums, nullptr, as_stream(stream));
+    AWR_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(act && mask_scale), "bn_bwd_reduce: give act OR mask_scale+mask_shift");
+    return col_reduce_launch(1, dout, act, y, mean, invstd, mask_scale, mask_shift, npix, C, sums, nullptr, as_stream(stream));
 }
 
 int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     double* sums, int64_t npix, int C, float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate,
+                     const float* mask_scale, const float* mask_shift, double* sums, int64_t npix, int C, float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate,
                      void* stream) {
     AWR_REQUIRE(dout && y && mean && invstd && sums && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, gamma, sums,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, gamma, mask_scale, mask_shift, sums,
                        1.0 / (double)npix, n4, C, dy, dy_add, g_out, dgamma, dbeta, accumulate);
     if (int e = check_launch("bn_bwd_apply_kernel")) return e;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, as_stream(stream)) != hipSuccess) {
@@ -501,7 +516,7 @@ int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulat
         set_error("bias_grad: hipMemsetAsync failed");
         return AWR_ERR_HIP;
     }
-    return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, as_stream(stream));
+    return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, as_stream(stream));
 }
 
 int awr_maxpool_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* out, uint8_t* argmax, void* stream) {

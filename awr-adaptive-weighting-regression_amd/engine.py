@@ -282,16 +282,18 @@ class Plan:
         a = self.new(B, H, W, C_, name=bn.name + ".act")
         self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
                 y.npix, C_)
-        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd))
+        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh))
         return a
 
-    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd):
+    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd, sc, sh):
         da = a.grad
         assert da is not None, "no gradient reached %s" % a.name
         C_ = y.shape[3]
         sums = self.alloc(2, C_, dtype=torch.float64, zero=True)
-        act = L.ptr(a.buf) if relu else None
-        self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), y.npix, C_, L.ptr(sums))
+        # ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
+        act = L.ptr(a.buf) if (relu and res is not None) else None
+        msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None) else (None, None)
+        self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums))
         gy, acc = self._gtarget(y) if y.needs_grad else (self.alloc(*y.shape), False)
         g_out, post_add = None, None
         if res is not None and res.needs_grad:
@@ -304,7 +306,7 @@ class Plan:
                     post_add = g_out
             else:
                 pass  # handled below: identity of da
-        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), L.ptr(sums), y.npix, C_,
+        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), y.npix, C_,
                 L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
         if post_add is not None:
             self._b("awr_add", L.ptr(res.grad), L.ptr(post_add), L.ptr(res.grad), post_add.numel())

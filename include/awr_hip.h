@@ -179,14 +179,18 @@ int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* 
 /* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,
                  float* out, int64_t npix, int C, void* stream);
-/* backward pass 1: g = dout * (act>0 if act) ; sums[0][c] += sum g ; sums[1][c] += sum g*xhat */
+/* backward pass 1: g = dout * relu_mask ; sums[0][c] += sum g ; sums[1][c] += sum g*xhat.
+ * relu_mask: (act > 0) if act is given; (y*mask_scale+mask_shift > 0) if mask_scale/shift are given (the
+ * activation is re-derived from y with the forward's scale/shift: no read of the activation tensor); else 1. */
 int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean,
-                      const float* invstd, int64_t npix, int C, double* sums, void* stream);
+                      const float* invstd, const float* mask_scale, const float* mask_shift, int64_t npix,
+                      int C, double* sums, void* stream);
 /* backward pass 2: dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) [+ dy_add]; optional g_out = g
  * (residual branch); dgamma/dbeta (+)= sums (accumulate); zeroes sums afterwards.  dy may alias
  * dy_add or dout. */
 int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean,
-                     const float* invstd, const float* gamma, double* sums, int64_t npix, int C,
+                     const float* invstd, const float* gamma, const float* mask_scale,
+                     const float* mask_shift, double* sums, int64_t npix, int C,
                      float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta,
                      int accumulate, void* stream);
 /* plain ReLU backward / mask: g = dout * (act > 0) */
