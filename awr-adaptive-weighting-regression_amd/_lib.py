@@ -47,6 +47,22 @@ class ConvArgs(C.Structure):
                 ("ph", Phase * 4)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("transpose", C.c_int),
+                ("rows", C.c_int), ("ld", C.c_int), ("first", C.c_int64)]
+
+
+class UnpackJob(C.Structure):
+    _fields_ = [("packed", C.c_void_p), ("grad", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("ld", C.c_int),
+                ("first", C.c_int64)]
+
+
+def job_table(jobs, device):
+    """ctypes structs -> device byte tensor (the batched kernels read the table from HBM)."""
+    arr = (type(jobs[0]) * len(jobs))(*jobs)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("D", C.c_void_p), ("G", C.c_void_p), ("R", C.c_void_p),
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
@@ -70,6 +86,8 @@ _SIGS = {
     "awr_sgd_step": ([_P, _P, _P, _L, _F, _F, _F, _L, _F, _P], C.c_int),
     "awr_pack_weight": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "awr_unpack_wgrad": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_pack_weights_batched": ([_P, _I, _L, _P], C.c_int),
+    "awr_unpack_wgrads_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),
@@ -79,7 +97,7 @@ _SIGS = {
     "awr_channel_stats": ([_P, _L, _I, _P, _P], C.c_int),
     "awr_bn_apply": ([_P, _P, _P, _P, _I, _P, _L, _I, _P], C.c_int),
     "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P], C.c_int),
-    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
+    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
     "awr_relu_bwd": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_add": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_bias_grad": ([_P, _L, _I, _P, _I, _P], C.c_int),

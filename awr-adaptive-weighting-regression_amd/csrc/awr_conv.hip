@@ -18,6 +18,8 @@
 //     (bias, folded BN, residual add, ReLU, per-channel sum / sum-of-squares for the next
 //     BatchNorm) remove whole HBM passes.
 //   * XCD-aware workgroup remap: consecutive tiles of one row-panel land on the same XCD's L2.
+#include <stdlib.h>
+
 #include "awr_common.h"
 
 namespace awr {
@@ -431,10 +433,14 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
                 "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
-    int TM = a->Cd > 64 ? 2 : 1, TN = 1;      // 128x64 (cd x cg) measured best for >= 128-channel layers
+    // measured (tools/microbench_gemm.py, AWR_WGRAD_BLOCKS sweep): 64x64 tiles with ~3072 workgroups win on the small
+    // feature maps; the 128x64 (cd x cg) tile with ~2048 workgroups wins once there are >= 128K pixels to contract.
+    int TM = (a->Cd > 64 && M >= 131072) ? 2 : 1, TN = 1;
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
-    int64_t nsplit = (1536 + tiles - 1) / tiles;
+    static const int target_blocks = []() { const char* e = getenv("AWR_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning hook
+    const int want_blocks = target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
+    int64_t nsplit = (want_blocks + tiles - 1) / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 8 K-slices per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

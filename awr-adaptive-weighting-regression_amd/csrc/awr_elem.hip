@@ -40,6 +40,45 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     grad[idx] = accumulate ? grad[idx] + v : v;
 }
 
+// batched variants: binary-search the job table by running element offset (a few hundred jobs at most)
+template <typename Job>
+__device__ __forceinline__ int find_job(const Job* __restrict__ jobs, int n, int64_t idx) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first <= idx) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* __restrict__ jobs, int n, int64_t total) {
+    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= total) return;
+    const awr_pack_job jb = jobs[find_job(jobs, n, gidx)];
+    const int64_t idx = gidx - jb.first;
+    const int c = (int)(idx % jb.ld);
+    const int t = (int)((idx / jb.ld) % jb.T);
+    const int r = (int)(idx / ((int64_t)jb.ld * jb.T));
+    float v = 0.f;
+    if (!jb.transpose) {
+        if (r < jb.d0 && c < jb.d1) v = jb.src[((int64_t)r * jb.d1 + c) * jb.T + t];
+    } else {
+        if (r < jb.d1 && c < jb.d0) v = jb.src[((int64_t)c * jb.d1 + r) * jb.T + t];
+    }
+    jb.dst[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void unpack_batched_kernel(const awr_unpack_job* __restrict__ jobs, int n, int64_t total) {
+    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= total) return;
+    const awr_unpack_job jb = jobs[find_job(jobs, n, gidx)];
+    const int64_t idx = gidx - jb.first;
+    const int t = (int)(idx % jb.T);
+    const int b = (int)((idx / jb.T) % jb.d1);
+    const int a = (int)(idx / ((int64_t)jb.T * jb.d1));
+    jb.grad[idx] = jb.packed[((int64_t)a * jb.T + t) * jb.ld + b];
+}
+
 // cols[b][y][x][k] = img[b][y+k/5-2][x+k%5-2] for k < 25, 0 for k in [25,32) and outside the image
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, int B, int H, int W, float* __restrict__ cols) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 = 4 taps
@@ -127,28 +166,45 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             kt = ld4(msh + cg * 4);
         }
     }
-    if (active) {
-        for (int64_t r = r0 + rg; r < r1; r += rpp) {
-            const int64_t o = r * C + cg * 4;
-            float4 v = ld4(x + o);
-            if (MODE == 0) {
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
-            } else if (MODE == 1) {
-                const float4 yy = ld4(y + o);
-                if (act) {
-                    const float4 a = ld4(act + o);
-                    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
-                } else if (msc) {   // ReLU mask recomputed exactly as bn_apply computed the activation: relu(y*scale+shift) > 0
-                    v.x = yy.x * ks.x + kt.x > 0.f ? v.x : 0.f; v.y = yy.y * ks.y + kt.y > 0.f ? v.y : 0.f;
-                    v.z = yy.z * ks.z + kt.z > 0.f ? v.z : 0.f; v.w = yy.w * ks.w + kt.w > 0.f ? v.w : 0.f;
-                }
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x += v.x * ((yy.x - mu.x) * is.x); s2.y += v.y * ((yy.y - mu.y) * is.y);
-                s2.z += v.z * ((yy.z - mu.z) * is.z); s2.w += v.w * ((yy.w - mu.w) * is.w);
-            } else {
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    // one row (all operands) -> partial sums
+    auto accum = [&](float4 v, float4 aa, float4 yy) {
+        if (MODE == 0) {
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+        } else if (MODE == 1) {
+            if (act) {
+                v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
+            } else if (msc) {   // ReLU mask recomputed exactly as bn_apply computed the activation: relu(y*scale+shift) > 0
+                v.x = yy.x * ks.x + kt.x > 0.f ? v.x : 0.f; v.y = yy.y * ks.y + kt.y > 0.f ? v.y : 0.f;
+                v.z = yy.z * ks.z + kt.z > 0.f ? v.z : 0.f; v.w = yy.w * ks.w + kt.w > 0.f ? v.w : 0.f;
             }
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * ((yy.x - mu.x) * is.x); s2.y += v.y * ((yy.y - mu.y) * is.y);
+            s2.z += v.z * ((yy.z - mu.z) * is.z); s2.w += v.w * ((yy.w - mu.w) * is.w);
+        } else {
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        }
+    };
+    if (active) {
+        // 4 rows per trip: up to 12 independent 16-byte loads in flight per lane (the loop is latency-bound otherwise)
+        constexpr int U = 4;
+        int64_t r = r0 + rg;
+        const float4 z4 = make_float4(0, 0, 0, 0);
+        for (; r + (int64_t)(U - 1) * rpp < r1; r += (int64_t)U * rpp) {
+            float4 v[U], aa[U], yy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t o = (r + (int64_t)u * rpp) * C + cg * 4;
+                v[u] = ld4(x + o);
+                aa[u] = (MODE == 1 && act) ? ld4(act + o) : z4;
+                yy[u] = (MODE == 1) ? ld4(y + o) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) accum(v[u], aa[u], yy[u]);
+        }
+        for (; r < r1; r += rpp) {
+            const int64_t o = r * C + cg * 4;
+            accum(ld4(x + o), (MODE == 1 && act) ? ld4(act + o) : z4, (MODE == 1) ? ld4(y + o) : z4);
         }
     }
     __shared__ float4 sh1[256], sh2[256];
@@ -168,7 +224,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             if (MODE == 2) {
                 atomicAdd(out32 + c, (float)a[k]);
             } else {
-                double* o = out64 + (MODE == 0 ? (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * C : 0);
+                double* o = out64 + (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * C;
                 atomicAdd(o + c, a[k]);
                 atomicAdd(o + C + c, b[k]);
             }
@@ -193,20 +249,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     st4(out + i * 4, o);
 }
 
+// collapse the slot-spread backward sums into per-channel coefficients, emit dgamma/dbeta, re-arm the accumulator
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, double inv_count, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ coef, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {
+        s1 += sums[(size_t)k * 2 * C + c];
+        s2 += sums[(size_t)k * 2 * C + C + c];
+        sums[(size_t)k * 2 * C + c] = 0.0;
+        sums[(size_t)k * 2 * C + C + c] = 0.0;
+    }
+    coef[c] = (float)(s1 * inv_count);                        // mean of g
+    coef[C + c] = (float)(s2 * inv_count);                    // mean of g * xhat
+    coef[2 * C + c] = (gamma ? gamma[c] : 1.f) * invstd[c];   // gamma * invstd
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act, const float* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, const float* __restrict__ msc,
-                                                           const float* __restrict__ msh, const double* __restrict__ sums, double inv_count,
-                                                           int64_t n4, int C, float* dy, const float* dy_add, float* __restrict__ g_out,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                                           const float* __restrict__ msc, const float* __restrict__ msh,
+                                                           const float* __restrict__ coef, int64_t n4, int C, float* dy, const float* dy_add,
+                                                           float* __restrict__ g_out) {
     const int C4 = C >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0) {  // parameter gradients: dgamma = sum g*xhat, dbeta = sum g
-        for (int c = threadIdx.x; c < C; c += 256) {
-            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
-            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
-        }
-    }
     if (i >= n4) return;
     const int cg = (int)(i % C4);
     float4 g = ld4(dout + i * 4);
@@ -220,18 +289,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
         g.z = yy.z * ks.z + kt.z > 0.f ? g.z : 0.f; g.w = yy.w * ks.w + kt.w > 0.f ? g.w : 0.f;
     }
     if (g_out) st4(g_out + i * 4, g);
-    const float4 ga = gamma ? ld4(gamma + cg * 4) : make_float4(1, 1, 1, 1);
-    float k1[4], k2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        k1[k] = (float)(sums[cg * 4 + k] * inv_count);
-        k2[k] = (float)(sums[C + cg * 4 + k] * inv_count);
-    }
+    const float4 k1 = ld4(coef + cg * 4), k2 = ld4(coef + C + cg * 4), gi = ld4(coef + 2 * C + cg * 4);
     float4 o;
-    o.x = ga.x * is.x * (g.x - k1[0] - (yy.x - mu.x) * is.x * k2[0]);
-    o.y = ga.y * is.y * (g.y - k1[1] - (yy.y - mu.y) * is.y * k2[1]);
-    o.z = ga.z * is.z * (g.z - k1[2] - (yy.z - mu.z) * is.z * k2[2]);
-    o.w = ga.w * is.w * (g.w - k1[3] - (yy.w - mu.w) * is.w * k2[3]);
+    o.x = gi.x * (g.x - k1.x - (yy.x - mu.x) * is.x * k2.x);
+    o.y = gi.y * (g.y - k1.y - (yy.y - mu.y) * is.y * k2.y);
+    o.z = gi.z * (g.z - k1.z - (yy.z - mu.z) * is.z * k2.z);
+    o.w = gi.w * (g.w - k1.w - (yy.w - mu.w) * is.w * k2.w);
     if (dy_add) {
         const float4 e = ld4(dy_add + i * 4);
         o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
@@ -406,7 +469,7 @@ static int col_reduce_launch(int mode, const float* x, const float* act, const f
     AWR_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "channel reduction: C=%d must be a multiple of 4 in [4,1024]", C);
     AWR_REQUIRE(npix > 0, "channel reduction: empty tensor");
     const int rpp = 256 / (C / 4);
-    int64_t rows = (npix + 1023) / 1024;  // <= 1024 workgroups
+    int64_t rows = (npix + 1023) / 1024;  // <= 1024 workgroups; their atomics are spread over AWR_STAT_SLOTS copies
     if (rows < 64) rows = 64;
     rows = (rows + rpp - 1) / rpp * rpp;
     const unsigned grid = (unsigned)((npix + rows - 1) / rows);
@@ -439,6 +502,18 @@ int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* 
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblk((int64_t)d0 * d1 * T)), dim3(256), 0, as_stream(stream), packed, d0, d1, T, ld, grad,
                        accumulate);
     return check_launch("unpack_wgrad_kernel");
+}
+
+int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total, void* stream) {
+    AWR_REQUIRE(jobs_dev && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), jobs_dev, njobs, total);
+    return check_launch("pack_batched_kernel");
+}
+
+int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total, void* stream) {
+    AWR_REQUIRE(jobs_dev && njobs > 0 && total > 0, "unpack_wgrads_batched: bad arguments");
+    hipLaunchKernelGGL(unpack_batched_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), jobs_dev, njobs, total);
+    return check_launch("unpack_batched_kernel");
 }
 
 int awr_stem_im2col(const float* img, int B, int H, int W, float* cols, void* stream) {
@@ -484,18 +559,16 @@ int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const
 }
 
 int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* mask_scale, const float* mask_shift, double* sums, int64_t npix, int C, float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate,
-                     void* stream) {
-    AWR_REQUIRE(dout && y && mean && invstd && sums && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+                     const float* mask_scale, const float* mask_shift, double* sums, float* coef, int64_t npix, int C, float* dy,
+                     const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate, void* stream) {
+    AWR_REQUIRE(dout && y && mean && invstd && sums && coef && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), sums, C, 1.0 / (double)npix, gamma, invstd,
+                       coef, dgamma, dbeta, accumulate);
+    if (int e = check_launch("bn_bwd_finalize_kernel")) return e;
     const int64_t n4 = npix * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, gamma, mask_scale, mask_shift, sums,
-                       1.0 / (double)npix, n4, C, dy, dy_add, g_out, dgamma, dbeta, accumulate);
-    if (int e = check_launch("bn_bwd_apply_kernel")) return e;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, as_stream(stream)) != hipSuccess) {
-        set_error("bn_bwd_apply: hipMemsetAsync failed");
-        return AWR_ERR_HIP;
-    }
-    return AWR_OK;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
+                       coef, n4, C, dy, dy_add, g_out);
+    return check_launch("bn_bwd_apply_kernel");
 }
 
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream) {

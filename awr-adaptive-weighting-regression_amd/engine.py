@@ -66,6 +66,8 @@ class ConvLayer:
                 calls.append(("awr_pack_weight", (L.ptr(self.w), d0, d1, T_, tr, rows, ld, L.ptr(dst))))
         return calls
 
+    batchable = True       # plain layers go through the one-launch batched pack / unpack tables
+
     def bias_ptr(self):
         return self.bias
 
@@ -80,6 +82,7 @@ class ConvLayer:
 class HeadLayer(ConvLayer):
     """final1 (256->3J) and final2 (256->J) 1x1 convs fused into one 256->Cp GEMM (Cp = 4J rounded up
     to 32; extra rows are zero).  resnet_deconv.py:52-53,:133-136 / hourglass.py:137-138,:153-157."""
+    batchable = False
 
     def __init__(self, cin, J, w1, gw1, b1, gb1, w2, gw2, b2, gb2, name=""):
         self.J, self.cin = J, cin
@@ -137,6 +140,8 @@ class Plan:
         self.bytes = 0
         self._built_bwd = False
         self._bufs = []
+        self._scratch_buf, self._scratch_used, self._scratch_cap = None, 0, 0
+        self._unpack_jobs, self._unpack_tab, self._pack_tab = [], None, None
         self.macs = {}              # op name -> algorithmic MACs of that GEMM launch (bench.py roofline)
         self._keep = []             # ctypes argument structs referenced by the op lists
         self._head_states = []
@@ -159,6 +164,16 @@ class Plan:
 
     def new(self, B, H, W, C_, needs_grad=True, name=""):
         return T(self.alloc(B, H, W, C_), needs_grad, name)
+
+    def _scratch(self, n):
+        """Slice of the split-K scratch arena (sized on first use at build_backward; zeroed by ONE fill per step)."""
+        n = round_up(n, 4)
+        off = self._scratch_used
+        self._scratch_used += n
+        if self._scratch_buf is None:
+            self._scratch_buf = self.alloc(self._scratch_cap)
+        assert self._scratch_used <= self._scratch_cap, "wgrad scratch arena too small"
+        return self._scratch_buf[off:off + n]
 
     def _f(self, name, *args):
         self.fwd_ops.append((getattr(L.lib, name), args + (None,), name))
@@ -232,15 +247,18 @@ class Plan:
         # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
         wp = spec.wgrad_problem(H, W)
         ld = wp["Cg"]
-        R = self.alloc(wp["Cd"], len(wp["taps"]), ld)
+        R = self._scratch(wp["Cd"] * len(wp["taps"]) * ld).view(wp["Cd"], len(wp["taps"]), ld)
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
         wa = make_wgrad_args(wp, B, D, G, R, ld)
         self._keep.append(wa)
-        self.bwd_ops.append((None, (R,), "__zero__"))
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
-        for name, args in layer.wgrad_unpack_calls(R, ld):
-            self._b(name, *args)
+        if layer.batchable:        # scattered back to checkpoint layout by the single batched launch at the end of the backward
+            for name, args in layer.wgrad_unpack_calls(R, ld):
+                self._unpack_jobs.append(L.UnpackJob(args[0], args[5], args[1], args[2], args[3], args[4], 0))
+        else:
+            for name, args in layer.wgrad_unpack_calls(R, ld):
+                self._b(name, *args)
         # data gradient
         if x.needs_grad:
             dp = spec.dgrad_problem(H, W)
@@ -289,7 +307,8 @@ class Plan:
         da = a.grad
         assert da is not None, "no gradient reached %s" % a.name
         C_ = y.shape[3]
-        sums = self.alloc(2, C_, dtype=torch.float64, zero=True)
+        sums = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
+        coef = self.alloc(3, C_)
         # ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
         act = L.ptr(a.buf) if (relu and res is not None) else None
         msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None) else (None, None)
@@ -306,7 +325,7 @@ class Plan:
                     post_add = g_out
             else:
                 pass  # handled below: identity of da
-        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), y.npix, C_,
+        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), L.ptr(coef), y.npix, C_,
                 L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
         if post_add is not None:
             self._b("awr_add", L.ptr(res.grad), L.ptr(post_add), L.ptr(res.grad), post_add.numel())
@@ -372,14 +391,40 @@ class Plan:
         assert self.training and not self._built_bwd
         for i, st in enumerate(self._head_states):
             st["used"] = i in supervised_stages
+        # split-K scratch for every weight gradient, as one arena (capacity = all packed gradients of the used layers)
+        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) for l in self.layers) + 64
+        first = len(self.bwd_ops)
         for emit in reversed(self.nodes):
             emit()
+        if self._scratch_buf is not None:
+            self.bwd_ops.insert(first, (None, (self._scratch_buf[:self._scratch_used],), "__zero__"))
+        if self._unpack_jobs:      # ONE launch scatters every packed weight gradient back to checkpoint layout
+            total = 0
+            for jb in self._unpack_jobs:
+                jb.first = total
+                total += jb.d0 * jb.d1 * jb.T
+            self._unpack_tab = L.job_table(self._unpack_jobs, self.dev)
+            self._b("awr_unpack_wgrads_batched", self._unpack_tab.data_ptr(), len(self._unpack_jobs), total)
         self._built_bwd = True
 
     def refresh_weights(self):
-        """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena."""
+        """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena: one batched launch for the
+        plain layers, a few extra calls for the fused heads."""
         s = L.stream()
+        if self._pack_tab is None:
+            jobs, total = [], 0
+            for layer in self.layers:
+                if layer.batchable:
+                    for name, args in layer.pack_calls():
+                        jobs.append(L.PackJob(args[0], args[7], args[1], args[2], args[3], args[4], args[5], args[6], total))
+                        total += args[5] * args[3] * args[6]
+            self._pack_tab = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
+        tab, njobs, total = self._pack_tab
+        if njobs:
+            L.check(L.lib.awr_pack_weights_batched(tab.data_ptr(), njobs, total, s), "awr_pack_weights_batched")
         for layer in self.layers:
+            if layer.batchable:
+                continue
             for name, args in layer.pack_calls():
                 if name == "__copy__":
                     args[0].copy_(args[1])

@@ -107,6 +107,24 @@ int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_
 int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* grad, int accumulate,
                      void* stream);
 
+/* Batched forms of the two calls above: ONE launch repacks / scatters every layer of a network.  The
+ * descriptor tables live in DEVICE memory (built once per plan); `first` is the running element offset of
+ * each job (packed elements for pack jobs, gradient elements for unpack jobs), `total` their sum. */
+typedef struct awr_pack_job {
+    const float* src;
+    float* dst;
+    int d0, d1, T, transpose, rows, ld;
+    int64_t first;
+} awr_pack_job;
+typedef struct awr_unpack_job {
+    const float* packed;
+    float* grad;
+    int d0, d1, T, ld;
+    int64_t first;
+} awr_unpack_job;
+int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total, void* stream);
+int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total, void* stream);
+
 /* Geometry of one implicit-GEMM convolution-like gather:
  *   out[b, qy*so+py, qx*so+px, n] = sum_{tap in phase} sum_c in[b, qy*si+dy, qx*si+dx, c] * P[n][wt][c]
  * conv kxk stride s pad p      : so=1, si=s, one phase, taps (dy,dx,wt)=(ky-p,kx-p,ky*k+kx)
@@ -179,7 +197,8 @@ int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* 
 /* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,
                  float* out, int64_t npix, int C, void* stream);
-/* backward pass 1: g = dout * relu_mask ; sums[0][c] += sum g ; sums[1][c] += sum g*xhat.
+/* backward pass 1: g = dout * relu_mask ; sums[slot][0][c] += sum g ; sums[slot][1][c] += sum g*xhat
+ * (sums is [AWR_STAT_SLOTS][2][C] doubles, zero before the first use; pass 2 re-arms it).
  * relu_mask: (act > 0) if act is given; (y*mask_scale+mask_shift > 0) if mask_scale/shift are given (the
  * activation is re-derived from y with the forward's scale/shift: no read of the activation tensor); else 1. */
 int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean,
@@ -187,10 +206,10 @@ int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const
                       int C, double* sums, void* stream);
 /* backward pass 2: dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) [+ dy_add]; optional g_out = g
  * (residual branch); dgamma/dbeta (+)= sums (accumulate); zeroes sums afterwards.  dy may alias
- * dy_add or dout. */
+ * dy_add or dout.  coef: 3*C floats of scratch (per-channel coefficients collapsed from the slots). */
 int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean,
                      const float* invstd, const float* gamma, const float* mask_scale,
-                     const float* mask_shift, double* sums, int64_t npix, int C,
+                     const float* mask_shift, double* sums, float* coef, int64_t npix, int C,
                      float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta,
                      int accumulate, void* stream);
 /* plain ReLU backward / mask: g = dout * (act > 0) */
