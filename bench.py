@@ -183,9 +183,23 @@ def main():
     tot_fl = sum(k["flops"] for k in kern.values())
     tot_sec = sum(k["seconds"] for k in kern.values())
     nsteps_timed = next(iter(per.values()))[1] if per else 1
+    # HBM bytes per launch of the dominant kernel family: PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    # separate rocprofv3 --pmc runs of this same command: tools/gpu_pmc.sh) cannot be collected from inside the
+    # process, so the committed summary of the last PMC run is reported (null when absent).
+    traffic, traffic_src = None, None
+    tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
+    if os.path.exists(tpath) and args.net.startswith("resnet") and args.batch == 64:
+        tj = json.load(open(tpath))
+        key = "conv_gemm_kernel" if dom.startswith("conv_gemm") else "conv_wgrad_kernel"
+        ent = [v for k, v in tj.items() if key in k]
+        nl = sum(v["launches"] for v in ent)
+        if nl:
+            traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_x2"] + v["write_MB_per_launch"]) for v in ent) / nl * 1e6)
+            traffic_src = "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
     roofline = {
         "bound": "mfma", "kernel": dom, "achieved": round(kern[dom]["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_flop_per_launch": round(kern[dom]["flops"] / max(kern[dom]["launches"], 1)),
         "avg_launch_us": round(kern[dom]["avg_us"], 2), "launches_per_step": kern[dom]["launches"] // max(nsteps_timed, 1),
         "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2) if tot_sec else 0.0,
         "gemm_seconds_per_step": round(tot_sec / max(nsteps_timed, 1), 6),
