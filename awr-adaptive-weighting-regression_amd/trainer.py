@@ -172,6 +172,31 @@ class TrainEngine:
         return {"state": state if self.step_count else {}, "param_groups": [group]}
 
 
+def _load_opt_into(engine, sd):
+    """Inverse of optimizer_state_dict(): accepts a stock torch.optim.Adam/SGD state dict (train.py:84)."""
+    net = engine.net
+    names = [k for k, _, kind in net._layout if kind in ("conv_w", "deconv_w", "conv_b", "bn_w", "bn_b")]
+    steps = []
+    for i, k in enumerate(names):
+        ent = sd.get("state", {}).get(i)
+        if ent is None or k in net._unused:
+            continue
+        o, n, s = net._poff[k]
+        if engine.opt == "adam":
+            engine.m[o:o + n].copy_(ent["exp_avg"].reshape(-1))
+            engine.v[o:o + n].copy_(ent["exp_avg_sq"].reshape(-1))
+            steps.append(int(float(ent["step"])))
+        else:
+            engine.m[o:o + n].copy_(ent["momentum_buffer"].reshape(-1))
+    if steps:
+        engine.step_count = max(steps)
+    elif engine.opt != "adam" and sd.get("state"):
+        engine.step_count = max(engine.step_count, 1)
+
+
+TrainEngine.load_optimizer_state_dict = lambda self, sd: _load_opt_into(self, sd)
+
+
 class InferEngine:
     """test.py:67-86 without the per-sample host loop: img -> dense map -> joints, eval-mode BN."""
 
@@ -203,6 +228,183 @@ class InferEngine:
             self._core()
             self._warm += 1
         return self.jt
+
+
+class _Plateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'min', patience=2, min_lr=1e-8) (train.py:90),
+    defaults factor=0.1, threshold=1e-4 'rel', cooldown=0 -- host-side, drives TrainEngine.set_lr."""
+
+    def __init__(self, lr, patience=2, factor=0.1, min_lr=1e-8, threshold=1e-4):
+        self.lr, self.patience, self.factor, self.min_lr, self.threshold = lr, patience, factor, min_lr, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            self.lr = max(self.lr * self.factor, self.min_lr)
+            self.bad = 0
+        return self.lr
+
+
+class SyntheticHands(torch.utils.data.Dataset):
+    """Stand-in for dataloader/nyu_loader.py (the NYU files are not redistributable): yields the same 6-tuple
+    `(img[1,S,S], jt_xyz[J,3], jt_uvd[J,3], center_xyz[3], M[3,3], cube[3])` (nyu_loader.py:66) with joints that lie
+    on a synthetic hand surface, so a network can actually fit them."""
+
+    def __init__(self, n, img_size=128, jt_num=14, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        S = img_size
+        yy, xx = torch.meshgrid(torch.arange(S).float(), torch.arange(S).float(), indexing="ij")
+        c = S / 2 + (torch.rand(n, 2, generator=g) * 2 - 1) * (S / 16)
+        R = 0.31 * S
+        r2 = (xx - c[:, 0].view(n, 1, 1)) ** 2 + (yy - c[:, 1].view(n, 1, 1)) ** 2
+        depth = (0.5 * r2 / (R * R) - 0.3).clamp(-1.0, 0.98)
+        self.img = torch.where(r2 < R * R, depth, torch.ones(())).view(n, 1, S, S).contiguous()
+        ang = torch.rand(n, jt_num, generator=g) * 6.2831853
+        rad = torch.rand(n, jt_num, generator=g).sqrt() * 0.8 * R
+        px = (c[:, 0:1] + rad * torch.cos(ang)).round().clamp(0, S - 1).long()
+        py = (c[:, 1:2] + rad * torch.sin(ang)).round().clamp(0, S - 1).long()
+        d = self.img[torch.arange(n).view(n, 1), 0, py, px]
+        self.jt_uvd = torch.stack([(px.float() + 0.5) * 2 / S - 1, (py.float() + 0.5) * 2 / S - 1, d], -1)
+        self.center = torch.tensor([0.0, 0.0, 750.0]).expand(n, 3).contiguous()
+        self.cube = torch.tensor([300.0, 300.0, 300.0]).expand(n, 3).contiguous()
+        s = 0.45                                   # crop matrix: original-image pixels -> crop pixels
+        self.M = torch.tensor([[s, 0.0, 64.0 - 320.0 * s], [0.0, s, 64.0 - 240.0 * s], [0.0, 0.0, 1.0]]).expand(n, 3, 3).contiguous()
+        # ground-truth xyz consistent with the evaluator's uvd -> xyz chain, normalised like loader.py:242-260
+        from .evaluator import uvd2xyz
+        uv = (self.jt_uvd[:, :, :2] + 1) * S / 2.0
+        uv = (uv - torch.tensor([64.0 - 320.0 * s, 64.0 - 240.0 * s])) / s
+        uvd = torch.cat([uv, self.jt_uvd[:, :, 2:] * 150.0 + 750.0], -1)
+        xyz = torch.from_numpy(uvd2xyz(uvd.numpy(), (588.03, 587.07, 320.0, 240.0), -1))
+        self.jt_xyz = (xyz - self.center.view(n, 1, 3)) / 150.0
+        self.img_size, self.jt_num, self.paras, self.flip = S, jt_num, (588.03, 587.07, 320.0, 240.0), -1
+
+    def __len__(self):
+        return self.img.shape[0]
+
+    def __getitem__(self, i):
+        return self.img[i], self.jt_xyz[i], self.jt_uvd[i], self.center[i], self.M[i], self.cube[i]
+
+
+class Trainer:
+    """The reference's Trainer (train.py:27-227, test.py:20-110) on the MI355X engines: same config attributes, same
+    log lines, same checkpoint files, with the per-sample host loops removed.  `train_data` / `test_data` are any
+    map-style datasets yielding the NYU 6-tuple (the reference's own `NYU(...)` objects work unchanged)."""
+
+    def __init__(self, config, train_data=None, test_data=None, process_group=None):
+        import os
+        from . import resnet_deconv, hourglass
+        from .evaluator import EvalUtil
+        self.config, self.EvalUtil = config, EvalUtil
+        self.trainData, self.testData, self.pg = train_data, test_data, process_group
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        self.work_dir = os.path.join(config.output_dir, config.dataset, "checkpoint_" + config.exp_id)
+        self.result_dir = os.path.join(self.work_dir, "results")
+        os.makedirs(self.result_dir, exist_ok=True)
+        self.log = open(os.path.join(self.work_dir, "%s_%s.log" % (config.net, config.log_id)), "a") if self.rank == 0 else None
+        self._msg("-------------------start programming-------------------", stdout=False)
+        for k, v in config.__class__.__dict__.items():
+            if not k.startswith("_"):
+                self._msg(str(k) + ":" + str(v))
+        if "resnet" in config.net:
+            self.net = resnet_deconv.get_deconv_net(int(config.net.split("_")[1]), config.jt_num, config.downsample)
+            self.stacks = 1
+        else:
+            self.stacks = int(config.net.split("_")[1])
+            self._msg("hourglass stacks:{}".format(self.stacks))
+            self.net = hourglass.PoseNet(config.net, config.jt_num)
+        self.net = self.net.cuda()
+        self.best_records = {"epoch": 0, "MPE": 1e10, "AUC": 0}
+        self.engine = TrainEngine(self.net, config.batch_size, config.img_size, config.kernel_size, config.coord_weight, config.dense_weight,
+                                  config.lr, config.weight_decay, config.optimizer, process_group=process_group,
+                                  use_graph=getattr(config, "use_hipgraph", True))
+        if config.load_model and os.path.exists(config.load_model):
+            self._msg("loading model from {}".format(config.load_model))
+            pth = torch.load(config.load_model, map_location="cpu", weights_only=False)     # trusted project artefact (best_records may hold numpy scalars)
+            self.net.load_state_dict(pth["model"])
+            if "optimizer" in pth:
+                self.engine.load_optimizer_state_dict(pth["optimizer"])
+            if "best_records" in pth:
+                self.best_records = pth["best_records"]
+        # train.py:94-96: the learning rate is force-reset to config.lr after loading
+        self.engine.set_lr(config.lr)
+        self._plateau = _Plateau(config.lr) if config.scheduler == "auto" else None
+        self._msg("learning rate: {:.1e}".format(config.lr))
+
+    def _msg(self, msg, stdout=True):
+        if self.rank != 0:
+            return
+        if stdout:
+            print(msg)
+        print(msg, file=self.log)
+
+    def _loader(self, data, shuffle):
+        return torch.utils.data.DataLoader(data, batch_size=self.config.batch_size, shuffle=shuffle, num_workers=0, drop_last=shuffle)
+
+    def train(self):
+        cfg, eng = self.config, self.engine
+        for epoch in range(self.best_records["epoch"] + 1, cfg.max_epoch + 1):
+            self.net.train()
+            ev = self.EvalUtil(self.trainData.img_size, self.trainData.paras, self.trainData.flip, self.trainData.jt_num)
+            lsum, lcnt, pend, last_mean = torch.zeros(3, device=self.net.device), 0, [], float("nan")
+            for ii, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(self._loader(self.trainData, True)):
+                losses, jt_pred = eng.step(img.cuda(non_blocking=True), jt_uvd_gt.cuda(non_blocking=True))
+                lsum += losses                                      # device-side meter: no loss.item() per iteration
+                lcnt += 1
+                pend.append((jt_pred.clone(), jt_xyz_gt, center_xyz, M, cube))
+                if (ii + 1) % cfg.print_freq == 0:
+                    l = (lsum / lcnt).tolist()
+                    last_mean = l[2]
+                    self._msg("[epoch: {:02d}][train loss: {:.5f}][offset_loss: {:.5f}][coord_loss: {:.5f}]".format(epoch, l[2], l[1], l[0]))
+                    lsum.zero_()
+                    lcnt = 0
+                    for jt, a, b, c, d in pend:
+                        ev.feed_batch(jt.cpu().numpy(), a.numpy(), b.numpy(), c.numpy(), d.numpy())
+                    pend = []
+            for jt, a, b, c, d in pend:
+                ev.feed_batch(jt.cpu().numpy(), a.numpy(), b.numpy(), c.numpy(), d.numpy())
+            train_mpe = ev.get_measures()[0]
+            last = (lsum / lcnt).tolist()[2] if lcnt else last_mean      # meter is reset at every print (train.py:139)
+            self._msg("[epoch {:02d}], [train loss {:.5f}], [train mpe {:.5f}], [lr {:.1e}]".format(epoch, last, train_mpe, eng.lr))
+            if cfg.scheduler == "auto":
+                eng.set_lr(self._plateau.step(train_mpe))
+            elif cfg.scheduler == "step":                          # StepLR(step_size=cfg.step, gamma=0.1).step(epoch)
+                eng.set_lr(cfg.lr * 0.1 ** (epoch // cfg.step))
+            if self.testData is not None:
+                self.test(epoch)
+            if self.rank == 0:
+                import os
+                torch.save({"model": self.net.state_dict(), "optimizer": eng.optimizer_state_dict(), "best_records": self.best_records},
+                           os.path.join(self.work_dir, "epoch_{}.pth".format(epoch)))
+        if self.log:
+            self.log.flush()
+
+    @torch.no_grad()
+    def test(self, epoch=0):
+        import os
+        import numpy as np
+        cfg = self.config
+        inf = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False)
+        ev = self.EvalUtil(self.testData.img_size, self.testData.paras, self.testData.flip, self.testData.jt_num)
+        n = len(self.testData)
+        for i0 in range(0, n, cfg.batch_size):
+            items = [self.testData[i] for i in range(i0, min(n, i0 + cfg.batch_size))]
+            img, jt_xyz_gt, _, center_xyz, M, cube = (torch.stack([torch.as_tensor(it[k]) for it in items]) for k in range(6))
+            nb = img.shape[0]
+            if nb < cfg.batch_size:                                  # ragged last batch: pad, then drop the padding
+                img = torch.cat([img, img[-1:].expand(cfg.batch_size - nb, -1, -1, -1)])
+            jt = inf(img.cuda().float())[:nb].cpu().numpy()
+            ev.feed_batch(jt, jt_xyz_gt.numpy(), center_xyz.numpy(), M.numpy(), cube.numpy())
+        self.net.train()
+        mpe, mid, auc, pck, thresh = ev.get_measures()
+        if epoch in (0, -1) and self.rank == 0:                      # train.py:217-221 / test.py:103-108
+            jt_uvd = np.array(ev.jt_uvd_pred, dtype=np.float32)
+            np.savetxt(os.path.join(self.work_dir, "test_%.3f.txt" % mpe), jt_uvd.reshape([jt_uvd.shape[0], cfg.jt_num * 3]), fmt="%.3f")
+        self._msg("[epoch {:2d}], [test mpe {:.3f}], [lr {:.1e}]".format(epoch, mpe, self.engine.lr))
+        return mpe
 
 
 def smoke_step(dev):

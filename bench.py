@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (roofline then comes from a separate eager pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--coord-weight", type=float, default=0.0, help="reference default config.py:41")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"], help="infer = test.py:67-86 path (eval BN, img -> joints); not the headline metric")
     ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
     args = ap.parse_args()
 
@@ -128,6 +129,26 @@ def main():
     ks = 1.0 if args.net.startswith("resnet") else 0.4          # config.py:42
     torch.manual_seed(0)
     net = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
+    if args.mode == "infer":
+        from awr_amd.trainer import InferEngine
+        inf = InferEngine(net, args.batch, 128, ks, use_graph=args.graph)
+        imgs, _ = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)
+        imgs = imgs.to(dev)
+        for _ in range(max(args.warmup, 3)):
+            inf(imgs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            inf(imgs)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        macs = sum(v for k, v in inf.plan.macs.items())
+        print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": round(args.batch * args.steps / el, 2), "unit": "images/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+                          "dtype": "f32", "data": "synthetic", "config": {"workload": "%s eval forward + head, batch %d" % (args.net, args.batch),
+                                                                          "hipgraph": bool(args.graph)},
+                          "mfma_frac": round(2 * macs / (el / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}), flush=True)
+        return
     eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
                       use_graph=args.graph)
     img, jt = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)

@@ -245,3 +245,45 @@ def test_roundtrip_save_load_checkpoint(amd, dev, tmp_path):
     with torch.no_grad():
         a, b = m(img.to(dev))[0], m2(img.to(dev))[0]
     assert torch.equal(a, b)
+
+
+def test_trainer_end_to_end(amd, dev, tmp_path):
+    """train.py / test.py orchestration (a9) on a synthetic hand dataset: the loss goes down, the evaluator
+    reports a finite mm error, StepLR semantics, checkpoint files and the results txt are written and reload."""
+    from awr_amd.trainer import SyntheticHands, Trainer
+    from awr_amd.config import Config
+
+    class Cfg(Config):
+        net = "resnet_18"
+        kernel_size = 1.0
+        batch_size = 8
+        max_epoch = 3
+        step = 2
+        print_freq = 2
+        output_dir = str(tmp_path)
+        load_model = ""
+        exp_id = "t"
+        coord_weight = 1.0
+        use_hipgraph = False
+    tr = Trainer(Cfg(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
+    mpe0 = tr.test(0)
+    tr.train()
+    work = os.path.join(str(tmp_path), "nyu", "checkpoint_t")
+    log = open(os.path.join(work, "resnet_18_dense.log")).read()
+    assert "[epoch 01], [train loss" in log and "[epoch  3], [test mpe" in log and "learning rate: 1.0e-03" in log
+    assert abs(tr.engine.lr - 1e-3 * 0.1 ** (3 // 2)) < 1e-12                     # StepLR(step_size=2, gamma=0.1).step(3)
+    losses = [float(l.split("[train loss ")[1].split("]")[0]) for l in log.splitlines() if l.startswith("[epoch 0") and "train mpe" in l]
+    assert len(losses) == 3 and losses[-1] < losses[0]
+    assert np.isfinite(mpe0) and any(f.startswith("test_") and f.endswith(".txt") for f in os.listdir(work))
+    txt = np.loadtxt(os.path.join(work, [f for f in os.listdir(work) if f.startswith("test_")][0]))
+    assert txt.shape == (12, 42)                                                   # results/*.txt format (test.py:105-108)
+    pth = torch.load(os.path.join(work, "epoch_3.pth"), weights_only=False)
+    assert set(pth) == {"model", "optimizer", "best_records"} and len(pth["model"]) == 142
+
+    class Cfg2(Cfg):
+        load_model = os.path.join(work, "epoch_3.pth")
+        exp_id = "t2"
+    tr2 = Trainer(Cfg2(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
+    assert torch.equal(tr2.net.flat_params(), tr.net.flat_params()) and tr2.engine.step_count == tr.engine.step_count
+    assert torch.equal(tr2.engine.m, tr.engine.m) and abs(tr2.engine.lr - 1e-3) < 1e-12       # LR force-reset (train.py:94-96)
+    assert abs(tr2.test(1) - tr.test(1)) < 1e-6
