@@ -23,6 +23,32 @@ BN_MOMENTUM = 0.1
 STAT_SLOTS = 16     # AWR_STAT_SLOTS in include/awr_hip.h
 
 
+def plan_buckets(writes, n_active, n_buckets):
+    """Group gradient tensors into contiguous arena ranges that become final in backward order.
+
+    writes: list of (arena_lo, arena_hi, ready_op) -- the gradient occupying [lo,hi) floats is final once
+    backward op number `ready_op` has been enqueued.  Returns [(lo, hi, ready_op)] with the ranges tiling
+    [0, n_active) from the arena END downwards (the backward pass finishes the last layers first), ready_op
+    non-decreasing, so bucket k can be all-reduced while the backward of the earlier layers still runs."""
+    if not writes:
+        return []
+    ws = sorted(writes, key=lambda w: -w[0])
+    total = sum(hi - lo for lo, hi, _ in ws)
+    target = total / float(max(1, n_buckets))
+    out, acc, ready, hi_edge = [], 0, -1, n_active
+    for i, (lo, hi, r) in enumerate(ws):
+        acc += hi - lo
+        ready = max(ready, r)
+        last = i == len(ws) - 1
+        if last or (acc >= target and len(out) < n_buckets - 1):
+            edge = 0 if last else lo
+            out.append([edge, hi_edge, ready])
+            hi_edge, acc = edge, 0
+    for k in range(1, len(out)):                 # a later bucket is never launched before an earlier one
+        out[k][2] = max(out[k][2], out[k - 1][2])
+    return [tuple(b) for b in out]
+
+
 class T:
     """Plan-time tensor handle: an NHWC fp32 buffer plus (later) its gradient buffer."""
     __slots__ = ("buf", "grad", "needs_grad", "stats", "name")
@@ -142,6 +168,11 @@ class Plan:
         self._bufs = []
         self._scratch_buf, self._scratch_used, self._scratch_cap = None, 0, 0
         self._unpack_jobs, self._unpack_tab, self._pack_tab = [], None, None
+        self.garena = None          # flat gradient arena of the network (set by AwrBackbone.get_plan)
+        self.n_active = 0
+        self.n_buckets = 1          # > 1: gradients leave the backward pass in buckets (data-parallel overlap)
+        self.bucket_hook = None     # callable(lo, hi) fired when arena[lo:hi] holds final gradients
+        self._grad_writes = []      # (arena_lo, arena_hi, ready_op_index, unpack_job|None)
         self.macs = {}              # op name -> algorithmic MACs of that GEMM launch (bench.py roofline)
         self._keep = []             # ctypes argument structs referenced by the op lists
         self._head_states = []
@@ -180,6 +211,14 @@ class Plan:
 
     def _b(self, name, *args):
         self.bwd_ops.append((getattr(L.lib, name), args + (None,), name))
+
+    def _note_grad(self, tensor, job=None):
+        """The gradient view `tensor` (a slice of the flat gradient arena) is final after the op just appended
+        (or, with `job`, once that unpack job has run)."""
+        if self.garena is None or tensor is None:
+            return
+        lo = (tensor.data_ptr() - self.garena.data_ptr()) // 4
+        self._grad_writes.append((lo, lo + tensor.numel(), len(self.bwd_ops) - 1, job))
 
     def _gtarget(self, t):
         """-> (gradient buffer, accumulate?)  and marks the gradient as live."""
@@ -244,6 +283,9 @@ class Plan:
             if hasattr(layer, "bias_grad_post"):
                 for _, (dst, src) in layer.bias_grad_post():
                     self.bwd_ops.append((None, (dst, src), "__copy__"))
+                    self._note_grad(dst)
+            else:
+                self._note_grad(tgt)
         # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
         wp = spec.wgrad_problem(H, W)
         ld = wp["Cg"]
@@ -253,12 +295,16 @@ class Plan:
         self._keep.append(wa)
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
-        if layer.batchable:        # scattered back to checkpoint layout by the single batched launch at the end of the backward
+        if layer.batchable:        # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
             for name, args in layer.wgrad_unpack_calls(R, ld):
-                self._unpack_jobs.append(L.UnpackJob(args[0], args[5], args[1], args[2], args[3], args[4], 0))
+                job = L.UnpackJob(args[0], args[5], args[1], args[2], args[3], args[4], 0)
+                self._unpack_jobs.append(job)
+                self._note_grad(layer.gw, job)
         else:
             for name, args in layer.wgrad_unpack_calls(R, ld):
                 self._b(name, *args)
+            self._note_grad(layer.gw1)
+            self._note_grad(layer.gw2)
         # data gradient
         if x.needs_grad:
             dp = spec.dgrad_problem(H, W)
@@ -327,6 +373,8 @@ class Plan:
                 pass  # handled below: identity of da
         self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), L.ptr(coef), y.npix, C_,
                 L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
+        self._note_grad(bn.ggamma)
+        self._note_grad(bn.gbeta)
         if post_add is not None:
             self._b("awr_add", L.ptr(res.grad), L.ptr(post_add), L.ptr(res.grad), post_add.numel())
         if res is not None and res.needs_grad and not relu:
@@ -394,17 +442,36 @@ class Plan:
         # split-K scratch for every weight gradient, as one arena (capacity = all packed gradients of the used layers)
         self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) for l in self.layers) + 64
         first = len(self.bwd_ops)
+        self.bwd_ops.append(None)        # placeholder for the scratch fill (kept in place so recorded op indices stay valid)
         for emit in reversed(self.nodes):
             emit()
         if self._scratch_buf is not None:
-            self.bwd_ops.insert(first, (None, (self._scratch_buf[:self._scratch_used],), "__zero__"))
-        if self._unpack_jobs:      # ONE launch scatters every packed weight gradient back to checkpoint layout
+            self.bwd_ops[first] = (None, (self._scratch_buf[:self._scratch_used],), "__zero__")
+        else:
+            self.bwd_ops[first] = (None, (self.alloc(4),), "__zero__")
+        def unpack_op(jobs):
             total = 0
-            for jb in self._unpack_jobs:
+            for jb in jobs:
                 jb.first = total
                 total += jb.d0 * jb.d1 * jb.T
-            self._unpack_tab = L.job_table(self._unpack_jobs, self.dev)
-            self._b("awr_unpack_wgrads_batched", self._unpack_tab.data_ptr(), len(self._unpack_jobs), total)
+            tab = L.job_table(jobs, self.dev)
+            self._bufs.append(tab)
+            return (L.lib.awr_unpack_wgrads_batched, (tab.data_ptr(), len(jobs), total, None), "awr_unpack_wgrads_batched")
+        if self.n_buckets <= 1 or not self._grad_writes:
+            if self._unpack_jobs:      # ONE launch scatters every packed weight gradient back to checkpoint layout
+                self.bwd_ops.append(unpack_op(self._unpack_jobs))
+            self.buckets = [(0, self.n_active, len(self.bwd_ops) - 1)]
+        else:
+            # data-parallel overlap: each bucket's weight gradients are scattered into the arena as soon as the backward has
+            # passed its layers, then a marker lets the host start that bucket's all-reduce while the backward continues
+            self.buckets = plan_buckets([(lo, hi, r) for lo, hi, r, _ in self._grad_writes], self.n_active, self.n_buckets)
+            inserts = []
+            for lo, hi, ready in self.buckets:
+                jobs = [j for (wlo, whi, _, j) in self._grad_writes if j is not None and lo <= wlo < hi]
+                ops = ([unpack_op(jobs)] if jobs else []) + [(None, (lo, hi), "__bucket__")]
+                inserts.append((ready + 1, ops))
+            for pos, ops in sorted(inserts, key=lambda t: -t[0]):
+                self.bwd_ops[pos:pos] = ops
         self._built_bwd = True
 
     def refresh_weights(self):
@@ -442,6 +509,9 @@ class Plan:
             if fn is None:
                 if name == "__zero__":
                     args[0].zero_()
+                elif name == "__bucket__":
+                    if self.bucket_hook is not None:
+                        self.bucket_hook(args[0], args[1])
                 else:
                     args[0].copy_(args[1])
                 continue

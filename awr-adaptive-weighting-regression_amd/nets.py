@@ -237,15 +237,16 @@ class AwrBackbone(nn.Module):
         return BNLayer(c, self.param_view(prefix + ".weight"), self.param_view(prefix + ".bias"), self.grad_view(prefix + ".weight"),
                        self.grad_view(prefix + ".bias"), self._barena[om:om + c], self._barena[ov:ov + c], self._counters[idx], name=prefix)
 
-    def get_plan(self, B, H, training, supervised="all", bn_repeat=1):
+    def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1):
         if not self._arena.is_cuda:
             raise L.AwrError("the AWR backbone runs on the MI355X only: call .cuda() first (there is no CPU path)")
-        key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat)
+        key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets)
         plan = self._plans.get(key)
         if plan is None:
             plan = Plan(B, self.device, training, bn_repeat=bn_repeat)
             plan.img = plan.alloc(B, 1, H, H)
             plan.gen = 0
+            plan.garena, plan.n_active, plan.n_buckets = self._garena, self.n_active, n_buckets
             self.build(plan, plan.img, H)
             if training:
                 plan.build_backward(range(self.nstage) if supervised == "all" else supervised)

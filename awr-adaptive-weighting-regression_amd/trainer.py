@@ -40,7 +40,7 @@ class GradSync:
         self.grad_scale = 1.0 / self.world
 
     def broadcast(self, *tensors):
-        if self.world > 1:
+        if self.pg is not None:
             for t in tensors:
                 torch.distributed.broadcast(t, 0, group=self.pg)
 
@@ -63,7 +63,11 @@ class TrainEngine:
         dev = net.device
         self.stage = net.nstage - 1
         net.train()
-        self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage)
+        world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        import os
+        self.dp = world > 1 or (process_group is not None and os.environ.get("AWR_FORCE_DP") == "1")   # test hook: 1-rank group
+        self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
+                                 n_buckets=n_buckets if self.dp else 1)
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
         self.jt_pred = torch.zeros(batch_size, self.J, 3, device=dev)
         self.stat = torch.zeros(batch_size, self.J, 2, device=dev)
@@ -79,9 +83,16 @@ class TrainEngine:
         self._warm = 0
         self.sync = GradSync(n, process_group, n_buckets)
         self.world = self.sync.world
-        if self.world > 1:      # identical initial parameters and BN buffers on every rank
+        self._works = []
+        if self.dp:             # identical initial parameters and BN buffers on every rank
             self.sync.broadcast(net.flat_params(), net._barena)
             net.weights_changed()
+            self.use_graph = False          # the bucket markers interleave RCCL calls with the backward: run it eagerly
+            g = net.flat_grads()
+            # torch's NCCL work stream waits for the compute stream at the point of the call and runs concurrently with
+            # whatever is enqueued afterwards: the rest of the backward overlaps the bucket's all-reduce over xGMI
+            self.plan.bucket_hook = lambda lo, hi: self._works.append(
+                torch.distributed.all_reduce(g[lo:hi], group=process_group, async_op=True))
 
     # ---- the captured part: repack -> forward -> head + losses -> backward -------------------------------
     def _core(self):
@@ -138,8 +149,10 @@ class TrainEngine:
             self._warm += 1
         for bn in plan.bns:
             bn.counter += plan.bn_repeat
-        if self.world > 1:
-            self._allreduce()
+        if self.dp:
+            for w in self._works:           # compute stream waits for the bucket all-reduces before the optimiser
+                w.wait()
+            self._works.clear()
         self.step_count += 1
         self._optimizer()
         self.net.weights_changed()

@@ -143,3 +143,18 @@ def test_reference_init_distributions(amd):
     h = amd.PoseNet("hourglass_1", 14).state_dict()
     w = h["pre.1.conv2.conv.weight"]
     assert float(w.abs().max()) <= 1.0 / (w.shape[1] * 9) ** 0.5 + 1e-7                       # kaiming_uniform(a=sqrt(5))
+
+
+def test_gradient_bucket_planner(amd):
+    """Data-parallel overlap: buckets tile the arena from its end downwards, in backward (ready) order."""
+    from awr_amd.engine import plan_buckets
+    # 6 tensors laid out in forward order; backward finalises them in reverse, with a local swap (offset 300 before 400)
+    writes = [(0, 100, 50), (100, 300, 40), (300, 400, 25), (400, 700, 30), (700, 900, 10), (900, 1000, 5)]
+    b = plan_buckets(writes, 1000, 3)
+    assert b[0][1] == 1000 and b[-1][0] == 0
+    assert all(x[0] == y[1] for x, y in zip(b, b[1:]))                 # contiguous, descending
+    assert [r for _, _, r in b] == sorted(r for _, _, r in b)          # launch order follows the backward
+    for lo, hi, ready in b:
+        assert ready >= max(r for (wlo, whi, r) in writes if lo <= wlo < hi)    # nothing is reduced before it is final
+    assert plan_buckets(writes, 1000, 1) == [(0, 1000, 50)]
+    assert len(plan_buckets(writes, 1000, 16)) <= 6

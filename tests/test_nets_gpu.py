@@ -287,3 +287,65 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     assert torch.equal(tr2.net.flat_params(), tr.net.flat_params()) and tr2.engine.step_count == tr.engine.step_count
     assert torch.equal(tr2.engine.m, tr.engine.m) and abs(tr2.engine.lr - 1e-3) < 1e-12       # LR force-reset (train.py:94-96)
     assert abs(tr2.test(1) - tr.test(1)) < 1e-6
+
+
+def test_bucketed_backward_matches_and_is_final_at_the_marker(amd, dev):
+    """Data-parallel overlap: with n_buckets > 1 the backward hands out arena ranges as soon as they are final.
+    Snapshots taken at each marker must equal the end-of-step gradients, and those must equal the 1-bucket plan's."""
+    J = 14
+    img, jt_gt = O.synth_batch(2, 128, J, seed=61)
+    man = O.manifest_for("resnet_18", J)
+    grads = []
+    for nb in (1, 4):
+        m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=6))
+        m.train()
+        plan = m.get_plan(2, 128, True, supervised=(0,), n_buckets=nb)
+        snaps = []
+        plan.bucket_hook = lambda lo, hi: snaps.append((lo, hi, m.flat_grads()[lo:hi].clone()))
+        m.sync_weights(plan, force=True)
+        plan.img.copy_(img.to(dev))
+        plan.forward()
+        plan.grad_outs[0].copy_(_hashed_like(plan.grad_outs[0]))
+        plan.backward()
+        torch.cuda.synchronize()
+        g = m.flat_grads()[:m.n_active].clone()
+        grads.append(g)
+        if nb > 1:
+            assert len(snaps) >= 2 and snaps[0][1] == m.n_active and snaps[-1][0] == 0
+            assert all(a[0] == b[1] for a, b in zip(snaps, snaps[1:]))
+            for lo, hi, snap in snaps:
+                assert torch.equal(snap, m.flat_grads()[lo:hi]), (lo, hi)      # nothing wrote the range after its marker
+    d = (grads[0] - grads[1]).abs().max() / grads[0].abs().max()
+    assert float(d) < 1e-4          # same kernels, split-K atomics order differs
+
+
+def _hashed_like(t):
+    v = O._hash_uniform(t.numel(), 77, 5) * np.float32(1e-3)
+    return torch.from_numpy(v.reshape(tuple(t.shape)).copy()).to(t.device)
+
+
+def test_train_engine_with_one_rank_rccl_group(amd, dev, monkeypatch):
+    """The data-parallel code path (RCCL broadcast, bucketed async all-reduce overlapped with the backward, 1/world
+    scale) on a 1-rank `nccl` group: must give the same step as the single-process engine."""
+    import torch.distributed as dist
+    from awr_amd.trainer import TrainEngine
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setenv("AWR_FORCE_DP", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        J = 14
+        img, jt_gt = O.synth_batch(2, 128, J, seed=71)
+        man = O.manifest_for("resnet_18", J)
+        out = []
+        for pg in (None, dist.group.WORLD):
+            m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=7))
+            eng = TrainEngine(m, 2, 128, 1.0, coord_weight=1.0, use_graph=False, process_group=pg)
+            assert eng.dp == (pg is not None) and len(eng.plan.buckets) == (4 if pg is not None else 1)
+            l = [float(eng.step(img.to(dev), jt_gt.to(dev))[0][2]) for _ in range(2)]
+            out.append((l, m.flat_params().clone()))
+        assert np.allclose(out[0][0], out[1][0], rtol=1e-4)
+        d = (out[0][1] - out[1][1]).abs()
+        assert float(torch.quantile(d[:1000000], 0.9)) <= 2e-4
+    finally:
+        dist.destroy_process_group()
