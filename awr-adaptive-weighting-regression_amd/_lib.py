@@ -65,6 +65,8 @@ def job_table(jobs, device):
 
 class WgradArgs(C.Structure):
     _fields_ = [("D", C.c_void_p), ("G", C.c_void_p), ("R", C.c_void_p),
+                ("d_scale", C.c_void_p), ("d_shift", C.c_void_p), ("g_scale", C.c_void_p), ("g_shift", C.c_void_p),
+                ("d_relu", C.c_int), ("g_relu", C.c_int),
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
                 ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]
@@ -91,6 +93,7 @@ _SIGS = {
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),
+    "awr_debug_gemm_variant": ([_I], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P], C.c_int),
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),
@@ -101,7 +104,7 @@ _SIGS = {
     "awr_relu_bwd": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_add": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_bias_grad": ([_P, _L, _I, _P, _I, _P], C.c_int),
-    "awr_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "awr_maxpool_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "awr_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "awr_upsample2_add": ([_P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
     "awr_upsample2_bwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),

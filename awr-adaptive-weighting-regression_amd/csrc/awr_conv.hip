@@ -59,12 +59,17 @@ __device__ __forceinline__ float4 affine_relu(float4 v, float4 sc, float4 sh, in
 // ------------------------------------------------------------------------------------------
 // out[pix(m), n] = sum_{tap, c} in[gather(m, tap), c] * w[n][wt(tap)][c]
 // ------------------------------------------------------------------------------------------
-template <int TM, int TN>
+// DB = true: double-buffered LDS + explicit fragment prefetch: ONE barrier per K-slice, and every LDS / global access of
+// a wave is issued in the shadow of its own MFMAs (the staging registers of slice k+1 are written to the other LDS buffer
+// at the start of slice k, the loads of slice k+2 follow immediately, the fragments of sub-step s+1 are read while the
+// MFMAs of sub-step s run).
+template <int TM, int TN, bool DB, bool PRIO>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    constexpr int NBUF = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float As[NBUF * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDK];
 
     const awr_phase& ph = a.ph[blockIdx.y];
     const int M = a.B * a.Hq * a.Wq;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         c0_staged = c0;
     };
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
-    auto store_slice = [&]() {
+    auto store_slice = [&](int buf) {
         if (a.in_scale) {
             const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
@@ -154,46 +159,89 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&As[(r0 + 32 * i) * LDK + kc], ra[i]);
+        for (int i = 0; i < RA; ++i) st4(&As[buf * BM * LDK + (r0 + 32 * i) * LDK + kc], ra[i]);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&Bs[(r0 + 32 * i) * LDK + kc], rb[i]);
+        for (int i = 0; i < RB; ++i) st4(&Bs[buf * BN * LDK + (r0 + 32 * i) * LDK + kc], rb[i]);
     };
 
     int tap = 0, c0 = 0;
-    set_tap(0);
-    load_slice(0);
-    store_slice();
-    __syncthreads();
-
     const int half = lane >> 5, l31 = lane & 31;
     const float* a_frag = &As[(wm * 32 * TM + l31) * LDK + 4 * half];
     const float* b_frag = &Bs[(wn * 32 * TN + l31) * LDK + 4 * half];
+    auto advance = [&]() {
+        c0 += BK;
+        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
+    };
+    auto mfma_group = [&](const float4 (&fa)[TM], const float4 (&fb)[TN]) {
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);     // let MFMA-issuing waves win arbitration over staging waves
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
 
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const bool more = ks + 1 < ksteps;
-        if (more) {
-            c0 += BK;
-            if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
-            load_slice(c0);        // global loads in flight while the MFMAs below run
+    set_tap(0);
+    load_slice(0);
+    store_slice(0);
+    if constexpr (!DB) {
+        __syncthreads();
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool more = ks + 1 < ksteps;
+            if (more) {
+                advance();
+                load_slice(c0);        // global loads in flight while the MFMAs below run
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
+                mfma_group(fa, fb);
+            }
+            __syncthreads();
+            if (more) {
+                store_slice(0);
+                __syncthreads();
+            }
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+    } else {
+        if (ksteps > 1) {
+            advance();
+            load_slice(c0);            // slice 1 travels while slice 0 is consumed
         }
         __syncthreads();
-        if (more) {
-            store_slice();
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int cur = ks & 1;
+            const float* af = a_frag + cur * BM * LDK;
+            const float* bf = b_frag + cur * BN * LDK;
+            float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = ld4(af + i * 32 * LDK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = ld4(bf + j * 32 * LDK);
+            if (ks + 1 < ksteps) {
+                store_slice(cur ^ 1);  // staged one whole slice ago: no memory stall here
+                if (ks + 2 < ksteps) {
+                    advance();
+                    load_slice(c0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = ld4(af + i * 32 * LDK + 8 * (s + 1));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = ld4(bf + j * 32 * LDK + 8 * (s + 1));
+                }
+                mfma_group(fa[s & 1], fb[s & 1]);
+            }
             __syncthreads();
         }
     }
@@ -304,11 +352,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
     const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)M * a.Cd * 4u);
     const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
     const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
+    unsigned d_ok = 0, g_ok = 0;     // staged rows that hold real data (a fused affine must not touch padding / tail rows)
     auto load_slice = [&](int m0) {
+        d_ok = g_ok = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = m0 + da_r + PM * i;
-            rd[i] = buf_ld4(rs_d, (m < m_end && d_cok) ? (unsigned)m * a.Cd * 4u + d_col : OOB);
+            const bool ok = m < m_end && d_cok;
+            rd[i] = buf_ld4(rs_d, ok ? (unsigned)m * a.Cd * 4u + d_col : OOB);
+            d_ok |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -328,9 +380,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
             const int gy = y * a.sg + dy, gx = x * a.sg + dx;
             const bool ok = m < m_end && g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
             rg[i] = buf_ld4(rs_g, ok ? ((unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg) * 4u + g_col : OOB);
+            g_ok |= ok ? (1u << i) : 0u;
         }
     };
+    // per-thread channel chunk is fixed: the fused BatchNorm coefficients are loaded once
+    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
+    if (a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * BM + da_c); dsh = ld4(a.d_shift + tcd * BM + da_c); }
+    if (a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * BN + ga_c); gsh = ld4(a.g_shift + tcg * BN + ga_c); }
     auto store_slice = [&]() {
+        if (a.d_scale) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                if (d_ok & (1u << i)) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
+        }
+        if (a.g_scale) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (g_ok & (1u << i)) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) st4(&Ds[(da_r + PM * i) * LDM + da_c], rd[i]);
 #pragma unroll
@@ -382,7 +449,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
 
 using namespace awr;
 
-static int g_force_tm = 0, g_force_tn = 0;
+static int g_force_tm = 0, g_force_tn = 0, g_gemm_variant = 0;
 
 extern "C" {
 
@@ -390,6 +457,12 @@ int awr_debug_force_tile(int tm, int tn) {
     AWR_REQUIRE((tm == 0 && tn == 0) || ((tm == 1 || tm == 2) && (tn == 1 || tn == 2)), "force_tile: tm,tn must be 0,0 or in {1,2}");
     g_force_tm = tm;
     g_force_tn = tn;
+    return AWR_OK;
+}
+
+int awr_debug_gemm_variant(int v) {
+    AWR_REQUIRE(v >= 0 && v <= 3, "gemm_variant: bit 0 = double-buffered pipeline, bit 1 = s_setprio around the MFMA groups");
+    g_gemm_variant = v;
     return AWR_OK;
 }
 
@@ -418,10 +491,18 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     hipStream_t st = as_stream(stream);
-    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, dim3(256), 0, st, *a);
-    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_gemm_kernel<2, 1>), grid, dim3(256), 0, st, *a);
-    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 2>), grid, dim3(256), 0, st, *a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, dim3(256), 0, st, *a);
+#define AWR_LAUNCH_GEMM(tm, tn)                                                                          \
+    do {                                                                                                 \
+        if (g_gemm_variant == 1) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, true, false>), grid, dim3(256), 0, st, *a);       \
+        else if (g_gemm_variant == 2) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, false, true>), grid, dim3(256), 0, st, *a);  \
+        else if (g_gemm_variant == 3) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, true, true>), grid, dim3(256), 0, st, *a);   \
+        else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, false, false>), grid, dim3(256), 0, st, *a);                         \
+    } while (0)
+    if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);
+    else if (TM == 2 && TN == 1) AWR_LAUNCH_GEMM(2, 1);
+    else if (TM == 1 && TN == 2) AWR_LAUNCH_GEMM(1, 2);
+    else AWR_LAUNCH_GEMM(1, 1);
+#undef AWR_LAUNCH_GEMM
     return check_launch("conv_gemm_kernel");
 }
 
@@ -429,6 +510,8 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
     AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
+    AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),
+                "conv_wgrad: scale/shift must come in pairs");
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),

@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 // ------------------------------------------------------------------------------------------
 // pooling / up-sampling (NHWC, one thread = one pixel x 4 channels)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int k, int s, int p, int Ho,
-                                                          int Wo, float* __restrict__ out, uint8_t* __restrict__ arg) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ isc, const float* __restrict__ ish,
+                                                          int in_relu, int B, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
+                                                          float* __restrict__ out, uint8_t* __restrict__ arg) {
     const int C4 = C >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)B * Ho * Wo * C4;
@@ -333,13 +334,22 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int64_t b = pix / ((int64_t)Wo * Ho);
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int a[4] = {0, 0, 0, 0};
+    float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+    if (isc) {
+        sc = ld4(isc + cg * 4);
+        sh = ld4(ish + cg * 4);
+    }
     for (int ky = 0; ky < k; ++ky) {
         const int yy = oy * s - p + ky;
         if (yy < 0 || yy >= H) continue;
         for (int kx = 0; kx < k; ++kx) {
             const int xx = ox * s - p + kx;
             if (xx < 0 || xx >= W) continue;
-            const float4 v = ld4(x + ((b * H + yy) * W + xx) * C + cg * 4);
+            float4 v = ld4(x + ((b * H + yy) * W + xx) * C + cg * 4);
+            if (isc) {      // pooled tensor = relu(x*scale+shift): the BatchNorm+ReLU output is never materialised
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -592,11 +602,13 @@ int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulat
     return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, as_stream(stream));
 }
 
-int awr_maxpool_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* out, uint8_t* argmax, void* stream) {
+int awr_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, int in_relu, int B, int H, int W, int C, int k, int s, int p,
+                    float* out, uint8_t* argmax, void* stream) {
+    AWR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "maxpool_fwd: in_scale/in_shift must come together");
     AWR_REQUIRE(x && out && B > 0 && C % 4 == 0 && k >= 1 && k <= 15 && s >= 1 && p >= 0 && p < k, "maxpool_fwd: bad arguments");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream), x, B, H, W, C, k, s, p,
-                       Ho, Wo, out, argmax);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream), x, in_scale, in_shift, in_relu, B, H, W,
+                       C, k, s, p, Ho, Wo, out, argmax);
     return check_launch("maxpool_fwd_kernel");
 }
 

@@ -51,10 +51,13 @@ def plan_buckets(writes, n_active, n_buckets):
 
 class T:
     """Plan-time tensor handle: an NHWC fp32 buffer plus (later) its gradient buffer."""
-    __slots__ = ("buf", "grad", "needs_grad", "stats", "name")
+    __slots__ = ("buf", "grad", "needs_grad", "stats", "name", "lazy")
 
-    def __init__(self, buf, needs_grad=True, name=""):
+    def __init__(self, buf, needs_grad=True, name="", lazy=None):
         self.buf, self.grad, self.needs_grad, self.stats, self.name = buf, None, needs_grad, None, name
+        # lazy = (scale, shift, relu): the tensor this handle stands for is relu(buf*scale+shift) -- a BatchNorm(+ReLU)
+        # output that is never written to HBM; its consumers (conv / wgrad / maxpool loaders) apply the affine on the fly
+        self.lazy = lazy
 
     @property
     def shape(self):
@@ -260,6 +263,10 @@ class Plan:
         if want_stats:
             y.stats = self.alloc(STAT_SLOTS, 2, prob["N"], dtype=torch.float64, zero=True)
         bias = layer.bias_ptr() if use_bias else None
+        assert res is None or res.lazy is None, "a fused residual must be a materialised tensor"
+        if x.lazy is not None:
+            assert in_affine is None
+            in_affine, relu_in = (x.lazy[0], x.lazy[1]), x.lazy[2]
         a = make_conv_args(prob, B, x.buf, layer.p_fwd, y.buf, in_scale=in_affine[0] if in_affine else None,
                            in_shift=in_affine[1] if in_affine else None, bias=bias,
                            out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
@@ -268,7 +275,8 @@ class Plan:
         self.macs["awr_conv_gemm:" + layer.name] = self._gemm_macs(prob, B, spec)
         self._keep.append(a)
         if self.training:
-            assert in_affine is None and out_affine is None and not relu_in and not relu_out, "fused affine/ReLU are inference-only"
+            assert out_affine is None and not relu_out, "fused output affine/ReLU are inference-only"
+            assert x.lazy is not None or (in_affine is None and not relu_in), "training-mode input affine comes from a lazy tensor"
             self.nodes.append(lambda: self._conv_bwd(x, y, layer, res, bias is not None))
         return y
 
@@ -291,7 +299,8 @@ class Plan:
         ld = wp["Cg"]
         R = self._scratch(wp["Cd"] * len(wp["taps"]) * ld).view(wp["Cd"], len(wp["taps"]), ld)
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
-        wa = make_wgrad_args(wp, B, D, G, R, ld)
+        xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
+        wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
         self._keep.append(wa)
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
@@ -326,9 +335,11 @@ class Plan:
                                                         L.ptr(sc), L.ptr(sh), None), "awr_bn_fold_eval"))
         return sc, sh
 
-    def bn_act(self, y, bn, relu, res=None):
-        """Training-mode BatchNorm (+residual) (+ReLU): a = [relu](bn(y) [+ res])."""
-        assert self.training
+    def bn_act(self, y, bn, relu, res=None, lazy=False):
+        """Training-mode BatchNorm (+residual) (+ReLU): a = [relu](bn(y) [+ res]).  lazy=True (no residual): the
+        normalised tensor is NOT written; the returned handle carries (scale, shift, relu) for its consumers."""
+        assert self.training and y.lazy is None and (res is None or res.lazy is None)
+        assert not (lazy and res is not None)
         B, H, W, C_ = y.shape
         if y.stats is None:
             y.stats = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
@@ -343,9 +354,12 @@ class Plan:
         self._f("awr_bn_finalize", L.ptr(own_stats), C_, y.npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom,
                 BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd))
         self.bns.append(bn)
-        a = self.new(B, H, W, C_, name=bn.name + ".act")
-        self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
-                y.npix, C_)
+        if lazy:
+            a = T(y.buf, True, bn.name + ".act(lazy)", lazy=(sc, sh, bool(relu)))
+        else:
+            a = self.new(B, H, W, C_, name=bn.name + ".act")
+            self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
+                    y.npix, C_)
         self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh))
         return a
 
@@ -385,7 +399,9 @@ class Plan:
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = self.new(B, Ho, Wo, C_, name=x.name + ".pool")
         arg = self.alloc(B, Ho, Wo, C_, dtype=torch.uint8) if self.training else None
-        self._f("awr_maxpool_fwd", L.ptr(x.buf), B, H, W, C_, k, s, p, L.ptr(y.buf), L.ptr(arg))
+        lz = x.lazy
+        self._f("awr_maxpool_fwd", L.ptr(x.buf), L.ptr(lz[0]) if lz else None, L.ptr(lz[1]) if lz else None, int(lz[2]) if lz else 0,
+                B, H, W, C_, k, s, p, L.ptr(y.buf), L.ptr(arg))
         if self.training:
             def bwd():
                 if not x.needs_grad:
@@ -398,6 +414,7 @@ class Plan:
     def upsample_add(self, up1, low):
         """out = up1 + nearest_upsample_x2(low)   (hourglass.py:77,:88)"""
         B, Hl, Wl, C_ = low.shape
+        assert up1.lazy is None and low.lazy is None
         y = self.new(B, 2 * Hl, 2 * Wl, C_, name=up1.name + ".upadd")
         self._f("awr_upsample2_add", L.ptr(up1.buf), L.ptr(low.buf), B, Hl, Wl, C_, L.ptr(y.buf))
         if self.training:

@@ -363,16 +363,17 @@ class ResNet18Deconv(AwrBackbone):
         return Lr
 
     @staticmethod
-    def _cbr(P, Lr, x, conv, bn, relu, res=None):
-        """conv -> BatchNorm [-> +res] [-> ReLU]; fused into one GEMM epilogue in inference."""
+    def _cbr(P, Lr, x, conv, bn, relu, res=None, lazy=False):
+        """conv -> BatchNorm [-> +res] [-> ReLU]; fused into one GEMM epilogue in inference.  lazy (training): the
+        BN+ReLU output is not materialised -- legal when every consumer is a conv / max-pool loader."""
         if P.training:
             y = P.conv(x, Lr[conv], want_stats=True, use_bias=Lr[conv].bias is not None)
-            return P.bn_act(y, Lr[bn], relu, res)
+            return P.bn_act(y, Lr[bn], relu, res, lazy=lazy and res is None)
         return P.conv(x, Lr[conv], out_affine=P.fold_bn(Lr[bn]), res=res, relu_out=relu, use_bias=Lr[conv].bias is not None)
 
     def build(self, P, img, H):
         Lr = self._layers()
-        c = self._cbr(P, Lr, P.im2col5(img, H, H), "pre.0", "pre.1", True)
+        c = self._cbr(P, Lr, P.im2col5(img, H, H), "pre.0", "pre.1", True, lazy=True)     # consumed by the max-pool loader only
         c = P.maxpool(c, 3, 2, 1)
         for li in range(1, 5):
             for bi in range(2):
@@ -380,10 +381,10 @@ class ResNet18Deconv(AwrBackbone):
                 # the downsample branch is emitted first so that, in the reversed (backward) order, conv1's
                 # full-coverage data gradient initialises d(block input) before the strided 1x1 accumulates
                 r = self._cbr(P, Lr, c, p + ".downsample.0", p + ".downsample.1", False) if (p + ".downsample.0") in Lr else c
-                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True)
+                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=True)              # consumed by conv2 only
                 c = self._cbr(P, Lr, o, p + ".conv2", p + ".bn2", True, res=r)
         for i in range(self.ndeconv):
-            c = self._cbr(P, Lr, c, "deconv_layers.%d" % (3 * i), "deconv_layers.%d" % (3 * i + 1), True)
+            c = self._cbr(P, Lr, c, "deconv_layers.%d" % (3 * i), "deconv_layers.%d" % (3 * i + 1), True, lazy=True)   # next deconv / head GEMM
         pred = P.conv(c, Lr["head"])
         P.head_out(pred, self.J)
 
@@ -444,9 +445,10 @@ class HourglassNet(AwrBackbone):
     def _residual(self, P, Lr, x, p):
         skip = Lr.get(p + ".skip_layer")
         if P.training:
-            a = P.bn_act(x, Lr[p + ".bn1"], True)
-            a = P.bn_act(P.conv(a, Lr[p + ".conv1"], want_stats=True), Lr[p + ".bn2"], True)
-            a = P.bn_act(P.conv(a, Lr[p + ".conv2"], want_stats=True), Lr[p + ".bn3"], True)
+            # the three pre-activations feed exactly one conv each: never written to HBM
+            a = P.bn_act(x, Lr[p + ".bn1"], True, lazy=True)
+            a = P.bn_act(P.conv(a, Lr[p + ".conv1"], want_stats=True), Lr[p + ".bn2"], True, lazy=True)
+            a = P.bn_act(P.conv(a, Lr[p + ".conv2"], want_stats=True), Lr[p + ".bn3"], True, lazy=True)
             r = P.conv(x, skip) if skip is not None else x
             return P.conv(a, Lr[p + ".conv3"], res=r, want_stats=True)
         y = P.conv(x, Lr[p + ".conv1"], in_affine=P.fold_bn(Lr[p + ".bn1"]), relu_in=True)
@@ -471,7 +473,7 @@ class HourglassNet(AwrBackbone):
         for i in range(self.nstack):
             hg = self._hg(P, Lr, c, "hgs.%d.0" % i, 4)
             ft = self._residual(P, Lr, hg, "features.%d.0" % i)
-            ft = ResNet18Deconv._cbr(P, Lr, ft, "features.%d.1" % i, "features.%d.1.bn" % i, True)
+            ft = ResNet18Deconv._cbr(P, Lr, ft, "features.%d.1" % i, "features.%d.1.bn" % i, True, lazy=True)      # head / merge GEMMs
             pred = P.conv(ft, Lr["head.%d" % i])
             P.head_out(pred, self.J)
             if i < self.nstack - 1:

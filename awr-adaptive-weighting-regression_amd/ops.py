@@ -125,9 +125,14 @@ def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, 
     return a
 
 
-def make_wgrad_args(prob, B, D, G, R, ld):
+def make_wgrad_args(prob, B, D, G, R, ld, d_affine=None, g_affine=None):
+    """d_affine / g_affine: (scale, shift, relu) applied to the operand while staging (un-materialised BN+ReLU)."""
     a = L.WgradArgs()
     a.D, a.G, a.R = L.ptr(D), L.ptr(G), L.ptr(R)
+    if d_affine is not None:
+        a.d_scale, a.d_shift, a.d_relu = L.ptr(d_affine[0]), L.ptr(d_affine[1]), int(d_affine[2])
+    if g_affine is not None:
+        a.g_scale, a.g_shift, a.g_relu = L.ptr(g_affine[0]), L.ptr(g_affine[1]), int(g_affine[2])
     a.B, a.Hd, a.Wd, a.Cd = B, prob["Hd"], prob["Wd"], prob["Cd"]
     a.Hg, a.Wg, a.Cg, a.sg, a.T, a.ld = prob["Hg"], prob["Wg"], prob["Cg"], prob["sg"], len(prob["taps"]), ld
     for t, (dy, dx) in enumerate(prob["taps"]):
@@ -173,14 +178,15 @@ def conv_dgrad(spec, dy, wp, hin, win, **kw):
     return out
 
 
-def conv_wgrad(spec, x, dy, grad=None, accumulate=False):
-    """Returns the gradient in checkpoint layout (same shape as the layer's weight)."""
+def conv_wgrad(spec, x, dy, grad=None, accumulate=False, x_affine=None):
+    """Returns the gradient in checkpoint layout (same shape as the layer's weight).  x_affine: (scale, shift, relu)
+    when the layer input is relu(x*scale+shift) of the tensor passed as `x`."""
     B, H, W, _ = x.shape
     prob = spec.wgrad_problem(H, W)
     ld = prob["Cg"]
     R = torch.zeros(prob["Cd"], len(prob["taps"]), ld, device=x.device, dtype=torch.float32)
     D, G = (dy, x) if prob["D"] == "dy" else (x, dy)
-    a = make_wgrad_args(prob, B, D, G, R, ld)
+    a = make_wgrad_args(prob, B, D, G, R, ld, **({"g_affine" if prob["D"] == "dy" else "d_affine": x_affine} if x_affine else {}))
     L.call("awr_conv_wgrad", C.byref(a), L.stream())
     if grad is None:
         grad = torch.empty(prob["d0"], prob["d1"], spec.k, spec.k, device=x.device, dtype=torch.float32)

@@ -164,6 +164,8 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream);
 /* test hook: force the (TM,TN) in {1,2}^2 workgroup tile of awr_conv_gemm / awr_conv_wgrad
  * (0,0 = automatic choice).  Not for production use. */
 int awr_debug_force_tile(int tm, int tn);
+/* test/tuning hook: main-loop variant of awr_conv_gemm (0 = single LDS buffer, 1 = double-buffered pipeline) */
+int awr_debug_gemm_variant(int v);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).
@@ -174,6 +176,11 @@ typedef struct awr_wgrad_args {
     const float* D;
     const float* G;
     float* R;
+    const float* d_scale;   /* optional per-channel affine (+ReLU) applied to D / G while staging: the operand is */
+    const float* d_shift;   /* then relu(t*scale+shift) of the stored tensor, i.e. a BatchNorm+ReLU output that  */
+    const float* g_scale;   /* was never materialised (zero padding of the gather stays zero)                    */
+    const float* g_shift;
+    int d_relu, g_relu;
     int B, Hd, Wd, Cd, Hg, Wg, Cg, sg, T, ld;
     int8_t dy[16], dx[16];
 } awr_wgrad_args;
@@ -219,9 +226,10 @@ int awr_add(const float* a, const float* b, float* out, int64_t n, void* stream)
 /* per-channel bias gradient: db[c] (+)= sum over pixels dy[pix][c] */
 int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulate, void* stream);
 
-/* MaxPool2d(k,s,p) NHWC forward (+ uint8 argmax) and backward; nn.MaxPool2d(3,2,1)/(2,2). */
-int awr_maxpool_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* out,
-                    uint8_t* argmax, void* stream);
+/* MaxPool2d(k,s,p) NHWC forward (+ uint8 argmax) and backward; nn.MaxPool2d(3,2,1)/(2,2).
+ * in_scale/in_shift (optional): pool relu(x*scale+shift) instead of x (fused BatchNorm+ReLU input). */
+int awr_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, int in_relu, int B, int H,
+                    int W, int C, int k, int s, int p, float* out, uint8_t* argmax, void* stream);
 int awr_maxpool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k,
                     int s, int p, float* dx, int accumulate, void* stream);
 /* hourglass.py:88: out = up1 + nearest_upsample2(low)  and its backward (dlow = 2x2 sums of dout) */

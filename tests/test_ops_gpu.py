@@ -98,16 +98,20 @@ def test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, 
     assert rel_err(gw2.cpu(), 2 * gw_ref) < 1e-5
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
-                                                              ("deconv", 64, 96, 4, 2, 1, 3, 10)])
-def test_conv_every_tile_shape(ops, L, dev, tm, tn, kind, cin, cout, k, stride, pad, B, H):
-    """All four workgroup tiles (64/128 x 64/128) on ragged M and N (not multiples of any tile)."""
+                                                              ("deconv", 64, 96, 4, 2, 1, 3, 10), ("conv", 32, 64, 1, 1, 0, 2, 12)])
+def test_conv_every_tile_shape(ops, L, dev, variant, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """All four workgroup tiles (64/128 x 64/128) and both main-loop variants (single-buffer / double-buffered
+    pipeline) on ragged M and N (not multiples of any tile), incl. a single-K-slice problem."""
     L.call("awr_debug_force_tile", tm, tn)
+    L.call("awr_debug_gemm_variant", variant)
     try:
         test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, H)
     finally:
         L.call("awr_debug_force_tile", 0, 0)
+        L.call("awr_debug_gemm_variant", 0)
 
 
 def test_conv_fused_prologue_epilogue_stats(ops, dev):
@@ -229,7 +233,7 @@ def test_maxpool(L, dev, k, s, p, B, H, C):
     xg = ops.nhwc(x).to(dev)
     out = torch.empty(B, Ho, Ho, C, device=dev)
     arg = torch.empty(B, Ho, Ho, C, device=dev, dtype=torch.uint8)
-    L.call("awr_maxpool_fwd", L.ptr(xg), B, H, H, C, k, s, p, L.ptr(out), L.ptr(arg), L.stream())
+    L.call("awr_maxpool_fwd", L.ptr(xg), None, None, 0, B, H, H, C, k, s, p, L.ptr(out), L.ptr(arg), L.stream())
     assert rel_err(ops.nchw(out).cpu(), ref.detach()) == 0.0
     dx = torch.empty_like(xg)
     L.call("awr_maxpool_bwd", DP(L, ops.nhwc(gout), dev), L.ptr(arg), B, H, H, C, k, s, p, L.ptr(dx), 0, L.stream())
@@ -238,6 +242,28 @@ def test_maxpool(L, dev, k, s, p, B, H, C):
     assert rel_err(got, gx_ref) < 1e-6
     L.call("awr_maxpool_bwd", DP(L, ops.nhwc(gout), dev), L.ptr(arg), B, H, H, C, k, s, p, L.ptr(dx), 1, L.stream())
     assert rel_err(ops.nchw(dx).cpu(), 2 * gx_ref) < 1e-6
+
+
+def test_fused_affine_loaders(ops, L, dev):
+    """Un-materialised BatchNorm+ReLU inputs: wgrad (conv: gathered operand, deconv: dense operand) and max-pool
+    apply relu(x*s+t) while loading and must equal the same op on the materialised tensor."""
+    B, H, cin, cout = 2, 16, 64, 96
+    x = rnd(B, cin, H, H, seed=1)
+    s_, t_ = rnd(cin, seed=2) + 0.2, rnd(cin, seed=3) * 0.5          # some negative scales too
+    a = TF.relu(x * s_.view(1, -1, 1, 1) + t_.view(1, -1, 1, 1))
+    xg, ag, sg, tg = ops.nhwc(x).to(dev), ops.nhwc(a).to(dev), s_.to(dev), t_.to(dev)
+    for kind, k, st, p in (("conv", 3, 1, 1), ("conv", 3, 2, 1), ("deconv", 4, 2, 1)):
+        spec = ops.ConvSpec(kind, cin, cout, k, st, p)
+        ho = spec.out_hw(H, H)[0]
+        gy = ops.nhwc(rnd(B, cout, ho, ho, seed=4)).to(dev)
+        ref = ops.conv_wgrad(spec, ag, gy)
+        got = ops.conv_wgrad(spec, xg, gy, x_affine=(sg, tg, True))
+        assert rel_err(got.cpu(), ref.cpu()) < 2e-5, kind
+    out_a, out_x = torch.empty(B, 8, 8, cin, device=dev), torch.empty(B, 8, 8, cin, device=dev)
+    arg_a, arg_x = torch.empty(B, 8, 8, cin, device=dev, dtype=torch.uint8), torch.empty(B, 8, 8, cin, device=dev, dtype=torch.uint8)
+    L.call("awr_maxpool_fwd", L.ptr(ag), None, None, 0, B, H, H, cin, 3, 2, 1, L.ptr(out_a), L.ptr(arg_a), L.stream())
+    L.call("awr_maxpool_fwd", L.ptr(xg), L.ptr(sg), L.ptr(tg), 1, B, H, H, cin, 3, 2, 1, L.ptr(out_x), L.ptr(arg_x), L.stream())
+    assert rel_err(out_x.cpu(), out_a.cpu()) < 1e-6 and float((arg_a != arg_x).float().mean()) < 1e-3
 
 
 def test_upsample_add_and_misc(L, dev):

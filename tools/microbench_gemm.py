@@ -94,8 +94,13 @@ def main():
                 if spec.cout <= 64 and tile[1] == 2:
                     continue
                 t, tf = run_fwd(spec, B, H, tile)
+                alt = []
+                for v in (1, 2, 3):
+                    L.call("awr_debug_gemm_variant", v)
+                    alt.append("v%d %.0fTF" % (v, run_fwd(spec, B, H, tile)[1]))
+                L.call("awr_debug_gemm_variant", 0)
                 tw, tfw = run_wgrad(spec, B, H, tile)
-                best.append("%s fwd %.0fus %.0fTF | wgrad %.0fus %.0fTF" % (tile, t * 1e6, tf, tw * 1e6, tfw))
+                best.append("%s fwd %.0fus %.0fTF  [%s] | wgrad %.0fus %.0fTF" % (tile, t * 1e6, tf, " ".join(alt), tw * 1e6, tfw))
             t, tf = run_fwd(spec, B, H)
             print("%-28s auto fwd %.0f TF" % (name, tf))
             for b_ in best:
