@@ -418,26 +418,3 @@ class Trainer:
             np.savetxt(os.path.join(self.work_dir, "test_%.3f.txt" % mpe), jt_uvd.reshape([jt_uvd.shape[0], cfg.jt_num * 3]), fmt="%.3f")
         self._msg("[epoch {:2d}], [test mpe {:.3f}], [lr {:.1e}]".format(epoch, mpe, self.engine.lr))
         return mpe
-
-
-def smoke_step(dev):
-    """Tiny end-to-end check used by __graft_entry__.smoke(): one ResNet18-deconv train step (B=2)
-    on the HIP path against the oracle."""
-    import awr_oracle as O          # test infrastructure; only reachable from smoke()
-    from .nets import ResNet18Deconv
-    img, jt = O.synth_batch(2, 128, 14, seed=7)
-    man = O.manifest_for("resnet_18", 14)
-    sd = O.procedural_state(man, seed=1)
-    net = ResNet18Deconv(14)
-    net.load_state_dict(sd)
-    net = net.cuda()
-    eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, dense_weight=1.0, use_graph=False)
-    losses, jt_pred = eng.step(img.to(dev), jt.to(dev))
-    ost = {"step": 0, "m": {}, "v": {}}
-    lo, lc, ld, grads, jt_o = O.train_step("resnet_18", sd, ost, img, jt, 1.0, 1.0, 1.0)
-    got = float(losses[2])
-    assert abs(got - float(lo)) <= 2e-4 * max(1e-3, abs(float(lo))), ("loss", got, float(lo))
-    assert float((jt_pred.cpu() - jt_o).abs().max()) < 1e-4, "joints"
-    w = net.state_dict()["layer1.0.conv1.weight"].cpu()
-    d = (w - sd["layer1.0.conv1.weight"]).abs().flatten()
-    assert float(torch.quantile(d, 0.9)) < 1e-4 and float(d.max()) < 2.1e-3, "params after Adam"
