@@ -68,8 +68,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
     constexpr int NBUF = DB ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float As[NBUF * BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDK];
+    // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
+    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 configuration)
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDK];
+    float* const As = smem;
+    float* const Bs = smem + NBUF * BM * LDK;
 
     const awr_phase& ph = a.ph[blockIdx.y];
     const int M = a.B * a.Hq * a.Wq;
@@ -246,63 +249,99 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // The MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) gives each lane ONE column: storing
+    // from it means 16 four-byte stores per tile per lane.  Each wave instead bounces its 32x32 tile through a private
+    // 32x36 LDS tile and leaves with float4 rows: 4 sixteen-byte stores per lane, every store instruction covering eight
+    // full 128-byte lines; bias / folded-BN affine / residual (also loaded as float4) / statistics / ReLU are applied on
+    // the way out.  (The single-K-slice layers -- im2col'd stem, 1x1 convs on the 128x128 maps -- are store-bound.)
     const bool direct = (a.so == 1);   // out pixel index == m
-    float cs1[TN], cs2[TN];
+    __syncthreads();                    // every wave is done with the staged slices
+    float* tbuf = smem + wave * (32 * LDK);
+    const int c4 = lane & 7, rbase = lane >> 3;
+    float4 cs1[TN], cs2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = tile_n * BN + wn * 32 * TN + j * 32 + l31;
-        const bool nok = n < a.N;
-        const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
-        const float osc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
-        const float osh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
+        const bool nok = n0 < a.N;                                        // N % 4 == 0: the whole float4 is in or out
+        const float4 z4 = make_float4(0, 0, 0, 0), o4 = make_float4(1, 1, 1, 1);
+        const float4 bias = (a.bias && nok) ? ld4(a.bias + n0) : z4;
+        const float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
+        const float4 osh = (a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
+        float4 s1 = z4, s2 = z4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tile_m * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * half) * LDK + l31] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();       // LDS ops of one wave execute in order; keep the compiler from reordering
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rbase + 8 * q;
+                float4 v = ld4(tbuf + row * LDK + 4 * c4);
+                const int m = tile_m * BM + wm * 32 * TM + i * 32 + row;
                 if (m < M && nok) {
                     int opix = m;
                     if (!direct) {
                         const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
                         opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
                     }
-                    float v = acc[i][j][r] + bias;
-                    if (a.out_scale) v = v * osc + osh;
-                    if (a.res) v += a.res[opix * a.N + n];
-                    s1 += v;
-                    s2 += v * v;
-                    if (a.relu_out) v = fmaxf(v, 0.f);
-                    a.out[opix * a.N + n] = v;
+                    const size_t o = (size_t)opix * a.N + n0;
+                    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                    if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
+                    if (a.res) {
+                        const float4 rr = ld4(a.res + o);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                    if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    st4(a.out + o, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
+        }
+        cs1[j] = s1;
+        cs2[j] = s2;
+    }
+    if (a.stats) {
+        // BatchNorm statistics.  Lanes with equal (lane & 7) hold partial sums of the same 4 columns: fold lane bits 3..5,
+        // combine the two M-waves of the workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over
+        // AWR_STAT_SLOTS accumulator copies (thousands of workgroups hit the same C channels; without the slots the
+        // atomics serialise in L2 and cost more than the GEMM epilogue itself).
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float* p1 = &cs1[j].x;
+            float* p2 = &cs2[j].x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) {
+                    p1[e] += __shfl_xor(p1[e], o, 64);
+                    p2[e] += __shfl_xor(p2[e], o, 64);
                 }
             }
         }
-        cs1[j] = s1 + __shfl_xor(s1, 32, 64);
-        cs2[j] = s2 + __shfl_xor(s2, 32, 64);
-    }
-    if (a.stats) {
-        // BatchNorm statistics: combine the two M-waves of the workgroup in LDS, then ONE fp64 atomic per column and
-        // statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands of workgroups hit the same C channels;
-        // without the slots the atomics serialise in L2 and cost more than the GEMM epilogue itself).
-        float* red = As;     // the K loop is over: LDS is free
-        __syncthreads();
-        if (wm == 1 && half == 0) {
+        __syncthreads();                 // all transpose tiles are dead: reuse the LDS for the cross-wave combine
+        float4* red = reinterpret_cast<float4*>(smem);
+        if (wm == 1 && lane < 8) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                red[(wn * TN + j) * 64 + l31] = cs1[j];
-                red[(wn * TN + j) * 64 + 32 + l31] = cs2[j];
+                red[((wn * TN + j) * 2 + 0) * 8 + lane] = cs1[j];
+                red[((wn * TN + j) * 2 + 1) * 8 + lane] = cs2[j];
             }
         }
         __syncthreads();
-        if (wm == 0 && half == 0) {
+        if (wm == 0 && lane < 8) {
             double* st = a.stats + (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * a.N;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = tile_n * BN + wn * 32 * TN + j * 32 + l31;
-                if (n < a.N) {
-                    atomicAdd(st + n, (double)(cs1[j] + red[(wn * TN + j) * 64 + l31]));
-                    atomicAdd(st + a.N + n, (double)(cs2[j] + red[(wn * TN + j) * 64 + 32 + l31]));
+                const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
+                if (n0 < a.N) {
+                    const float4 o1 = red[((wn * TN + j) * 2 + 0) * 8 + lane], o2 = red[((wn * TN + j) * 2 + 1) * 8 + lane];
+                    atomicAdd(st + n0 + 0, (double)(cs1[j].x + o1.x)); atomicAdd(st + n0 + 1, (double)(cs1[j].y + o1.y));
+                    atomicAdd(st + n0 + 2, (double)(cs1[j].z + o1.z)); atomicAdd(st + n0 + 3, (double)(cs1[j].w + o1.w));
+                    atomicAdd(st + a.N + n0 + 0, (double)(cs2[j].x + o2.x)); atomicAdd(st + a.N + n0 + 1, (double)(cs2[j].y + o2.y));
+                    atomicAdd(st + a.N + n0 + 2, (double)(cs2[j].z + o2.z)); atomicAdd(st + a.N + n0 + 3, (double)(cs2[j].w + o2.w));
                 }
             }
         }
@@ -471,6 +510,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
     AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
+    AWR_REQUIRE(a->N % 4 == 0, "conv_gemm: N=%d must be a multiple of 4 (16-byte output rows)", a->N);
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
     for (int p = 0; p < a->nphase; ++p) {
