@@ -66,7 +66,7 @@ def job_table(jobs, device):
 class WgradArgs(C.Structure):
     _fields_ = [("D", C.c_void_p), ("G", C.c_void_p), ("R", C.c_void_p),
                 ("d_scale", C.c_void_p), ("d_shift", C.c_void_p), ("g_scale", C.c_void_p), ("g_shift", C.c_void_p),
-                ("d_relu", C.c_int), ("g_relu", C.c_int),
+                ("d_colsum", C.c_void_p), ("d_relu", C.c_int), ("g_relu", C.c_int),
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
                 ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]

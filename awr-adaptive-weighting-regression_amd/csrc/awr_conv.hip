@@ -426,11 +426,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
     float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
     if (a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * BM + da_c); dsh = ld4(a.d_shift + tcd * BM + da_c); }
     if (a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * BN + ga_c); gsh = ld4(a.g_shift + tcg * BN + ga_c); }
+    // column sums of D (= the conv's bias gradient): only the tap-0 / first-cg-tile workgroups of each pixel chunk count
+    const bool do_colsum = a.d_colsum != nullptr && t == 0 && tcg == 0;
+    float4 csum = make_float4(0, 0, 0, 0);
     auto store_slice = [&]() {
         if (a.d_scale) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 if (d_ok & (1u << i)) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
+        }
+        if (do_colsum) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
         }
         if (a.g_scale) {
 #pragma unroll
@@ -481,6 +488,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
                 const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + t) * a.ld + cg, acc[i][j][r]);
             }
+    }
+    if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(Ds);
+        red[da_r * FM + (tid % FM)] = csum;
+        __syncthreads();
+        if (da_r == 0 && d_cok) {
+            float4 tsum = make_float4(0, 0, 0, 0);
+            for (int g = 0; g < PM; ++g) {
+                const float4 v = red[g * FM + tid];
+                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
+            }
+            float* o = a.d_colsum + tcd * BM + da_c;
+            atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+        }
     }
 }
 

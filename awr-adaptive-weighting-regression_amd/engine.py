@@ -285,7 +285,8 @@ class Plan:
         B, H, W, _ = x.shape
         dy = y.grad
         assert dy is not None, "no gradient reached %s" % y.name
-        if has_bias:
+        fused_bias = has_bias and layer.batchable and spec.kind == "conv"
+        if has_bias and not fused_bias:
             tgt = layer.bias_grad_target()
             self._b("awr_bias_grad", L.ptr(dy), y.npix, y.shape[3], L.ptr(tgt), 0)
             if hasattr(layer, "bias_grad_post"):
@@ -300,6 +301,10 @@ class Plan:
         R = self._scratch(wp["Cd"] * len(wp["taps"]) * ld).view(wp["Cd"], len(wp["taps"]), ld)
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
         xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
+        bsum = None
+        if fused_bias:      # the bias gradient (column sums of dY) falls out of the slices the wgrad kernel stages anyway
+            bsum = self._scratch(y.shape[3])
+            xa["d_colsum"] = bsum
         wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
         self._keep.append(wa)
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
@@ -309,6 +314,11 @@ class Plan:
                 job = L.UnpackJob(args[0], args[5], args[1], args[2], args[3], args[4], 0)
                 self._unpack_jobs.append(job)
                 self._note_grad(layer.gw, job)
+            if bsum is not None:
+                n = layer.gbias.numel()
+                job = L.UnpackJob(L.ptr(bsum), L.ptr(layer.gbias), 1, n, 1, n, 0)
+                self._unpack_jobs.append(job)
+                self._note_grad(layer.gbias, job)
         else:
             for name, args in layer.wgrad_unpack_calls(R, ld):
                 self._b(name, *args)
@@ -457,7 +467,8 @@ class Plan:
         for i, st in enumerate(self._head_states):
             st["used"] = i in supervised_stages
         # split-K scratch for every weight gradient, as one arena (capacity = all packed gradients of the used layers)
-        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) for l in self.layers) + 64
+        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) + round_up(l.spec.cout_pad, 4)
+                                for l in self.layers) + 64
         first = len(self.bwd_ops)
         self.bwd_ops.append(None)        # placeholder for the scratch fill (kept in place so recorded op indices stay valid)
         for emit in reversed(self.nodes):

@@ -180,6 +180,8 @@ typedef struct awr_wgrad_args {
     const float* d_shift;   /* then relu(t*scale+shift) of the stored tensor, i.e. a BatchNorm+ReLU output that  */
     const float* g_scale;   /* was never materialised (zero padding of the gather stays zero)                    */
     const float* g_shift;
+    float* d_colsum;        /* optional [Cd]: += column sums of D over all pixels (for conv wgrad, D = dY, this IS the
+                               bias gradient -- it falls out of the slices the kernel stages anyway); zeroed by caller */
     int d_relu, g_relu;
     int B, Hd, Wd, Cd, Hg, Wg, Cg, sg, T, ld;
     int8_t dy[16], dx[16];

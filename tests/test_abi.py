@@ -56,7 +56,7 @@ def test_struct_layout_matches_header(lib):
     # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 10 pointers + 15 ints + 4 phases
     assert C.sizeof(lib.Phase) == 76
     assert C.sizeof(lib.ConvArgs) == 10 * 8 + 15 * 4 + 4 * 76 + 4   # trailing pad to 8-byte alignment
-    assert C.sizeof(lib.WgradArgs) == 7 * 8 + 12 * 4 + 32
+    assert C.sizeof(lib.WgradArgs) == 8 * 8 + 12 * 4 + 32
 
 
 def test_product_path_fails_loudly_on_cpu_tensors(lib):

@@ -87,8 +87,11 @@ def test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, 
     wpd = ops.pack_weight(wg, spec.dgrad_pack())
     gx = ops.conv_dgrad(spec, ops.nhwc(gy).to(dev), wpd, H, H)
     assert rel_err(ops.nchw(gx).cpu(), gx_ref) < tol
-    gw = ops.conv_wgrad(spec, ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev))
+    bg = torch.empty(cout, device=dev) if kind == "conv" else None
+    gw = ops.conv_wgrad(spec, ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev), bias_grad=bg)
     assert rel_err(gw.cpu(), gw_ref) < 1e-5
+    if bg is not None:       # the bias gradient falls out of the same kernel (column sums of dY)
+        assert rel_err(bg.cpu(), gy.double().sum((0, 2, 3))) < 1e-5
     # accumulate paths: dgrad onto an existing gradient, wgrad onto an existing gradient
     base = rnd(B, cin, H, H, seed=5)
     acc = ops.nhwc(base).to(dev)
