@@ -39,11 +39,12 @@ class ConvArgs(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p),
                 ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("bias", C.c_void_p),
                 ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("res", C.c_void_p), ("stats", C.c_void_p),
+                ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p),
                 ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
                 ("Hq", C.c_int), ("Wq", C.c_int),
                 ("Hout", C.c_int), ("Wout", C.c_int), ("N", C.c_int),
                 ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
-                ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int),
+                ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int), ("tile_m", C.c_int), ("tile_n", C.c_int),
                 ("ph", Phase * 4)]
 
 
@@ -69,6 +70,7 @@ class WgradArgs(C.Structure):
                 ("d_colsum", C.c_void_p), ("d_relu", C.c_int), ("g_relu", C.c_int),
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
                 ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
+                ("tile_m", C.c_int), ("tile_n", C.c_int), ("target_blocks", C.c_int),
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]
 
 

@@ -268,6 +268,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         const float4 bias = (a.bias && nok) ? ld4(a.bias + n0) : z4;
         const float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
         const float4 osh = (a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
+        float4 ksc = o4, ksh = z4, kmu = z4, kis = o4;       // fused BatchNorm-backward reduction coefficients
+        if (a.bnr_y && nok) {
+            ksc = ld4(a.bnr_coef + n0); ksh = ld4(a.bnr_coef + a.N + n0);
+            kmu = ld4(a.bnr_coef + 2 * a.N + n0); kis = ld4(a.bnr_coef + 3 * a.N + n0);
+        }
         float4 s1 = z4, s2 = z4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -292,8 +297,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
                         const float4 rr = ld4(a.res + o);
                         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                     }
-                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                    if (a.bnr_y) {
+                        // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
+                        const float4 yy = ld4(a.bnr_y + o);
+                        v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
+                        v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
+                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                        s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
+                        s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
+                    } else {
+                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                    }
                     if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     st4(a.out + o, v);
                 }
@@ -533,6 +548,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
     AWR_REQUIRE(a->N % 4 == 0, "conv_gemm: N=%d must be a multiple of 4 (16-byte output rows)", a->N);
+    AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && !a->res), "conv_gemm: fused BN-backward reduction needs coef + stats and no accumulate");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
     for (int p = 0; p < a->nphase; ++p) {
@@ -550,6 +566,11 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     auto blocks = [&](int tm, int tn) { return ((M + 64 * tm - 1) / (64 * tm)) * ((a->N + 64 * tn - 1) / (64 * tn)) * a->nphase; };
     int TM = 1, TN = (a->N > 64 && blocks(1, 2) >= 512) ? 2 : 1;
     if (a->Cin * a->ph[0].ntaps <= 64) TM = 2;     // one or two K-slices (the im2col'd stem): store-bound, amortise the epilogue
+    if (a->tile_m) {
+        AWR_REQUIRE((a->tile_m == 1 || a->tile_m == 2) && (a->tile_n == 1 || a->tile_n == 2), "conv_gemm: tile_m/tile_n must be 1 or 2");
+        TM = a->tile_m;
+        TN = a->tile_n;
+    }
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     hipStream_t st = as_stream(stream);
@@ -581,10 +602,15 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     // measured (tools/microbench_gemm.py, AWR_WGRAD_BLOCKS sweep): 64x64 tiles with ~3072 workgroups win on the small
     // feature maps; the 128x64 (cd x cg) tile with ~2048 workgroups wins once there are >= 128K pixels to contract.
     int TM = (a->Cd > 64 && M >= 131072) ? 2 : 1, TN = 1;
+    if (a->tile_m) {
+        AWR_REQUIRE((a->tile_m == 1 || a->tile_m == 2) && (a->tile_n == 1 || a->tile_n == 2), "conv_wgrad: tile_m/tile_n must be 1 or 2");
+        TM = a->tile_m;
+        TN = a->tile_n;
+    }
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
     static const int target_blocks = []() { const char* e = getenv("AWR_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning hook
-    const int want_blocks = target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
+    const int want_blocks = a->target_blocks > 0 ? a->target_blocks : target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
     int64_t nsplit = (want_blocks + tiles - 1) / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 8 K-slices per workgroup
     if (nsplit > max_split) nsplit = max_split;

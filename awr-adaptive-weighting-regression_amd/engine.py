@@ -176,6 +176,10 @@ class Plan:
         self.n_buckets = 1          # > 1: gradients leave the backward pass in buckets (data-parallel overlap)
         self.bucket_hook = None     # callable(lo, hi) fired when arena[lo:hi] holds final gradients
         self._grad_writes = []      # (arena_lo, arena_hi, ready_op_index, unpack_job|None)
+        self._gemm_structs = []     # (entry point, ctypes args, name) of every GEMM launch: what autotune() iterates over
+        self._zero_init = []        # buffers that must be all-zero before the first real step (atomic accumulators)
+        self.tuned = {}
+        self._grad_writers = {}     # id(T) -> [ConvArgs of the dgrad that wrote T.grad | None for any other writer]
         self.macs = {}              # op name -> algorithmic MACs of that GEMM launch (bench.py roofline)
         self._keep = []             # ctypes argument structs referenced by the op lists
         self._head_states = []
@@ -194,6 +198,8 @@ class Plan:
         t = (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
         self.bytes += t.numel() * t.element_size()
         self._bufs.append(t)        # the op lists hold raw device pointers: the plan owns every buffer for its lifetime
+        if zero:
+            self._zero_init.append(t)
         return t
 
     def new(self, B, H, W, C_, needs_grad=True, name=""):
@@ -223,8 +229,10 @@ class Plan:
         lo = (tensor.data_ptr() - self.garena.data_ptr()) // 4
         self._grad_writes.append((lo, lo + tensor.numel(), len(self.bwd_ops) - 1, job))
 
-    def _gtarget(self, t):
+    def _gtarget(self, t, writer=None):
         """-> (gradient buffer, accumulate?)  and marks the gradient as live."""
+        if writer != "dgrad":
+            self._grad_writers.setdefault(id(t), []).append(None)
         if t.grad is None:
             t.grad = self.alloc(*t.shape)
             return t.grad, False
@@ -234,6 +242,7 @@ class Plan:
         """grad(t) += src_grad where src_grad is a finished gradient buffer: alias when first."""
         if not t.needs_grad:
             return
+        self._grad_writers.setdefault(id(t), []).append(None)
         if t.grad is None:
             t.grad = src_grad
         else:
@@ -272,6 +281,7 @@ class Plan:
                            out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
                            res=res.buf if res is not None else None, stats=y.stats, relu_in=relu_in, relu_out=relu_out, T=spec.T)
         self.fwd_ops.append((L.lib.awr_conv_gemm, (C.byref(a), None), "awr_conv_gemm:" + layer.name))
+        self._gemm_structs.append((L.lib.awr_conv_gemm, a, "awr_conv_gemm:" + layer.name))
         self.macs["awr_conv_gemm:" + layer.name] = self._gemm_macs(prob, B, spec)
         self._keep.append(a)
         if self.training:
@@ -308,6 +318,7 @@ class Plan:
         wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
         self._keep.append(wa)
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
+        self._gemm_structs.append((L.lib.awr_conv_wgrad, wa, "awr_conv_wgrad:" + layer.name))
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         if layer.batchable:        # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
             for name, args in layer.wgrad_unpack_calls(R, ld):
@@ -327,13 +338,16 @@ class Plan:
         # data gradient
         if x.needs_grad:
             dp = spec.dgrad_problem(H, W)
-            gx, acc = self._gtarget(x)
+            gx, acc = self._gtarget(x, "dgrad")
             if not dp["full"] and not acc:
                 self.bwd_ops.append((None, (gx,), "__zero__"))
                 acc = True
             da = make_conv_args(dp, B, dy, layer.p_dgrad, gx, res=gx if acc else None, T=spec.T)
             self._keep.append(da)
+            # remember who wrote d(x): a single full-coverage, non-accumulating dgrad can host the fused BN-backward reduction
+            self._grad_writers.setdefault(id(x), []).append(da if (dp["full"] and not acc) else None)
             self.bwd_ops.append((L.lib.awr_conv_gemm, (C.byref(da), None), "awr_conv_dgrad:" + layer.name))
+            self._gemm_structs.append((L.lib.awr_conv_gemm, da, "awr_conv_dgrad:" + layer.name))
             self.macs["awr_conv_dgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         if res is not None:
             self._contribute_identity(res, dy)
@@ -359,7 +373,8 @@ class Plan:
             own_stats = y.stats
         # several BNs may normalise the same tensor (hourglass): finalize zeroes the accumulator, so keep a copy
         y.stats = None
-        sc, sh, mean, invstd = (self.alloc(C_) for _ in range(4))
+        coef4 = self.alloc(4, C_)            # [scale | shift | mean | invstd][C]: one buffer so fused consumers take one pointer
+        sc, sh, mean, invstd = coef4[0], coef4[1], coef4[2], coef4[3]
         mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
         self._f("awr_bn_finalize", L.ptr(own_stats), C_, y.npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom,
                 BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd))
@@ -370,19 +385,28 @@ class Plan:
             a = self.new(B, H, W, C_, name=bn.name + ".act")
             self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
                     y.npix, C_)
-        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh))
+        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh, coef4))
         return a
 
-    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd, sc, sh):
+    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd, sc, sh, coef4):
         da = a.grad
         assert da is not None, "no gradient reached %s" % a.name
         C_ = y.shape[3]
         sums = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
         coef = self.alloc(3, C_)
+        # Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a lazy BN+ReLU output read
+        # by a single conv), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g / sum g*xhat itself --
+        # the separate reduction pass over d(a) and y disappears and the apply pass needs no mask.
+        writers = self._grad_writers.get(id(a), [])
+        fused = (a.lazy is not None and relu and res is None and len(writers) == 1 and writers[0] is not None)
+        if fused:
+            ga = writers[0]
+            ga.bnr_y, ga.bnr_coef, ga.stats = L.ptr(y.buf), L.ptr(coef4), L.ptr(sums)
         # ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
         act = L.ptr(a.buf) if (relu and res is not None) else None
-        msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None) else (None, None)
-        self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums))
+        msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None and not fused) else (None, None)
+        if not fused:
+            self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums))
         gy, acc = self._gtarget(y) if y.needs_grad else (self.alloc(*y.shape), False)
         g_out, post_add = None, None
         if res is not None and res.needs_grad:
@@ -501,6 +525,50 @@ class Plan:
             for pos, ops in sorted(inserts, key=lambda t: -t[0]):
                 self.bwd_ops[pos:pos] = ops
         self._built_bwd = True
+
+    def autotune(self, reps=3):
+        """Pick the fastest workgroup tile (and split-K depth) for every GEMM launch of this static plan by timing the
+        candidates in place with HIP events.  Runs before the first real step: outputs are scratch at this point, and every
+        atomic accumulator the launches touched is re-zeroed afterwards.  Shapes never change, so this is a one-off cost of
+        a few hundred milliseconds per (network, batch) plan."""
+        s = L.stream()
+        self.refresh_weights()
+
+        def time_one(fn, a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            L.check(fn(C.byref(a), s), "autotune warm-up")
+            e0.record()
+            for _ in range(reps):
+                L.check(fn(C.byref(a), s), "autotune")
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+        for fn, a, name in self._gemm_structs:
+            if fn is L.lib.awr_conv_gemm:
+                cands = [(1, 1, 0), (2, 1, 0)] + ([(1, 2, 0), (2, 2, 0)] if a.N > 64 else [])
+            else:
+                cands = [(1, 1, 2048), (1, 1, 3072), (1, 1, 4096)]
+                if a.Cd > 64:
+                    cands += [(2, 1, 1536), (2, 1, 2048)]
+                if a.Cg > 64:
+                    cands += [(1, 2, 2048)]
+            best, best_t = None, 1e30
+            for tm, tn, tb in cands:
+                a.tile_m, a.tile_n = tm, tn
+                if tb:
+                    a.target_blocks = tb
+                t = time_one(fn, a)
+                if t < best_t:
+                    best, best_t = (tm, tn, tb), t
+            a.tile_m, a.tile_n = best[0], best[1]
+            if best[2]:
+                a.target_blocks = best[2]
+            self.tuned[name] = (best, round(best_t * 1e3, 1))
+        for t in self._zero_init:
+            t.zero_()
+        if self._scratch_buf is not None:
+            self._scratch_buf.zero_()
+        torch.cuda.synchronize()
 
     def refresh_weights(self):
         """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena: one batched launch for the

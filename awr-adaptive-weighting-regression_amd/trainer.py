@@ -52,7 +52,7 @@ class GradSync:
 
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
-                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4):
+                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -68,6 +68,7 @@ class TrainEngine:
         self.dp = world > 1 or (process_group is not None and os.environ.get("AWR_FORCE_DP") == "1")   # test hook: 1-rank group
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
                                  n_buckets=n_buckets if self.dp else 1)
+        self._tune_pending = bool(autotune) and not self.plan.tuned      # runs right after the first step (buffers then hold real data)
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
         self.jt_pred = torch.zeros(batch_size, self.J, 3, device=dev)
         self.stat = torch.zeros(batch_size, self.J, 2, device=dev)
@@ -156,6 +157,14 @@ class TrainEngine:
         self.step_count += 1
         self._optimizer()
         self.net.weights_changed()
+        if self._tune_pending:
+            # one-off: time the GEMM tile candidates in place.  The step above is complete (losses, predictions and the
+            # optimiser update are final); the activation / gradient buffers the tuner scribbles on are rebuilt by the next step
+            self._tune_pending = False
+            keep = (self.losses.clone(), self.jt_pred.clone())
+            self.plan.autotune()
+            self.losses.copy_(keep[0])
+            self.jt_pred.copy_(keep[1])
         return self.losses, self.jt_pred
 
     def set_lr(self, lr):
@@ -213,10 +222,11 @@ TrainEngine.load_optimizer_state_dict = lambda self, sd: _load_opt_into(self, sd
 class InferEngine:
     """test.py:67-86 without the per-sample host loop: img -> dense map -> joints, eval-mode BN."""
 
-    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=True):
+    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=True, autotune=True):
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
+        self._tune_pending = bool(autotune) and not self.plan.tuned
         self.J, self.F = net.J, img_size // 2
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)
         self.stage = net.nstage - 1
@@ -240,6 +250,11 @@ class InferEngine:
         else:
             self._core()
             self._warm += 1
+        if self._tune_pending:
+            self._tune_pending = False
+            keep = self.jt.clone()
+            self.plan.autotune()
+            self.jt.copy_(keep)
         return self.jt
 
 

@@ -149,12 +149,17 @@ typedef struct awr_conv_args {
     const float* res;       /* optional tensor added element-wise, same shape as out            */
     double* stats;          /* optional [AWR_STAT_SLOTS][2][N]: += sum and sum of squares of the stored
                                value (taken after bias/affine/res, before relu_out)              */
+    const float* bnr_y;     /* optional fused BatchNorm-backward reduction (data-gradient launches): the result v   */
+    const float* bnr_coef;  /* is d(loss)/d(relu(bn(y)));  with coef = [scale|shift|mean|invstd][N] the kernel stores */
+                            /* g = v * (y*scale+shift > 0) and accumulates sum g, sum g*(y-mean)*invstd into `stats` */
     int B, Hin, Win, Cin;
     int Hq, Wq;             /* per-phase output grid */
     int Hout, Wout, N;
     int so, si, T;
     int relu_in, relu_out;
     int nphase;
+    int tile_m, tile_n;     /* workgroup tile in units of 64 rows / 64 columns ({1,2} each); 0,0 = built-in heuristic.
+                               Static plans autotune this per launch (engine.Plan.autotune). */
     awr_phase ph[4];
 } awr_conv_args;
 
@@ -184,6 +189,8 @@ typedef struct awr_wgrad_args {
                                bias gradient -- it falls out of the slices the kernel stages anyway); zeroed by caller */
     int d_relu, g_relu;
     int B, Hd, Wd, Cd, Hg, Wg, Cg, sg, T, ld;
+    int tile_m, tile_n;     /* (cd, cg) tile in units of 64; 0,0 = heuristic */
+    int target_blocks;      /* split-K: aim for this many workgroups; 0 = heuristic */
     int8_t dy[16], dx[16];
 } awr_wgrad_args;
 int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);

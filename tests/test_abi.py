@@ -53,10 +53,10 @@ def test_argument_validation_without_gpu(lib):
 
 def test_struct_layout_matches_header(lib):
     import ctypes as C
-    # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 10 pointers + 15 ints + 4 phases
+    # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 12 pointers + 15 ints + 4 phases
     assert C.sizeof(lib.Phase) == 76
-    assert C.sizeof(lib.ConvArgs) == 10 * 8 + 15 * 4 + 4 * 76 + 4   # trailing pad to 8-byte alignment
-    assert C.sizeof(lib.WgradArgs) == 8 * 8 + 12 * 4 + 32
+    assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4   # trailing pad to 8-byte alignment
+    assert C.sizeof(lib.WgradArgs) == 8 * 8 + 15 * 4 + 32 + 4
 
 
 def test_product_path_fails_loudly_on_cpu_tensors(lib):
