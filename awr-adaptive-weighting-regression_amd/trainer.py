@@ -130,9 +130,6 @@ class TrainEngine:
             L.call("awr_sgd_step", L.ptr(net.flat_params()), L.ptr(net.flat_grads()), L.ptr(self.m), n, self.lr, self.momentum, self.wd,
                    self.step_count, scale, s)
 
-    def _allreduce(self):
-        self.sync.allreduce(self.net.flat_grads()[:self.net.n_active])
-
     def step(self, img, jt_uvd_gt):
         """One optimisation step on this rank's shard.  Returns (losses[coord,dense,total], jt_uvd_pred)
         as device tensors that are valid until the next step; nothing is synchronised."""
