@@ -52,7 +52,7 @@ class GradSync:
 
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
-                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True):
+                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True, wgrad_streams=2):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -68,6 +68,8 @@ class TrainEngine:
         self.dp = world > 1 or (process_group is not None and os.environ.get("AWR_FORCE_DP") == "1")   # test hook: 1-rank group
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
                                  n_buckets=n_buckets if self.dp else 1)
+        # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off)
+        self.plan.side_streams = [torch.cuda.Stream(device=dev) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
         self._tune_pending = bool(autotune) and not self.plan.tuned      # runs right after the first step (buffers then hold real data)
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
         self.jt_pred = torch.zeros(batch_size, self.J, 3, device=dev)
