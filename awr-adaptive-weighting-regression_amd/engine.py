@@ -531,12 +531,29 @@ class Plan:
                 self.bwd_ops[pos:pos] = ops
         self._built_bwd = True
 
-    def autotune(self, reps=3):
+    def autotune(self, reps=3, cache_key=None):
         """Pick the fastest workgroup tile (and split-K depth) for every GEMM launch of this static plan by timing the
-        candidates in place with HIP events.  Runs before the first real step: outputs are scratch at this point, and every
-        atomic accumulator the launches touched is re-zeroed afterwards.  Shapes never change, so this is a one-off cost of
-        a few hundred milliseconds per (network, batch) plan."""
+        candidates in place with HIP events.  Runs right after the first real step (buffers hold real data; the next step
+        rebuilds whatever the tuner scribbles on) and re-zeroes every atomic accumulator the launches touched.  Shapes never
+        change, so this is a one-off cost of a few hundred milliseconds per (network, batch) plan; with AWR_TUNE_CACHE=<file>
+        the choices are stored / reloaded so that a later process (e.g. a profiler run of the same command) skips the timing."""
+        import json
+        import os
         s = L.stream()
+        cache_file = os.environ.get("AWR_TUNE_CACHE")
+        if cache_file and cache_key and os.path.exists(cache_file):
+            try:
+                ent = json.load(open(cache_file)).get(cache_key)
+            except (OSError, ValueError):
+                ent = None
+            if ent and all(name in ent for _, _, name in self._gemm_structs):
+                for fn, a, name in self._gemm_structs:
+                    (tm, tn, tb), t = ent[name]
+                    a.tile_m, a.tile_n = tm, tn
+                    if tb:
+                        a.target_blocks = tb
+                    self.tuned[name] = ((tm, tn, tb), t)
+                return
         self.refresh_weights()
 
         def time_one(fn, a):
@@ -574,6 +591,16 @@ class Plan:
         if self._scratch_buf is not None:
             self._scratch_buf.zero_()
         torch.cuda.synchronize()
+        if cache_file and cache_key:
+            try:
+                allc = json.load(open(cache_file)) if os.path.exists(cache_file) else {}
+            except (OSError, ValueError):
+                allc = {}
+            allc[cache_key] = {k: [list(v[0]), v[1]] for k, v in self.tuned.items()}
+            try:
+                json.dump(allc, open(cache_file, "w"))
+            except OSError:
+                pass
 
     def refresh_weights(self):
         """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena: one batched launch for the

@@ -161,7 +161,7 @@ class TrainEngine:
             # optimiser update are final); the activation / gradient buffers the tuner scribbles on are rebuilt by the next step
             self._tune_pending = False
             keep = (self.losses.clone(), self.jt_pred.clone())
-            self.plan.autotune()
+            self.plan.autotune(cache_key="train/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
             self.losses.copy_(keep[0])
             self.jt_pred.copy_(keep[1])
         return self.losses, self.jt_pred
@@ -252,7 +252,7 @@ class InferEngine:
         if self._tune_pending:
             self._tune_pending = False
             keep = self.jt.clone()
-            self.plan.autotune()
+            self.plan.autotune(cache_key="infer/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
             self.jt.copy_(keep)
         return self.jt
 
