@@ -542,8 +542,30 @@ int awr_debug_gemm_variant(int v) {
     return AWR_OK;
 }
 
+static int conv_gemm_one(const awr_conv_args* a, void* stream);
+
+// Tensors above 4 GB (Hourglass stem-resolution maps at batch 128) exceed the 32-bit buffer offsets of the kernels: the
+// batch is processed in power-of-two chunks, each an independent launch on the same stream (images are independent rows
+// of the GEMM; the BatchNorm statistic atomics simply accumulate across chunks).
 int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a && a->in && a->w && a->out, "conv_gemm: null pointer");
+    const int64_t in_img = (int64_t)a->Hin * a->Win * a->Cin, out_img = (int64_t)a->Hout * a->Wout * a->N;
+    int nchunk = 1;
+    while ((in_img * (a->B / nchunk) * 4 >= (1LL << 32) || out_img * (a->B / nchunk) >= (1LL << 31)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    if (nchunk == 1) return conv_gemm_one(a, stream);
+    for (int c = 0; c < nchunk; ++c) {
+        awr_conv_args b = *a;
+        b.B = a->B / nchunk;
+        b.in = a->in + in_img * b.B * c;
+        b.out = a->out + out_img * b.B * c;
+        if (a->res) b.res = a->res + out_img * b.B * c;
+        if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
+        if (int e = conv_gemm_one(&b, stream)) return e;
+    }
+    return AWR_OK;
+}
+
+static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
     AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
@@ -589,8 +611,25 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     return check_launch("conv_gemm_kernel");
 }
 
+static int conv_wgrad_one(const awr_wgrad_args* a, void* stream);
+
 int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
+    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
+    int nchunk = 1;
+    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    if (nchunk == 1) return conv_wgrad_one(a, stream);
+    for (int c = 0; c < nchunk; ++c) {       // split-K over batch chunks: partial sums accumulate in R
+        awr_wgrad_args b = *a;
+        b.B = a->B / nchunk;
+        b.D = a->D + d_img * b.B * c;
+        b.G = a->G + g_img * b.B * c;
+        if (int e = conv_wgrad_one(&b, stream)) return e;
+    }
+    return AWR_OK;
+}
+
+static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
     AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),

@@ -16,7 +16,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, N_ALIGN
+from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -189,9 +189,8 @@ class Plan:
     def _gemm_macs(fwd_prob, B, spec):
         """ALGORITHMIC multiply-accumulates of one conv-like layer (logical channels, zero padding counted as
         work, the usual 2*MAC convention): forward, data-gradient and weight-gradient all cost the same."""
-        taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(len(fwd_prob["phases"]) if fwd_prob["so"] > 1 else 1)
-        if fwd_prob["so"] > 1:      # transposed conv: each output pixel sees k*k/so^2 taps
-            taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(fwd_prob["so"] ** 2)
+        # conv: every output pixel sees all k*k taps; transposed conv: k*k/so^2 of them
+        taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(fwd_prob["so"] ** 2)
         return B * fwd_prob["Hout"] * fwd_prob["Wout"] * spec.cout * taps_per_out * spec.cin
 
     # ---- allocation -----------------------------------------------------------------------------------

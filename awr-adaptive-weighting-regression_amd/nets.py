@@ -9,7 +9,6 @@ modules while a gradient all-reduce / fused Adam can treat the whole network as 
 implementation of the network anywhere in this package.
 """
 import math
-from collections import OrderedDict
 
 import torch
 import torch.nn as nn

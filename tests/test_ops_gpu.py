@@ -319,3 +319,24 @@ def test_pack_unpack_roundtrip(ops, L, dev):
     assert torch.equal(g.cpu(), w)
     wpt = ops.pack_weight(w.to(dev), spec.dgrad_pack())
     assert torch.equal(wpt[:64, :, :96].cpu(), w.view(96, 64, 9).permute(1, 2, 0).contiguous())
+
+
+def test_batch_chunking_above_4gb(ops, dev):
+    """Tensors >= 4 GiB (Hourglass 128-channel maps at 256x256, batch 128: BASELINE config 5) exceed the kernels' 32-bit
+    buffer offsets; the entry points split the batch.  Property: the chunked call equals per-half calls bit for bit,
+    for the forward GEMM (4 GiB input) and, to rounding, for the weight gradient (4 GiB gathered operand)."""
+    B, H, cin, cout = 128, 256, 128, 64
+    spec = ops.ConvSpec("conv", cin, cout, 1, 1, 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.rand(B, H, H, cin, device=dev, generator=g) - 0.5
+    assert x.numel() * 4 >= (1 << 32)
+    w = (torch.rand(cout, cin, 1, 1, device=dev, generator=g) - 0.5) * 0.2
+    wp = ops.pack_weight(w, spec.fwd_pack())
+    y = ops.conv_forward(spec, x, wp)
+    for lo, hi in ((0, 64), (64, 128)):
+        assert torch.equal(y[lo:hi], ops.conv_forward(spec, x[lo:hi].contiguous(), wp))
+    ref = torch.einsum("bhwc,oc->bhwo", x[100, 17:19].unsqueeze(0).double(), w.view(cout, cin).double())
+    assert rel_err(y[100, 17:19].unsqueeze(0).cpu(), ref.cpu()) < 2e-6
+    gw = ops.conv_wgrad(spec, x, y)
+    gw2 = ops.conv_wgrad(spec, x[:64].contiguous(), y[:64].contiguous()) + ops.conv_wgrad(spec, x[64:].contiguous(), y[64:].contiguous())
+    assert rel_err(gw.cpu(), gw2.cpu()) < 1e-4

@@ -67,9 +67,36 @@ def run_wgrad(spec, B, H, tile=None):
     return t, 2 * macs / t / 1e12
 
 
+def run_split(spec, B, H, tile_a, tile_b):
+    """Two half-batch launches of the same layer with DIFFERENT tiles on two streams vs one full launch."""
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, H, H, spec.cin_pad, device=dev)
+    wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == "conv" else (spec.cin, spec.cout, spec.k, spec.k)
+    w = torch.randn(*wshape, device=dev) * 0.05
+    wp = ops.pack_weight(w, spec.fwd_pack())
+    prob = spec.fwd_problem(H, H)
+    out = torch.empty(B, prob["Hout"], prob["Wout"], prob["N"], device=dev)
+    hb = B // 2
+    a0 = ops.make_conv_args(prob, hb, x[:hb], wp, out[:hb], T=spec.T)
+    a1 = ops.make_conv_args(prob, B - hb, x[hb:], wp, out[hb:], T=spec.T)
+    a0.tile_m, a0.tile_n = tile_a
+    a1.tile_m, a1.tile_n = tile_b
+    side = torch.cuda.Stream()
+
+    def fn():
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        L.check(L.lib.awr_conv_gemm(C.byref(a0), main.cuda_stream))
+        L.check(L.lib.awr_conv_gemm(C.byref(a1), side.cuda_stream))
+        main.wait_stream(side)
+    t = timeit(fn)
+    macs = B * prob["Hout"] * prob["Wout"] * spec.cout * spec.cin * (spec.T if spec.kind == "conv" else spec.T / 4)
+    return t, 2 * macs / t / 1e12
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -83,6 +110,20 @@ def main():
             (n0, t0), (n1, t1) = pts[-2], pts[-1]
             b = (t1 - t0) / (n1 - n0)
             print("   -> per-slice %.2f us, fixed %.1f us  (= %.1f slices)" % (b * 1e6, (t1 - b * n1) * 1e6, (t1 - b * n1) / b))
+    elif args.mode == "split":
+        B = args.batch
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32)]
+        for name, spec, H in shapes:
+            t, tf = run_fwd(spec, B, H)
+            res = ["full(auto) %.0fus %.0fTF" % (t * 1e6, tf)]
+            tiles = [(1, 1), (2, 1)] + ([(1, 2), (2, 2)] if spec.cout > 64 else [])
+            for ta in tiles:
+                for tb in tiles:
+                    if ta <= tb:
+                        t2, tf2 = run_split(spec, B, H, ta, tb)
+                        res.append("%s|%s %.0fTF" % (ta, tb, tf2))
+            print("%-26s %s" % (name, "  ".join(res)))
     else:
         B = args.batch
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
