@@ -117,7 +117,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("AWR_FORCE_DP") == "1":      # AWR_FORCE_DP: exercise the data-parallel path on a 1-rank group (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = torch.distributed.group.WORLD
@@ -145,6 +145,18 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         macs = sum(v for k, v in inf.plan.macs.items())
+        if args.per_layer:
+            tm = KernelTimer()
+            inf.plan.timer = tm
+            inf.use_graph, inf.graph = False, None
+            for _ in range(5):
+                inf(imgs)
+            torch.cuda.synchronize()
+            inf.plan.timer = None
+            with open(args.per_layer, "w") as f:
+                f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
+                for n, (sec, c) in sorted(tm.collect().items(), key=lambda kv: -kv[1][0]):
+                    f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / sec))
         print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": round(args.batch * args.steps / el, 2), "unit": "images/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
                           "dtype": "f32", "data": "synthetic", "config": {"workload": "%s eval forward + head, batch %d" % (args.net, args.batch),
@@ -158,7 +170,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
 
     for _ in range(max(args.warmup, 3 if args.graph else 0)):
@@ -177,7 +189,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     eng.plan.timer = None
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -255,7 +267,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.net, ks, args.batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -1,0 +1,44 @@
+"""GPU: bench.py honours the driver's contract -- one JSON line with the required fields, also when launched
+through torch.distributed.run (the N > 1 launch form) with the data-parallel code path forced on a 1-rank group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_process_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"], cwd=REPO,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["algorithmic_gflop_per_image"] - 22.603) < 0.01                      # 22.60 GFLOP / image
+    assert d["joint_err_mm_vs_oracle"]["mean"] < 1e-3                                 # north_star: 1e-3 mm mean
+
+
+def test_bench_under_torchrun_with_forced_dp_path():
+    env = dict(os.environ, AWR_FORCE_DP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp1" and d["value"] > 0
