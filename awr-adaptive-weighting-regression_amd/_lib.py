@@ -19,6 +19,9 @@ class AwrError(RuntimeError):
 
 
 def _load():
+    probe = os.environ.get("AWR_LIB_PATH")      # kernel-study builds (tools/probe_gemm.sh); never set in production
+    if probe:
+        return C.CDLL(probe)
     if not os.path.exists(_build.LIB):
         if os.environ.get("AWR_AUTO_BUILD", "0") == "1":
             _build.build_lib(verbose=False)

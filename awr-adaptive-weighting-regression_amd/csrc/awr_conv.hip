@@ -192,24 +192,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     store_slice(0);
     if constexpr (!DB) {
         __syncthreads();
+#ifndef AWR_PROBE
+#define AWR_PROBE 0      // bottleneck probes (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores / 2nd barrier,
+#endif                   // 3 = both, 4 = both + no LDS fragment reads (MFMA only).  Results are wrong by construction; never shipped.
         for (int ks = 0; ks < ksteps; ++ks) {
             const bool more = ks + 1 < ksteps;
             if (more) {
                 advance();
-                load_slice(c0);        // global loads in flight while the MFMAs below run
+                if (AWR_PROBE != 1 && AWR_PROBE < 3) load_slice(c0);        // global loads in flight while the MFMAs below run
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float4 fa[TM], fb[TN];
+                if (AWR_PROBE < 4 || ks == 0) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
+                    for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
+                    for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = make_float4(1.f + ks, 2.f, 3.f, 4.f);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = make_float4(1.f, 2.f + ks, 3.f, 4.f);
+                }
                 mfma_group(fa, fb);
             }
-            __syncthreads();
-            if (more) {
-                store_slice(0);
+            if (AWR_PROBE < 2) {
+                __syncthreads();
+                if (more) {
+                    store_slice(0);
+                    __syncthreads();
+                }
+            } else if (AWR_PROBE < 4) {
                 __syncthreads();
             }
         }

@@ -96,7 +96,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -110,6 +110,17 @@ def main():
             (n0, t0), (n1, t1) = pts[-2], pts[-1]
             b = (t1 - t0) / (n1 - n0)
             print("   -> per-slice %.2f us, fixed %.1f us  (= %.1f slices)" % (b * 1e6, (t1 - b * n1) * 1e6, (t1 - b * n1) / b))
+    elif args.mode == "tiles":       # forward only, every tile, a few representative layers (used by tools/probe_gemm.sh)
+        B = args.batch
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16),
+                  ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32)]
+        for name, spec, H in shapes:
+            res = []
+            for tile in ((1, 1), (2, 1), (1, 2), (2, 2)):
+                if spec.cout <= 64 and tile[1] == 2:
+                    continue
+                res.append("%s %.0fTF" % (tile, run_fwd(spec, B, H, tile)[1]))
+            print("%-26s %s" % (name, "  ".join(res)))
     elif args.mode == "split":
         B = args.batch
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
