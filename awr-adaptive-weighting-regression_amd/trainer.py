@@ -59,7 +59,7 @@ class TrainEngine:
         self.ks, self.cw, self.dw = float(kernel_size), float(coord_weight), float(dense_weight)
         self.lr, self.wd, self.opt, self.momentum = float(lr), float(weight_decay), optimizer, float(momentum)
         self.J = net.J
-        self.F = img_size // 2
+        self.F = img_size // getattr(net, "downsample", 2)      # train.py:110: ft_sz = img_size / downsample
         dev = net.device
         self.stage = net.nstage - 1
         net.train()
@@ -226,7 +226,7 @@ class InferEngine:
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
         self._tune_pending = bool(autotune) and not self.plan.tuned
-        self.J, self.F = net.J, img_size // 2
+        self.J, self.F = net.J, img_size // getattr(net, "downsample", 2)
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)
         self.stage = net.nstage - 1
         self.use_graph, self.graph, self._warm = use_graph, None, 0

@@ -377,3 +377,29 @@ def test_wgrad_side_streams_do_not_change_the_step(amd, dev, net):
     d = (res[0][1] - res[1][1]).double().norm() / res[0][1].double().norm()
     assert float(d) < 1e-3, float(d)
     assert abs(res[0][0] - res[1][0]) <= 3e-2 * abs(res[0][0])       # after 3 Adam steps (chaotic amplification of rounding)
+
+
+@pytest.mark.parametrize("ds", [1, 4])
+def test_resnet_other_downsample_rates(amd, dev, ds):
+    """config.downsample in [1,2,4] (config.py:31): 4 - log2(ds) deconv stages; forward + one fused train step vs the oracle."""
+    from awr_amd.trainer import TrainEngine
+    J, B = 14, 2
+    img, jt_gt = O.synth_batch(B, 128, J, seed=91)
+    man = O.resnet18_manifest(J, ds)
+    sd = O.procedural_state(man, seed=9)
+    m = amd.get_deconv_net(18, J, ds)
+    assert [k for k in m.state_dict()] == [k for k, _, _ in man]
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(img.to(dev)).cpu()
+        ref = O.resnet18_forward(O.procedural_state(man, seed=9), img, False, ds)
+    assert out.shape == ref.shape == (B, 4 * J, 128 // ds, 128 // ds)
+    assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    eng = TrainEngine(m, B, 128, 1.0, coord_weight=1.0, use_graph=False, autotune=False)
+    losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+    F = 128 // ds
+    sdo = O.procedural_state(man, seed=9)
+    pred = O.resnet18_forward(sdo, img, True, ds)
+    lref = O.huber(O.offset2joint_softmax(pred, img, 1.0), jt_gt) + O.huber(pred, O.joint2offset(jt_gt, img, 1.0, F))
+    assert abs(float(losses[2]) - float(lref)) <= 3e-4 * abs(float(lref))
