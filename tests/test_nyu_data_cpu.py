@@ -1,0 +1,85 @@
+"""CPU: the cv2-free NYU test-time pipeline.  Helpers against the reference-generated vectors
+(tests/golden/loader_fns.npz); the dataset object end to end on a synthetic NYU-layout directory."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def ND():
+    import awr_amd  # noqa: F401
+    from awr_amd import nyu_data
+    return nyu_data
+
+
+def test_helpers_match_reference_vectors(ND, golden_dir):
+    g = np.load(os.path.join(golden_dir, "loader_fns.npz"))
+    rng = np.random.RandomState(int(g["seed"]))
+    centers_xyz = np.stack([rng.uniform(-200, 200, 6), rng.uniform(-150, 150, 6), rng.uniform(500, 1100, 6)], 1)
+    assert np.allclose(centers_xyz, g["centers_xyz"])
+    cube = np.array([300.0, 300.0, 300.0])
+    depth = rng.uniform(400, 1300, (480, 640)).astype(np.float32)
+    depth[rng.rand(480, 640) < 0.3] = 0
+    for i, c in enumerate(centers_xyz):
+        cuvd = ND.xyz2uvd(c, ND.PARAS, -1).astype(np.float64)
+        np.testing.assert_allclose(cuvd, g["center_uvd"][i], rtol=0, atol=1e-4)
+        b = ND.center2bounds(cuvd, cube)
+        assert list(b[:4]) == [int(v) for v in g["bounds"][i][:4]]
+        cr = ND.bounds2crop(depth.copy(), *b)
+        assert list(cr.shape) == list(g["crop_shape"][i])
+        np.testing.assert_array_equal(ND.center2transmat(cuvd, cube, np.array([128, 128])), g["M"][i])
+        small = cr[:96, :96].astype(np.float32).copy()
+        np.testing.assert_array_equal(ND.normalize(small.max(), small.copy(), c, cube), g["norm"][i])
+        rng.uniform(100, 500, (14, 3))          # keep the stream aligned with the generator
+
+
+def test_resize_nearest_follows_opencv_index_rule(ND):
+    img = np.arange(7 * 5, dtype=np.float32).reshape(7, 5)
+    out = ND.resize_nearest(img, (10, 14))                      # (w, h)
+    assert out.shape == (14, 10)
+    assert out[0, 0] == img[0, 0] and out[13, 9] == img[6, 4] and out[2, 3] == img[1, 1]     # floor(dst * src/dst)
+    assert np.array_equal(ND.resize_nearest(img, (5, 7)), img)
+
+
+def _write_fake_nyu(root, n, rng):
+    from PIL import Image
+    import scipy.io as sio
+    os.makedirs(os.path.join(root, "test"))
+    centers, xyz_all = [], np.zeros((1, n, 36, 3))
+    for i in range(n):
+        c = np.array([rng.uniform(-80, 80), rng.uniform(-60, 60), rng.uniform(650, 850)])
+        depth = np.full((480, 640), 1500.0)
+        uvd = np.array([588.03 * c[0] / c[2] + 320.0, -587.07 * c[1] / c[2] + 240.0])      # xyz2uvd with flip = -1
+        yy, xx = np.mgrid[0:480, 0:640]
+        hand = (xx - uvd[0]) ** 2 + (yy - uvd[1]) ** 2 < 55 ** 2
+        depth[hand] = c[2] + 0.2 * (xx[hand] - uvd[0])
+        d = depth.astype(np.int64)
+        rgb = np.stack([np.zeros_like(d), d // 256, d % 256], -1).astype(np.uint8)           # depth = G*256 + B
+        Image.fromarray(rgb).save(os.path.join(root, "test", "depth_1_%07d.png" % (i + 1)))
+        centers.append(c)
+        xyz_all[0, i] = c + rng.uniform(-60, 60, (36, 3))
+    sio.savemat(os.path.join(root, "test", "joint_data.mat"), {"joint_xyz": xyz_all, "joint_uvd": np.zeros((1, n, 36, 3))})
+    np.savetxt(os.path.join(root, "center_test_refined.txt"), np.array(centers))
+    return np.array(centers), xyz_all[0]
+
+
+def test_dataset_end_to_end_on_synthetic_directory(ND, tmp_path):
+    rng = np.random.RandomState(3)
+    centers, xyz = _write_fake_nyu(str(tmp_path), 4, rng)
+    data = ND.NYU(str(tmp_path), "test", img_size=128)
+    assert len(data) == 4
+    img, jt_xyz, jt_uvd, center_xyz, M, cube = data[1]
+    assert img.shape == (1, 128, 128) and img.dtype == torch.float32 and jt_xyz.shape == (14, 3) and M.shape == (3, 3)
+    assert float(img.max()) == 1.0 and float(img.min()) >= -1.0                     # background exactly at the far plane
+    fg = (img < 0.99).float().mean()
+    assert 0.05 < float(fg) < 0.9                                                    # the hand disk is inside the crop
+    np.testing.assert_allclose(center_xyz.numpy(), centers[1], rtol=1e-6)
+    sel = xyz[1][ND.JOINT][ND.EVAL]
+    np.testing.assert_allclose(jt_xyz.numpy(), (sel - centers[1]) / 150.0, atol=1e-5)
+    # labels are consistent with the evaluator's inverse chain (eval_tool.py:38-46): uvd -> xyz recovers the ground truth
+    from awr_amd.evaluator import EvalUtil
+    ev = EvalUtil(128, ND.PARAS, -1, 14)
+    ev.feed(jt_uvd.numpy(), jt_xyz.numpy(), center_xyz.numpy(), M.numpy(), cube.numpy())
+    assert ev.get_measures()[0] < 0.05                                               # mm

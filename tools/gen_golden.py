@@ -258,6 +258,41 @@ def main():
                         mpe=np.float64(mpe), med=np.float64(med), auc=np.float64(auc), pck=pck,
                         uvd=np.array(ev.jt_uvd_pred, dtype=np.float32))
 
+    # ---- f2 loader helpers that need no cv2 (dataloader/loader.py:88-101, :181-260) -----------------------------
+    print("[loader helpers f2]")
+    from dataloader.loader import Loader
+    from util.util import xyz2uvd as ref_xyz2uvd
+    sys.path.insert(0, REPO)
+    import awr_amd  # noqa: F401
+    from awr_amd import nyu_data as ND
+    ld = Loader.__new__(Loader)
+    ld.paras, ld.flip, ld.img_size = np.array(ND.PARAS), -1, 128
+    rng = np.random.RandomState(7)
+    out = {}
+    centers_xyz = np.stack([rng.uniform(-200, 200, 6), rng.uniform(-150, 150, 6), rng.uniform(500, 1100, 6)], 1)
+    cube = np.array([300.0, 300.0, 300.0])
+    depth = rng.uniform(400, 1300, (480, 640)).astype(np.float32)
+    depth[rng.rand(480, 640) < 0.3] = 0
+    b_ref, m_ref, c_ref, n_ref, j_ref, u_ref = [], [], [], [], [], []
+    for c in centers_xyz:
+        cuvd = ref_xyz2uvd(c, ld.paras, ld.flip).astype(np.float64)
+        check("xyz2uvd", ND.xyz2uvd(c, ND.PARAS, -1), ref_xyz2uvd(c, ld.paras, ld.flip), 1e-4)
+        b = ld.center2bounds(cuvd, cube)
+        assert ND.center2bounds(cuvd, cube)[:4] == b[:4]
+        check("center2bounds z", np.array(ND.center2bounds(cuvd, cube)[4:]), np.array(b[4:]), 1e-9)
+        cr = ld.bounds2crop(depth.copy(), *b)
+        check("bounds2crop", ND.bounds2crop(depth.copy(), *b), cr, 0.0)
+        M = ld.center2transmat(cuvd, cube, np.array([128, 128]))
+        check("center2transmat", ND.center2transmat(cuvd, cube, np.array([128, 128])), M, 0.0)
+        small = cr[:96, :96].astype(np.float32).copy()
+        nr = ld.normalize(small.max(), small.copy(), c, cube)
+        check("normalize", ND.normalize(small.max(), small.copy(), c, cube), nr, 0.0)
+        jt = rng.uniform(100, 500, (14, 3))
+        check("transform_jt_uvd", ND.transform_jt_uvd(jt, M), ld.transform_jt_uvd(jt, M), 1e-4)
+        u_ref.append(cuvd); b_ref.append(np.array(b)); m_ref.append(M); c_ref.append(cr.shape); n_ref.append(nr); j_ref.append(ld.transform_jt_uvd(jt, M))
+    np.savez_compressed(os.path.join(GOLD, "loader_fns.npz"), centers_xyz=centers_xyz, center_uvd=np.array(u_ref), bounds=np.array(b_ref),
+                        M=np.array(m_ref), crop_shape=np.array(c_ref), norm=np.array(n_ref), seed=7)
+
     json.dump(report, open(os.path.join(GOLD, "pin_report.json"), "w"), indent=1)
     print("golden vectors written to", GOLD)
     os.system("du -sh %s" % GOLD)
