@@ -131,7 +131,7 @@ int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t
  * transposed conv k4 s2 p1     : so=2, si=1, four phases (py,px), taps with (py+p-ky) even,
  *                                dy=(py+p-ky)/2 (likewise x), wt=ky*k+kx
  * Tensors must stay below 4 GB (the kernels use 32-bit buffer offsets with hardware bounds checking).
- * Built by the host (see awr_conv_geom_* helpers in the Python/C++ host code). */
+ * Built by the host (awr-adaptive-weighting-regression_amd/ops.py: ConvSpec.fwd_problem / dgrad_problem / wgrad_problem). */
 typedef struct awr_phase {
     int py, px, ntaps;
     int32_t tap[16];   /* (dy & 0xff) | (dx & 0xff) << 8 | wt << 16 : one scalar load per K-slice */

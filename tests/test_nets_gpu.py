@@ -403,3 +403,28 @@ def test_resnet_other_downsample_rates(amd, dev, ds):
     pred = O.resnet18_forward(sdo, img, True, ds)
     lref = O.huber(O.offset2joint_softmax(pred, img, 1.0), jt_gt) + O.huber(pred, O.joint2offset(jt_gt, img, 1.0, F))
     assert abs(float(losses[2]) - float(lref)) <= 3e-4 * abs(float(lref))
+
+
+@pytest.mark.parametrize("optimizer,wd", [("sgd", 0.0), ("adam", 1e-2), ("sgd", 1e-2)])
+def test_train_engine_optimizer_variants_vs_torch(amd, dev, optimizer, wd):
+    """train.py:66-69: Adam(lr, weight_decay) / SGD(lr, momentum=0.9, weight_decay).  The engine's flat-arena optimiser
+    kernels must move the parameters like the stock torch optimiser does when it is fed the engine's own gradients."""
+    from awr_amd.trainer import TrainEngine
+    J = 14
+    img, jt_gt = O.synth_batch(2, 128, J, seed=95)
+    man = O.manifest_for("resnet_18", J)
+    m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=9))
+    eng = TrainEngine(m, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, weight_decay=wd, optimizer=optimizer, use_graph=False, autotune=False)
+    shadow = torch.nn.Parameter(m.flat_params()[:m.n_active].clone())
+    opt = (torch.optim.Adam([shadow], lr=1e-3, weight_decay=wd) if optimizer == "adam"
+           else torch.optim.SGD([shadow], lr=1e-3, momentum=0.9, weight_decay=wd))
+    for _ in range(3):
+        before = m.flat_params()[:m.n_active].clone()
+        eng.step(img.to(dev), jt_gt.to(dev))
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            shadow.copy_(before)                      # same starting point, same gradient: compare one update at a time
+        shadow.grad = m.flat_grads()[:m.n_active].clone()
+        opt.step()
+        d = (m.flat_params()[:m.n_active] - shadow.detach()).abs().max()
+        assert float(d) <= 2e-6, (optimizer, wd, float(d))
