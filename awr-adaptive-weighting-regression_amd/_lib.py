@@ -48,11 +48,11 @@ class ConvArgs(C.Structure):
                 ("Hout", C.c_int), ("Wout", C.c_int), ("N", C.c_int),
                 ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
                 ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int), ("tile_m", C.c_int), ("tile_n", C.c_int),
-                ("ph", Phase * 4)]
+                ("ph", Phase * 4), ("w_split", C.c_void_p)]
 
 
 class PackJob(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("transpose", C.c_int),
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("split", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("transpose", C.c_int),
                 ("rows", C.c_int), ("ld", C.c_int), ("first", C.c_int64)]
 
 
@@ -98,7 +98,9 @@ _SIGS = {
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),
-    "awr_debug_gemm_variant": ([_I], C.c_int),
+    "awr_set_gemm_products": ([_I], C.c_int),
+    "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
+    "awr_get_gemm_products": ([], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P], C.c_int),
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),

@@ -20,6 +20,8 @@
 //   * XCD-aware workgroup remap: consecutive tiles of one row-panel land on the same XCD's L2.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "awr_common.h"
 
 namespace awr {
@@ -57,218 +59,100 @@ __device__ __forceinline__ float4 affine_relu(float4 v, float4 sc, float4 sh, in
 }
 
 // ------------------------------------------------------------------------------------------
-// out[pix(m), n] = sum_{tap, c} in[gather(m, tap), c] * w[n][wt(tap)][c]
+// Split-operand mode (NP = 6 or 9): exact fp32 products on the 16x faster bf16 matrix pipe.
 // ------------------------------------------------------------------------------------------
-// DB = true: double-buffered LDS + explicit fragment prefetch: ONE barrier per K-slice, and every LDS / global access of
-// a wave is issued in the shadow of its own MFMAs (the staging registers of slice k+1 are written to the other LDS buffer
-// at the start of slice k, the loads of slice k+2 follow immediately, the fragments of sub-step s+1 are read while the
-// MFMAs of sub-step s run).
-template <int TM, int TN, bool DB, bool PRIO>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
-    constexpr int NBUF = DB ? 2 : 1;
-    // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
-    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 configuration)
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDK];
-    float* const As = smem;
-    float* const Bs = smem + NBUF * BM * LDK;
+// Every fp32 value is cut into three bf16 pieces by truncation: h = top 8 significand bits, m = the next 8, l = the last 8,
+// x == h + m + l EXACTLY (both subtractions are exact in fp32).  A product x*y is then the sum of nine bf16 x bf16 products,
+// each of which the matrix pipe forms exactly and accumulates in fp32: NP = 9 issues all nine (the fp32 product is
+// reproduced exactly, the only rounding left is the fp32 accumulation every fp32 GEMM has); NP = 6 drops m*l, l*m, l*l
+// (relative weight <= 2^-23 of the product).  9 x 32 cycles (v_mfma_f32_32x32x16_bf16 covers 16 k) replace 8 x 64 cycles of
+// v_mfma_f32_32x32x2_f32: 1.8x (NP = 9) / 2.7x (NP = 6) the FP32-MFMA rate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDR = 3 * BK * 2 + 16;   // LDS row in split mode (bytes): [h | m | l] x 32 bf16 + 16 pad = 208 -> conflict-free b128 reads
 
-    const awr_phase& ph = a.ph[blockIdx.y];
-    const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = (a.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
-    const int r0 = tid >> 3;            // first row it stages (then +32, +64, ...)
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));      // <= 8 significant bits: its low half-word is already zero
+}
+// upper half-words of two fp32 bit patterns -> one dword holding two bf16 (lo = a, hi = b)
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-    // decode the A rows this thread stages (fixed for the whole K loop); byte offsets are 32-bit (tensors < 4 GB)
-    int a_iy[RA], a_ix[RA];
-    unsigned a_img[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = tile_m * BM + r0 + 32 * i;
-        if (m < M) {
-            const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
-            a_iy[i] = qy * a.si;
-            a_ix[i] = qx * a.si;
-            a_img[i] = (unsigned)b * a.Hin * a.Win;
-        } else {
-            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
-            a_ix[i] = 0;
-            a_img[i] = 0;
-        }
+// four consecutive k of one LDS row: three 8-byte stores (h, m, l planes)
+#ifndef AWR_PROBE
+#define AWR_PROBE 0      // bottleneck probes (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores / 2nd barrier,
+#endif                   // 3 = both, 4 = both + no LDS fragment reads (MFMA only); split mode: 6 = activation split free.
+                         // Results are wrong by construction; never shipped.
+__device__ __forceinline__ void store_split4(char* row_k, float4 v) {
+    if (AWR_PROBE == 6) {      // probe: the three stores without the split arithmetic
+        *reinterpret_cast<uint2*>(row_k) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+        *reinterpret_cast<uint2*>(row_k + 2 * BK) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+        *reinterpret_cast<uint2*>(row_k + 4 * BK) = make_uint2(__float_as_uint(v.y), __float_as_uint(v.z));
+        return;
     }
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, OOB);
-    unsigned w_off[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc) * 4u;
-
-    f32x16 acc[TM][TN];
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(row_k) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+    *reinterpret_cast<uint2*>(row_k + 2 * BK) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+    *reinterpret_cast<uint2*>(row_k + 4 * BK) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+}
+__device__ __forceinline__ bf16x8 ld_frag(const char* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    bf16x8 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+// the TM x TN accumulator tiles of one wave advance by 16 k: NP products per tile, tiles interleaved so that dependent
+// MFMAs on one accumulator are TM*TN issues apart
+template <int TM, int TN>
+__device__ __forceinline__ void load_split_frags(const char* a_frag, const char* b_frag, bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int s = 0; s < 3; ++s) fa[i][s] = ld_frag(a_frag + i * 32 * LDR + s * 2 * BK);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int cslices = a.Cin / BK;
-    const int ksteps = ph.ntaps * cslices;
-    float4 ra[RA], rb[RB];
-    unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
-    int c0_staged = 0;
-
-    // Per tap (every Cin/32 K-slices): bounds test + base byte offset of each staged row.  Per K-slice: one add
-    // per row.  Keeping the per-slice VALU work tiny matters: the two waves that share a SIMD's MFMA pipe drift
-    // into lock-step, so every VALU cycle spent between MFMA bursts is a cycle the matrix pipe idles.
-    unsigned a_off[RA], tapmask = 0, wtap = 0;
-    auto set_tap = [&](int tap) {
-        const int tp = ph.tap[tap];
-        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
-        tapmask = 0;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
-            tapmask |= ok ? (1u << i) : 0u;
-        }
-        wtap = (unsigned)wt * a.Cin * 4u;
-    };
-    // issue the global loads of one K-slice; nothing here waits for memory
-    auto load_slice = [&](int c0) {
-        const unsigned cb = (unsigned)c0 * 4u;
+        for (int s = 0; s < 3; ++s) fb[j][s] = ld_frag(b_frag + j * 32 * LDR + s * 2 * BK);
+}
+struct no_filler {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// One 16-k step of a wave's TM x TN accumulator tiles: NP product groups of TM*TN independent MFMAs.  `filler(q)` is VALU work
+// the caller wants issued in the shadow of group q; the scheduling fence after each group keeps the compiler from hoisting
+// all of it to the front (which costs its registers for the whole step and leaves the later MFMAs uncovered).
+template <int TM, int TN, int NP, class F = no_filler>
+__device__ __forceinline__ void mfma_split16(const bf16x8 (&fa)[TM][3], const bf16x8 (&fb)[TN][3], f32x16 (&acc)[TM][TN], F filler = F()) {
+    constexpr int PA[9] = {2, 0, 1, 1, 0, 0, 2, 1, 2}, PB[9] = {0, 2, 1, 0, 1, 0, 1, 2, 2};   // small terms first, then h*h; 6..8 = dropped at NP=6
+    constexpr int ORD6[9] = {0, 1, 2, 3, 4, 5, 5, 5, 5}, ORD9[9] = {8, 6, 7, 0, 1, 2, 3, 4, 5};
 #pragma unroll
-        for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+    for (int q = 0; q < NP; ++q) {
+        const int p = NP == 9 ? ORD9[q] : ORD6[q];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + (wtap + cb));
-        okmask = tapmask;
-        c0_staged = c0;
-    };
-    // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
-    auto store_slice = [&](int buf) {
-        if (a.in_scale) {
-            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
-        } else if (a.relu_in) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f); ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&As[buf * BM * LDK + (r0 + 32 * i) * LDK + kc], ra[i]);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&Bs[buf * BN * LDK + (r0 + 32 * i) * LDK + kc], rb[i]);
-    };
-
-    int tap = 0, c0 = 0;
-    const int half = lane >> 5, l31 = lane & 31;
-    const float* a_frag = &As[(wm * 32 * TM + l31) * LDK + 4 * half];
-    const float* b_frag = &Bs[(wn * 32 * TN + l31) * LDK + 4 * half];
-    auto advance = [&]() {
-        c0 += BK;
-        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
-    };
-    auto mfma_group = [&](const float4 (&fa)[TM], const float4 (&fb)[TN]) {
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);     // let MFMA-issuing waves win arbitration over staging waves
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    };
-
-    set_tap(0);
-    load_slice(0);
-    store_slice(0);
-    if constexpr (!DB) {
-        __syncthreads();
-#ifndef AWR_PROBE
-#define AWR_PROBE 0      // bottleneck probes (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores / 2nd barrier,
-#endif                   // 3 = both, 4 = both + no LDS fragment reads (MFMA only).  Results are wrong by construction; never shipped.
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const bool more = ks + 1 < ksteps;
-            if (more) {
-                advance();
-                if (AWR_PROBE != 1 && AWR_PROBE < 3) load_slice(c0);        // global loads in flight while the MFMAs below run
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float4 fa[TM], fb[TN];
-                if (AWR_PROBE < 4 || ks == 0) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = ld4(a_frag + i * 32 * LDK + 8 * s);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = ld4(b_frag + j * 32 * LDK + 8 * s);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = make_float4(1.f + ks, 2.f, 3.f, 4.f);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = make_float4(1.f, 2.f + ks, 3.f, 4.f);
-                }
-                mfma_group(fa, fb);
-            }
-            if (AWR_PROBE < 2) {
-                __syncthreads();
-                if (more) {
-                    store_slice(0);
-                    __syncthreads();
-                }
-            } else if (AWR_PROBE < 4) {
-                __syncthreads();
-            }
-        }
-    } else {
-        if (ksteps > 1) {
-            advance();
-            load_slice(c0);            // slice 1 travels while slice 0 is consumed
-        }
-        __syncthreads();
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int cur = ks & 1;
-            const float* af = a_frag + cur * BM * LDK;
-            const float* bf = b_frag + cur * BN * LDK;
-            float4 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = ld4(af + i * 32 * LDK);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = ld4(bf + j * 32 * LDK);
-            if (ks + 1 < ksteps) {
-                store_slice(cur ^ 1);  // staged one whole slice ago: no memory stall here
-                if (ks + 2 < ksteps) {
-                    advance();
-                    load_slice(c0);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = ld4(af + i * 32 * LDK + 8 * (s + 1));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = ld4(bf + j * 32 * LDK + 8 * (s + 1));
-                }
-                mfma_group(fa[s & 1], fb[s & 1]);
-            }
-            __syncthreads();
-        }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][j], 0, 0, 0);
+        filler(q);
+        if constexpr (!std::is_same<F, no_filler>::value) __builtin_amdgcn_sched_barrier(0);
     }
+}
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
-    // The MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) gives each lane ONE column: storing
-    // from it means 16 four-byte stores per tile per lane.  Each wave instead bounces its 32x32 tile through a private
-    // 32x36 LDS tile and leaves with float4 rows: 4 sixteen-byte stores per lane, every store instruction covering eight
-    // full 128-byte lines; bias / folded-BN affine / residual (also loaded as float4) / statistics / ReLU are applied on
-    // the way out.  (The single-K-slice layers -- im2col'd stem, 1x1 convs on the 128x128 maps -- are store-bound.)
+// ------------------------------------------------------------------------------------------
+// Epilogue shared by the f32 and the split-operand kernels.
+// ------------------------------------------------------------------------------------------
+// The MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) gives each lane ONE column: storing
+// from it means 16 four-byte stores per tile per lane.  Each wave instead bounces its 32x32 tile through a private
+// 32x36 LDS tile and leaves with float4 rows: 4 sixteen-byte stores per lane, every store instruction covering eight
+// full 128-byte lines; bias / folded-BN affine / residual (also loaded as float4) / statistics / ReLU are applied on
+// the way out.  (The single-K-slice layers -- im2col'd stem, 1x1 convs on the 128x128 maps -- are store-bound.)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
+                                              int tile_m, int tile_n) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
     const bool direct = (a.so == 1);   // out pixel index == m
     __syncthreads();                    // every wave is done with the staged slices
     float* tbuf = smem + wave * (32 * LDK);
@@ -375,6 +259,289 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[pix(m), n] = sum_{tap, c} in[gather(m, tap), c] * w[n][wt(tap)][c]
+// ------------------------------------------------------------------------------------------
+// NP = 0: operands stay fp32 in LDS, v_mfma_f32_32x32x2_f32.  NP = 6 / 9: split-operand mode (above).
+// AFF (split mode only): the fused input affine / ReLU is compiled in (two instantiations instead of a run-time branch around the
+// MFMA block: a branch there makes the register allocator keep both arms' accumulator copies alive).
+template <int TM, int TN, int NP, bool AFF>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
+    constexpr int ROWB = NP ? LDR : LDK * 4;    // LDS row pitch in bytes
+    // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
+    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 fp32 configuration)
+    __shared__ __attribute__((aligned(16))) char smem_raw[(BM + BN) * ROWB];
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+    char* const As = smem_raw;
+    char* const Bs = smem_raw + BM * ROWB;
+
+    const awr_phase& ph = a.ph[blockIdx.y];
+    const int M = a.B * a.Hq * a.Wq;
+    const int tilesN = (a.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
+    const int r0 = tid >> 3;            // first row it stages (then +32, +64, ...)
+
+    // decode the A rows this thread stages (fixed for the whole K loop); byte offsets are 32-bit (tensors < 4 GB)
+    int a_iy[RA], a_ix[RA];
+    unsigned a_img[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        if (m < M) {
+            const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+            a_iy[i] = qy * a.si;
+            a_ix[i] = qx * a.si;
+            a_img[i] = (unsigned)b * a.Hin * a.Win;
+        } else {
+            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
+            a_ix[i] = 0;
+            a_img[i] = 0;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, OOB);
+    unsigned w_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc) * 4u;
+    // split mode: the weight slice of a row is 192 contiguous bytes of the pre-split image = 12 sixteen-byte pieces that go
+    // to LDS verbatim (no arithmetic): piece q = tid + 256 i -> row q / 12, piece q % 12
+    constexpr int RB3 = NP ? 3 * TN : 1;
+    const __amdgpu_buffer_rsrc_t rs_w3 = make_rsrc(a.w_split, OOB);
+    unsigned w3_off[RB3], w3_lds[RB3];
+    if constexpr (NP != 0) {
+#pragma unroll
+        for (int i = 0; i < RB3; ++i) {
+            const int q = tid + 256 * i, row = q / 12, piece = q - 12 * row;
+            w3_off[i] = (unsigned)(tile_n * BN + row) * a.T * (a.Cin / BK) * (6u * BK) + 16u * piece;
+            w3_lds[i] = (unsigned)(row * ROWB + 16 * piece);
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cslices = a.Cin / BK;
+    const int ksteps = ph.ntaps * cslices;
+    float4 ra[RA], rb[NP ? RB3 : RB];
+    unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
+    int c0_staged = 0;
+
+    // Per tap (every Cin/32 K-slices): bounds test + base byte offset of each staged row.  Per K-slice: one add
+    // per row.  Keeping the per-slice VALU work tiny matters: the two waves that share a SIMD's MFMA pipe drift
+    // into lock-step, so every VALU cycle spent between MFMA bursts is a cycle the matrix pipe idles.
+    unsigned a_off[RA], tapmask = 0, wtap = 0;
+    auto set_tap = [&](int tap) {
+        const int tp = ph.tap[tap];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
+        tapmask = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
+            tapmask |= ok ? (1u << i) : 0u;
+        }
+        wtap = NP ? (unsigned)wt * (a.Cin / BK) * (6u * BK) : (unsigned)wt * a.Cin * 4u;
+    };
+    // issue the global loads of one K-slice; nothing here waits for memory
+    auto load_slice = [&](int c0) {
+        const unsigned cb = (unsigned)c0 * 4u;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + (wtap + cb));
+        } else {
+            const unsigned sb = wtap + (unsigned)(c0 / BK) * (6u * BK);
+#pragma unroll
+            for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
+        }
+        okmask = tapmask;
+        c0_staged = c0;
+    };
+    // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
+    auto store_slice = [&]() {
+        if (a.in_scale) {
+            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
+        } else if (a.relu_in) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f); ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+            }
+        }
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(As + (r0 + 32 * i) * ROWB) + kc, ra[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(Bs + (r0 + 32 * i) * ROWB) + kc, rb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) store_split4(As + (r0 + 32 * i) * ROWB + kc * 2, ra[i]);
+#pragma unroll
+            for (int i = 0; i < RB3; ++i) st4(reinterpret_cast<float*>(Bs + w3_lds[i]), rb[i]);
+        }
+    };
+
+    int tap = 0, c0 = 0;
+    const int half = lane >> 5, l31 = lane & 31;
+    // f32: lane reads 4 consecutive k (16 B) of its half-wave per 8-k sub-step; split: 8 consecutive bf16 k (16 B) per 16-k step
+    const char* a_frag = As + (wm * 32 * TM + l31) * ROWB + 16 * half;
+    const char* b_frag = Bs + (wn * 32 * TN + l31) * ROWB + 16 * half;
+    auto advance = [&]() {
+        c0 += BK;
+        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
+    };
+
+    set_tap(0);
+    if constexpr (NP == 0) {
+        load_slice(0);
+        store_slice();
+        __syncthreads();
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool more = ks + 1 < ksteps;
+            if (more) {
+                advance();
+                if (AWR_PROBE != 1 && AWR_PROBE < 3) load_slice(c0);        // global loads in flight while the MFMAs below run
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 fa[TM], fb[TN];
+                if (AWR_PROBE < 4 || ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_frag + i * 32 * ROWB) + 8 * s);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_frag + j * 32 * ROWB) + 8 * s);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = make_float4(1.f + ks, 2.f, 3.f, 4.f);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = make_float4(1.f, 2.f + ks, 3.f, 4.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+            }
+            if (AWR_PROBE < 2) {
+                __syncthreads();
+                if (more) {
+                    store_slice();
+                    __syncthreads();
+                }
+            } else if (AWR_PROBE < 4) {
+                __syncthreads();
+            }
+        }
+    } else {
+        // Split mode.  The bf16 MFMAs of a slice last about as long as cutting the next slice into its pieces, so that
+        // arithmetic has to run in the shadow of the MFMAs, not between them: the raw activation rows of slice k+1 are
+        // requested before the MFMAs of slice k start, have landed by the time the first half of those MFMAs has issued,
+        // and are cut into their pieces (fused affine + ReLU first) by VALU instructions that sit between the MFMAs of the
+        // second half in program order; what remains between the two barriers is 8- and 16-byte LDS stores.  Weight
+        // pieces need no arithmetic: they go registers -> LDS verbatim.
+        float4 r1[RA];
+        unsigned ok1 = 0;
+        int c1 = 0;
+        uint2 S[RA][3];
+        auto load_a = [&](float4 (&dst)[RA], int cc) {
+            const unsigned cb = (unsigned)cc * 4u;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) dst[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+        };
+        auto load_b = [&](int cc) {
+            const unsigned sb = wtap + (unsigned)(cc / BK) * (6u * BK);
+#pragma unroll
+            for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
+        };
+        const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();
+        // branch-free (it has to stay in the MFMAs' basic block): affine + ReLU on in-bounds rows, then the 3-way cut
+        auto split_rows = [&](const float4 (&src)[RA], unsigned okm, float4 sc, float4 sh, int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                float4 v = src[i];
+                if constexpr (AFF) {
+                    const bool ok = okm & (1u << i);
+                    v.x = ok ? fmaxf(v.x * sc.x + sh.x, relu_lo) : 0.f; v.y = ok ? fmaxf(v.y * sc.y + sh.y, relu_lo) : 0.f;
+                    v.z = ok ? fmaxf(v.z * sc.z + sh.z, relu_lo) : 0.f; v.w = ok ? fmaxf(v.w * sc.w + sh.w, relu_lo) : 0.f;
+                }
+                unsigned h[4], m[4], l[4];
+                split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+                S[i][0] = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+                S[i][1] = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+                S[i][2] = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+            }
+        };
+        auto coef = [&](int cc, float4& sc, float4& sh) {
+            sc = make_float4(1, 1, 1, 1); sh = make_float4(0, 0, 0, 0);
+            if (a.in_scale) { sc = ld4(a.in_scale + cc + kc); sh = ld4(a.in_shift + cc + kc); }
+        };
+        auto store_sb = [&]() {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                char* d = As + (r0 + 32 * i) * ROWB + kc * 2;
+                *reinterpret_cast<uint2*>(d) = S[i][0];
+                *reinterpret_cast<uint2*>(d + 2 * BK) = S[i][1];
+                *reinterpret_cast<uint2*>(d + 4 * BK) = S[i][2];
+            }
+#pragma unroll
+            for (int i = 0; i < RB3; ++i) st4(reinterpret_cast<float*>(Bs + w3_lds[i]), rb[i]);
+        };
+        float4 sc, sh;
+        load_a(r1, 0); ok1 = tapmask; c1 = 0;
+        load_b(0);
+        coef(0, sc, sh);
+        split_rows(r1, ok1, sc, sh, 0, RA);
+        store_sb();
+        __syncthreads();
+        // one basic block: fragment reads and MFMAs of the slice in LDS, the cut of the next slice inside the second half
+        auto multiply_and_cut = [&]() {
+            bf16x8 fa[TM][3], fb[TN][3];
+            load_split_frags<TM, TN>(a_frag, b_frag, fa, fb);
+            mfma_split16<TM, TN, NP>(fa, fb, acc);
+            load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_split16<TM, TN, NP>(fa, fb, acc, [&](int q) {
+                if (q < RA) split_rows(r1, ok1, sc, sh, q, q + 1);
+            });
+        };
+        for (int ks = 0; ks + 1 < ksteps; ++ks) {
+            advance();
+            load_a(r1, c0); ok1 = tapmask; c1 = c0;
+            load_b(c0);
+            coef(c1, sc, sh);
+            multiply_and_cut();
+            __syncthreads();
+            store_sb();
+            __syncthreads();
+        }
+        {   // last slice: nothing left to stage
+            bf16x8 fa[TM][3], fb[TN][3];
+            load_split_frags<TM, TN>(a_frag, b_frag, fa, fb);
+            mfma_split16<TM, TN, NP>(fa, fb, acc);
+            load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
+            mfma_split16<TM, TN, NP>(fa, fb, acc);
+        }
+    }
+    gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -535,11 +702,202 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient in split-operand mode (NP = 6 / 9).
+// ------------------------------------------------------------------------------------------
+// The contraction runs over pixels, so both MFMA operands need pixel-contiguous (k-contiguous) rows per channel, while HBM
+// holds channel-contiguous pixels: each thread owns a 4-pixel x 4-channel unit, loads its four float4 (a wave covers 8
+// pixel groups x 8 channel groups = eight full 128-byte lines per load instruction), transposes the 4x4 block in
+// registers (free: it is only a choice of which register feeds which store), cuts every value into its three bf16 pieces
+// and writes one 8-byte store per channel and piece.  Lane = pixel group + 8 x channel group keeps both the global loads
+// (128 B per pixel) and the LDS stores (64 contiguous bytes per 8 lanes, the other 8 lanes 16 banks away) conflict-free.
+// LDS image, fragment reads and MFMA schedule are the ones of the forward kernel (rows = channels).
+template <int TM, int TN, int NP>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int UD = 2 * BM, UG = 2 * BN;            // 4x4 units per 32-pixel slice of the D / G tile
+    constexpr int NU = (UD + UG + 255) / 256;          // unit slots per thread
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * LDR];
+    char* const Ds = smem;
+    char* const Gs = smem + BM * LDR;
+
+    const int M = a.B * a.Hd * a.Wd;
+    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
+    int wg = blockIdx.x;
+    const int tcg = wg % tiles_cg; wg /= tiles_cg;
+    const int tcd = wg % tiles_cd; wg /= tiles_cd;
+    const int t = wg;                                 // tap
+    const int dy = a.dy[t], dx = a.dx[t];
+    const int m_begin = blockIdx.y * chunk;
+    int m_end = m_begin + chunk;
+    if (m_end > M) m_end = M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // unit slots (the role of a slot is uniform per wave: the D/G boundary is a multiple of 128 threads)
+    int role[NU], upg[NU], uch[NU];
+    unsigned ucol[NU];
+    float4 usc[NU], ush[NU];
+    int urelu[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        int u = tid + 256 * i;
+        role[i] = u < UD ? 0 : (u < UD + UG ? 1 : 2);
+        if (role[i] == 1) u -= UD;
+        upg[i] = u & 7;
+        uch[i] = (u >> 3) * 4;
+        const int cbase = role[i] == 0 ? tcd * BM + uch[i] : tcg * BN + uch[i];
+        const bool cok = role[i] == 0 ? cbase < a.Cd : (role[i] == 1 && cbase < a.Cg);
+        ucol[i] = cok ? (unsigned)cbase * 4u : OOB;
+        usc[i] = make_float4(1, 1, 1, 1); ush[i] = make_float4(0, 0, 0, 0); urelu[i] = 0;
+        if (role[i] == 0 && a.d_scale && cok) { usc[i] = ld4(a.d_scale + cbase); ush[i] = ld4(a.d_shift + cbase); urelu[i] = a.d_relu; }
+        if (role[i] == 1 && a.g_scale && cok) { usc[i] = ld4(a.g_scale + cbase); ush[i] = ld4(a.g_shift + cbase); urelu[i] = a.g_relu; }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 raw[NU][4];
+    unsigned okm[NU];
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)M * a.Cd * 4u);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
+    const bool row4 = (a.Wd & 3) == 0;      // a unit's four pixels share an image row
+    auto g_offset = [&](int m, bool& ok) -> unsigned {
+        int x, y, b;
+        if (wshift >= 0) {
+            x = m & (a.Wd - 1);
+            const int tt = m >> wshift;
+            y = tt & (a.Hd - 1);
+            b = tt >> hshift;
+        } else {
+            x = m % a.Wd;
+            const int tt = m / a.Wd;
+            y = tt % a.Hd;
+            b = tt / a.Hd;
+        }
+        const int gy = y * a.sg + dy, gx = x * a.sg + dx;
+        ok = m < m_end && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
+        return (unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg * 4u;
+    };
+    auto load_slice = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            okm[i] = 0;
+            const int mb = m0 + 4 * upg[i];
+            if (role[i] == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = mb + q < m_end && ucol[i] != OOB;
+                    raw[i][q] = buf_ld4(rs_d, ok ? (unsigned)(mb + q) * a.Cd * 4u + ucol[i] : OOB);
+                    okm[i] |= ok ? (1u << q) : 0u;
+                }
+            } else if (role[i] == 1) {
+                if (row4) {
+                    bool ok0;
+                    const unsigned base = g_offset(mb, ok0);       // validity of the row; columns are tested per pixel below
+                    const int x0 = (wshift >= 0 ? (mb & (a.Wd - 1)) : mb % a.Wd) * a.sg + dx;
+                    int y; { const int tt = wshift >= 0 ? (mb >> wshift) : mb / a.Wd; y = (wshift >= 0 ? (tt & (a.Hd - 1)) : tt % a.Hd) * a.sg + dy; }
+                    const bool rowok = y >= 0 && y < a.Hg && ucol[i] != OOB;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gx = x0 + q * a.sg;
+                        const bool ok = rowok && mb + q < m_end && gx >= 0 && gx < a.Wg;
+                        raw[i][q] = buf_ld4(rs_g, ok ? base + (unsigned)(q * a.sg * a.Cg) * 4u + ucol[i] : OOB);
+                        okm[i] |= ok ? (1u << q) : 0u;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bool ok;
+                        const unsigned off = g_offset(mb + q, ok);
+                        ok = ok && ucol[i] != OOB;
+                        raw[i][q] = buf_ld4(rs_g, ok ? off + ucol[i] : OOB);
+                        okm[i] |= ok ? (1u << q) : 0u;
+                    }
+                }
+            }
+        }
+    };
+    const bool do_colsum = a.d_colsum != nullptr && t == 0 && tcg == 0;
+    float4 csum = make_float4(0, 0, 0, 0);
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            if (role[i] == 2) continue;
+            if (role[i] == 0 ? a.d_scale != nullptr : a.g_scale != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (okm[i] & (1u << q)) raw[i][q] = affine_relu(raw[i][q], usc[i], ush[i], urelu[i]);
+            }
+            if (role[i] == 0 && do_colsum) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { csum.x += raw[i][q].x; csum.y += raw[i][q].y; csum.z += raw[i][q].z; csum.w += raw[i][q].w; }
+            }
+            char* dst = (role[i] == 0 ? Ds : Gs) + uch[i] * LDR + 8 * upg[i];
+            store_split4(dst, make_float4(raw[i][0].x, raw[i][1].x, raw[i][2].x, raw[i][3].x));
+            store_split4(dst + LDR, make_float4(raw[i][0].y, raw[i][1].y, raw[i][2].y, raw[i][3].y));
+            store_split4(dst + 2 * LDR, make_float4(raw[i][0].z, raw[i][1].z, raw[i][2].z, raw[i][3].z));
+            store_split4(dst + 3 * LDR, make_float4(raw[i][0].w, raw[i][1].w, raw[i][2].w, raw[i][3].w));
+        }
+    };
+
+    load_slice(m_begin);
+    store_slice();
+    __syncthreads();
+    const char* a_frag = Ds + (wm * 32 * TM + l31) * LDR + 16 * half;
+    const char* b_frag = Gs + (wn * 32 * TN + l31) * LDR + 16 * half;
+    for (int m0 = m_begin; m0 < m_end; m0 += BK) {
+        const bool more = m0 + BK < m_end;
+        if (more) load_slice(m0 + BK);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[TM][3], fb[TN][3];
+            load_split_frags<TM, TN>(a_frag + 32 * s, b_frag + 32 * s, fa, fb);
+            mfma_split16<TM, TN, NP>(fa, fb, acc);
+        }
+        __syncthreads();
+        if (more) {
+            store_slice();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + t) * a.ld + cg, acc[i][j][r]);
+            }
+    }
+    if (do_colsum && role[0] == 0) {      // the 8 pixel-group lanes of a channel group hold partial sums of the same 4 channels
+#pragma unroll
+        for (int o = 1; o <= 4; o <<= 1) {
+            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+        }
+        if (upg[0] == 0 && ucol[0] != OOB) {
+            float* o = a.d_colsum + tcd * BM + uch[0];
+            atomicAdd(o + 0, csum.x); atomicAdd(o + 1, csum.y); atomicAdd(o + 2, csum.z); atomicAdd(o + 3, csum.w);
+        }
+    }
+}
+
 }  // namespace awr
 
 using namespace awr;
 
-static int g_force_tm = 0, g_force_tn = 0, g_gemm_variant = 0;
+static int g_force_tm = 0, g_force_tn = 0, g_products = []() { const char* e = getenv("AWR_GEMM_PRODUCTS"); return e ? atoi(e) : 1; }();
 
 extern "C" {
 
@@ -550,11 +908,13 @@ int awr_debug_force_tile(int tm, int tn) {
     return AWR_OK;
 }
 
-int awr_debug_gemm_variant(int v) {
-    AWR_REQUIRE(v >= 0 && v <= 3, "gemm_variant: bit 0 = double-buffered pipeline, bit 1 = s_setprio around the MFMA groups");
-    g_gemm_variant = v;
+int awr_set_gemm_products(int n) {
+    AWR_REQUIRE(n == 1 || n == 6, "gemm_products: 1 (f32 MFMA) or 6 (3-way bf16 split, 6 bf16 MFMA products per fp32 product)");
+    g_products = n;
     return AWR_OK;
 }
+
+int awr_get_gemm_products(void) { return g_products; }
 
 static int conv_gemm_one(const awr_conv_args* a, void* stream);
 
@@ -582,6 +942,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
 static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
     AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
+    AWR_REQUIRE(g_products == 1 || a->w_split, "conv_gemm: the %d-product mode needs the split image of the weights (w_split)", g_products);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
     AWR_REQUIRE(a->N % 4 == 0, "conv_gemm: N=%d must be a multiple of 4 (16-byte output rows)", a->N);
     AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && !a->res), "conv_gemm: fused BN-backward reduction needs coef + stats and no accumulate");
@@ -610,12 +971,12 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     hipStream_t st = as_stream(stream);
+    const bool aff = a->in_scale != nullptr || a->relu_in;
 #define AWR_LAUNCH_GEMM(tm, tn)                                                                          \
     do {                                                                                                 \
-        if (g_gemm_variant == 1) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, true, false>), grid, dim3(256), 0, st, *a);       \
-        else if (g_gemm_variant == 2) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, false, true>), grid, dim3(256), 0, st, *a);  \
-        else if (g_gemm_variant == 3) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, true, true>), grid, dim3(256), 0, st, *a);   \
-        else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, false, false>), grid, dim3(256), 0, st, *a);                         \
+        if (g_products == 6 && aff) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, true>), grid, dim3(256), 0, st, *a);   \
+        else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
+        else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)
     if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);
     else if (TM == 2 && TN == 1) AWR_LAUNCH_GEMM(2, 1);
@@ -676,10 +1037,16 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     int wshift = log2i(a->Wd), hshift = log2i(a->Hd);
     if (wshift < 0 || hshift < 0) wshift = hshift = -1;
-    if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
-    else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
-    else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);
+#define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
+    do {                                                                                                                                  \
+        if (g_products == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);                                \
+    } while (0)
+    if (TM == 2 && TN == 2) AWR_LAUNCH_WGRAD(2, 2);
+    else if (TM == 2 && TN == 1) AWR_LAUNCH_WGRAD(2, 1);
+    else if (TM == 1 && TN == 2) AWR_LAUNCH_WGRAD(1, 2);
+    else AWR_LAUNCH_WGRAD(1, 1);
+#undef AWR_LAUNCH_WGRAD
     return check_launch("conv_wgrad_kernel");
 }
 

@@ -51,6 +51,18 @@ __device__ __forceinline__ int find_job(const Job* __restrict__ jobs, int n, int
     return lo;
 }
 
+// element idx of a packed weight buffer -> its three bf16 pieces in the split image (awr_hip.h: awr_split_weight)
+__device__ __forceinline__ void store_split_elem(void* split, int64_t idx, float x) {
+    const unsigned h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    const unsigned m = __float_as_uint(r1) & 0xFFFF0000u;
+    const unsigned l = __float_as_uint(r1 - __uint_as_float(m));
+    unsigned short* o = reinterpret_cast<unsigned short*>(split) + (idx >> 5) * 96 + (idx & 31);
+    o[0] = (unsigned short)(h >> 16);
+    o[32] = (unsigned short)(m >> 16);
+    o[64] = (unsigned short)(l >> 16);
+}
+
 __global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* __restrict__ jobs, int n, int64_t total) {
     const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gidx >= total) return;
@@ -66,6 +78,12 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* _
         if (r < jb.d1 && c < jb.d0) v = jb.src[((int64_t)c * jb.d1 + r) * jb.T + t];
     }
     jb.dst[idx] = v;
+    if (jb.split) store_split_elem(jb.split, idx, v);
+}
+
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ packed, void* __restrict__ split, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) store_split_elem(split, idx, packed[idx]);
 }
 
 __global__ __launch_bounds__(256) void unpack_batched_kernel(const awr_unpack_job* __restrict__ jobs, int n, int64_t total) {
@@ -505,6 +523,12 @@ int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_
     hipLaunchKernelGGL(pack_weight_kernel, dim3(nblk((int64_t)n_pad * T * ld)), dim3(256), 0, as_stream(stream), w, d0, d1, T, transpose, n_pad,
                        ld, packed);
     return check_launch("pack_weight_kernel");
+}
+
+int awr_split_weight(const float* packed, void* split, int64_t n, void* stream) {
+    AWR_REQUIRE(packed && split && n > 0 && n % 32 == 0, "split_weight: n must be a positive multiple of 32");
+    hipLaunchKernelGGL(split_weight_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), packed, split, n);
+    return check_launch("split_weight_kernel");
 }
 
 int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* grad, int accumulate, void* stream) {

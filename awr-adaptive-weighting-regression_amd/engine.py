@@ -16,7 +16,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up
+from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, alloc_packed
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -81,10 +81,10 @@ class ConvLayer:
         dev = self.w.device
         if self.p_fwd is None:
             _, _, T_, _, rows, ld = self.spec.fwd_pack()
-            self.p_fwd = torch.empty(rows, T_, ld, device=dev, dtype=torch.float32)
+            self.p_fwd = alloc_packed(rows, T_, ld, dev)
         if need_dgrad and self.p_dgrad is None:
             _, _, T_, _, rows, ld = self.spec.dgrad_pack()
-            self.p_dgrad = torch.empty(rows, T_, ld, device=dev, dtype=torch.float32)
+            self.p_dgrad = alloc_packed(rows, T_, ld, dev)
 
     def pack_calls(self):
         """(fn, args) tuples that refresh the packed copies from the arena."""
@@ -92,7 +92,7 @@ class ConvLayer:
         for recipe, dst in ((self.spec.fwd_pack(), self.p_fwd), (self.spec.dgrad_pack(), self.p_dgrad)):
             if dst is not None:
                 d0, d1, T_, tr, rows, ld = recipe
-                calls.append(("awr_pack_weight", (L.ptr(self.w), d0, d1, T_, tr, rows, ld, L.ptr(dst))))
+                calls.append(("awr_pack_weight", (L.ptr(self.w), d0, d1, T_, tr, rows, ld, L.ptr(dst)), L.ptr(dst.split)))
         return calls
 
     batchable = True       # plain layers go through the one-launch batched pack / unpack tables
@@ -130,6 +130,9 @@ class HeadLayer(ConvLayer):
         calls.append(("awr_pack_weight", (L.ptr(self.w2), J, cin, 1, 0, rows - 3 * J, cin, self.p_fwd.data_ptr() + 3 * J * cin * 4)))
         if self.p_dgrad is not None:   # P[cin][1][cp]: columns [0,3J) from w1, [3J,4J) from w2 -> pack into a (cp, cin) staging then transpose
             calls.append(("awr_pack_weight", (self.p_fwd.data_ptr(), self.cp, cin, 1, 1, self.p_dgrad.shape[0], self.cp, L.ptr(self.p_dgrad))))
+        for p in (self.p_fwd, self.p_dgrad):
+            if p is not None:
+                calls.append(("awr_split_weight", (L.ptr(p), L.ptr(p.split), p.numel())))
         calls.append(("__copy__", (self.bias_cat[:3 * J], self.b1)))
         calls.append(("__copy__", (self.bias_cat[3 * J:4 * J], self.b2)))
         return calls
@@ -540,6 +543,8 @@ class Plan:
         import os
         s = L.stream()
         cache_file = os.environ.get("AWR_TUNE_CACHE")
+        if cache_key:
+            cache_key += "/x%d" % L.lib.awr_get_gemm_products()      # tile choices differ between the product modes
         if cache_file and cache_key and os.path.exists(cache_file):
             try:
                 ent = json.load(open(cache_file)).get(cache_key)
@@ -609,8 +614,8 @@ class Plan:
             jobs, total = [], 0
             for layer in self.layers:
                 if layer.batchable:
-                    for name, args in layer.pack_calls():
-                        jobs.append(L.PackJob(args[0], args[7], args[1], args[2], args[3], args[4], args[5], args[6], total))
+                    for name, args, split in layer.pack_calls():
+                        jobs.append(L.PackJob(args[0], args[7], split, args[1], args[2], args[3], args[4], args[5], args[6], total))
                         total += args[5] * args[3] * args[6]
             self._pack_tab = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
         tab, njobs, total = self._pack_tab
@@ -619,7 +624,7 @@ class Plan:
         for layer in self.layers:
             if layer.batchable:
                 continue
-            for name, args in layer.pack_calls():
+            for name, args, *_ in layer.pack_calls():
                 if name == "__copy__":
                     args[0].copy_(args[1])
                 else:

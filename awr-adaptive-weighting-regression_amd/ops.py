@@ -110,6 +110,7 @@ def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, 
                    stats=None, relu_in=False, relu_out=False, T=None):
     a = L.ConvArgs()
     a.in_, a.w, a.out = L.ptr(x), L.ptr(w), L.ptr(out)
+    a.w_split = L.ptr(getattr(w, "split", None))
     a.in_scale, a.in_shift, a.bias = L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias)
     a.out_scale, a.out_shift, a.res, a.stats = L.ptr(out_scale), L.ptr(out_shift), L.ptr(res), L.ptr(stats)
     a.B, a.Hin, a.Win, a.Cin = B, prob["Hin"], prob["Win"], prob["Cin"]
@@ -144,13 +145,27 @@ def make_wgrad_args(prob, B, D, G, R, ld, d_affine=None, g_affine=None, d_colsum
 # ---------------------------------------------------------------------------------------------
 # eager wrappers (allocate outputs; used by tests and by the drop-in modules' slow path)
 # ---------------------------------------------------------------------------------------------
+def alloc_packed(rows, T, ld, device):
+    """Packed GEMM weight [rows][T][ld] fp32 plus, as attribute `.split`, its split image (include/awr_hip.h:
+    awr_split_weight) for the 6- / 9-product modes of awr_conv_gemm."""
+    p = torch.zeros(rows, T, ld, device=device, dtype=torch.float32)
+    p.split = torch.zeros(rows * T * ld * 3, device=device, dtype=torch.int16)
+    return p
+
+
+def split_packed(p):
+    L.call("awr_split_weight", L.ptr(p), L.ptr(p.split), p.numel(), L.stream())
+
+
 def pack_weight(w, recipe, out=None, row_offset=0, rows=None):
     d0, d1, T, tr, n_rows, ld = recipe
     if out is None:
-        out = torch.empty(n_rows, T, ld, device=w.device, dtype=torch.float32)
+        out = alloc_packed(n_rows, T, ld, w.device)
     rows = n_rows if rows is None else rows
     dst = out.view(-1)[row_offset * T * ld:]
     L.call("awr_pack_weight", L.ptr(w), d0, d1, T, tr, rows, ld, dst.data_ptr(), L.stream())
+    if hasattr(out, "split"):
+        split_packed(out)
     return out
 
 

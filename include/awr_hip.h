@@ -113,6 +113,7 @@ int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* 
 typedef struct awr_pack_job {
     const float* src;
     float* dst;
+    void* split;          /* optional: split image of dst (awr_split_weight layout), written in the same pass */
     int d0, d1, T, transpose, rows, ld;
     int64_t first;
 } awr_pack_job;
@@ -122,6 +123,11 @@ typedef struct awr_unpack_job {
     int d0, d1, T, ld;
     int64_t first;
 } awr_unpack_job;
+/* Split image of a packed weight buffer of n fp32 elements (n % 32 == 0) for the 6- / 9-product modes of awr_conv_gemm:
+ * every 32-element K-slice becomes 192 bytes [h: 32 bf16 | m: 32 bf16 | l: 32 bf16] with x == h + m + l exactly
+ * (truncating 8+8+8-bit cut of the fp32 significand).  Weights are split once per optimiser step instead of once per
+ * workgroup that stages them. */
+int awr_split_weight(const float* packed, void* split, int64_t n, void* stream);
 int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total, void* stream);
 int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total, void* stream);
 
@@ -161,6 +167,7 @@ typedef struct awr_conv_args {
     int tile_m, tile_n;     /* workgroup tile in units of 64 rows / 64 columns ({1,2} each); 0,0 = built-in heuristic.
                                Static plans autotune this per launch (engine.Plan.autotune). */
     awr_phase ph[4];
+    const void* w_split;    /* split image of w (awr_split_weight); required when awr_get_gemm_products() != 1 */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
@@ -169,8 +176,15 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream);
 /* test hook: force the (TM,TN) in {1,2}^2 workgroup tile of awr_conv_gemm / awr_conv_wgrad
  * (0,0 = automatic choice).  Not for production use. */
 int awr_debug_force_tile(int tm, int tn);
-/* test/tuning hook: main-loop variant of awr_conv_gemm (0 = single LDS buffer, 1 = double-buffered pipeline) */
-int awr_debug_gemm_variant(int v);
+/* How awr_conv_gemm / awr_conv_wgrad form their fp32 products (process-wide; default 1, or $AWR_GEMM_PRODUCTS):
+ *   1 = v_mfma_f32_32x32x2_f32 on fp32 operands (bit-equal to an fmaf chain);
+ *   6 = every operand is cut EXACTLY into three bf16 pieces (x == h + m + l, 8+8+8 significand bits) and each fp32 product
+ *       is formed from six of its nine bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 -- each partial product
+ *       exact, accumulated in fp32; the three dropped ones (m*l, l*m, l*l) weigh <= 2^-23 of the product, i.e. less than
+ *       the rounding of the fp32 accumulation that both modes share.  16x faster matrix pipe, 6 passes: see DESIGN.md.
+ * Replaces nothing in the reference (torch's conv precision is whatever cuDNN / oneDNN pick; cuDNN defaults to TF32). */
+int awr_set_gemm_products(int n);
+int awr_get_gemm_products(void);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).

@@ -101,20 +101,20 @@ def test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, 
     assert rel_err(gw2.cpu(), 2 * gw_ref) < 1e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("products", [1, 6])
 @pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
                                                               ("deconv", 64, 96, 4, 2, 1, 3, 10), ("conv", 32, 64, 1, 1, 0, 2, 12)])
-def test_conv_every_tile_shape(ops, L, dev, variant, tm, tn, kind, cin, cout, k, stride, pad, B, H):
-    """All four workgroup tiles (64/128 x 64/128) and both main-loop variants (single-buffer / double-buffered
-    pipeline) on ragged M and N (not multiples of any tile), incl. a single-K-slice problem."""
+def test_conv_every_tile_shape(ops, L, dev, products, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """All four workgroup tiles (64/128 x 64/128) in both product modes (f32 MFMA, 6-product bf16 split)
+    on ragged M and N (not multiples of any tile), incl. a single-K-slice problem."""
     L.call("awr_debug_force_tile", tm, tn)
-    L.call("awr_debug_gemm_variant", variant)
+    L.call("awr_set_gemm_products", products)
     try:
         test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, H)
     finally:
         L.call("awr_debug_force_tile", 0, 0)
-        L.call("awr_debug_gemm_variant", 0)
+        L.call("awr_set_gemm_products", 1)
 
 
 def test_conv_fused_prologue_epilogue_stats(ops, dev):

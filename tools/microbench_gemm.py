@@ -147,12 +147,15 @@ def main():
                     continue
                 t, tf = run_fwd(spec, B, H, tile)
                 alt = []
-                for v in (1, 2, 3):
-                    L.call("awr_debug_gemm_variant", v)
-                    alt.append("v%d %.0fTF" % (v, run_fwd(spec, B, H, tile)[1]))
-                L.call("awr_debug_gemm_variant", 0)
+                for v in (6,):
+                    L.call("awr_set_gemm_products", v)
+                    alt.append("x%d %.0fTF" % (v, run_fwd(spec, B, H, tile)[1]))
+                L.call("awr_set_gemm_products", 1)
                 tw, tfw = run_wgrad(spec, B, H, tile)
-                best.append("%s fwd %.0fus %.0fTF  [%s] | wgrad %.0fus %.0fTF" % (tile, t * 1e6, tf, " ".join(alt), tw * 1e6, tfw))
+                L.call("awr_set_gemm_products", 6)
+                tw6, tfw6 = run_wgrad(spec, B, H, tile)
+                L.call("awr_set_gemm_products", 1)
+                best.append("%s fwd %.0fus %.0fTF  [%s] | wgrad %.0fus %.0fTF [x6 %.0fTF]" % (tile, t * 1e6, tf, " ".join(alt), tw * 1e6, tfw, tfw6))
             t, tf = run_fwd(spec, B, H)
             print("%-28s auto fwd %.0f TF" % (name, tf))
             for b_ in best:
