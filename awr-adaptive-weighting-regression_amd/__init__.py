@@ -7,6 +7,19 @@ library; the first use of any hot-path object does, and fails loudly if it is mi
 __version__ = "0.1.0"
 
 
+def set_gemm_products(n):
+    """Process-wide choice of how the conv GEMMs form their fp32 products (include/awr_hip.h: awr_set_gemm_products):
+    1 = FP32 MFMA (default), 6 = exact 3-way bf16 split of both operands, 6 bf16 MFMA partial products per fp32 product.
+    Takes effect for kernels launched (or hipGraphs captured) afterwards; autotuned tile choices are kept per mode."""
+    from . import _lib as L
+    L.call("awr_set_gemm_products", int(n))
+
+
+def get_gemm_products():
+    from . import _lib as L
+    return int(L.lib.awr_get_gemm_products())
+
+
 def __getattr__(name):
     import importlib
     table = {

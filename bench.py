@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16); the split-operand mode runs on this pipe
 
 
 class KernelTimer:
@@ -105,6 +106,9 @@ def main():
     ap.add_argument("--coord-weight", type=float, default=0.0, help="reference default config.py:41")
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="infer = test.py:67-86 path (eval BN, img -> joints); not the headline metric")
     ap.add_argument("--wgrad-streams", type=int, default=2, help="extra HIP streams for the weight-gradient GEMMs (0 = fully serial step)")
+    ap.add_argument("--gemm-products", type=int, default=1, choices=[1, 6],
+                    help="1 = FP32 MFMA (default, the headline); 6 = split-operand mode (fp32 operands as 3 exact bf16 pieces, 6 bf16 MFMA products)")
+    ap.add_argument("--no-split-mode", action="store_true", help="skip the extra split-operand measurement reported under 'split_mode'")
     ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
     args = ap.parse_args()
 
@@ -129,6 +133,11 @@ def main():
     import awr_oracle as O          # synthetic-input generator + cpu_baseline only; never on the measured path
 
     ks = 1.0 if args.net.startswith("resnet") else 0.4          # config.py:42
+    awr_amd.set_gemm_products(args.gemm_products)
+    nprod = args.gemm_products
+    dtype = "f32" if nprod == 1 else "f32 (operands as 3 exact bf16 pieces, 6 bf16 MFMA products per f32 product, f32 accumulate)"
+    # MFMA roofline of the mode: FP32 MFMA peak, or the bf16 dense peak against 6 MFMA flops per algorithmic flop
+    peak_tf, flop_mult = (PEAK_FP32_MFMA_TFLOPS, 1) if nprod == 1 else (PEAK_BF16_MFMA_TFLOPS, 6)
     torch.manual_seed(0)
     net = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
     if args.mode == "infer":
@@ -159,9 +168,9 @@ def main():
                     f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / sec))
         print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": round(args.batch * args.steps / el, 2), "unit": "images/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-                          "dtype": "f32", "data": "synthetic", "config": {"workload": "%s eval forward + head, batch %d" % (args.net, args.batch),
-                                                                          "hipgraph": bool(args.graph)},
-                          "mfma_frac": round(2 * macs / (el / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}), flush=True)
+                          "dtype": dtype, "data": "synthetic", "config": {"workload": "%s eval forward + head, batch %d" % (args.net, args.batch),
+                                                                          "hipgraph": bool(args.graph), "gemm_products": nprod},
+                          "mfma_frac": round(flop_mult * 2 * macs / (el / args.steps) / 1e12 / peak_tf, 4)}), flush=True)
         return
     eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
                       use_graph=args.graph, wgrad_streams=args.wgrad_streams)
@@ -236,15 +245,16 @@ def main():
             traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_x2"] + v["write_MB_per_launch"]) for v in ent) / nl * 1e6)
             traffic_src = "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
     roofline = {
-        "bound": "mfma", "kernel": dom, "event_pass": "timed region" if serial else "serialised pass after the timed region (kernels overlap on 2 streams in the timed region)", "achieved": round(kern[dom]["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "mfma", "kernel": dom, "event_pass": "timed region" if serial else "serialised pass after the timed region (kernels overlap on 2 streams in the timed region)",
+        "achieved": round(flop_mult * kern[dom]["tflops"], 2), "peak": peak_tf, "unit": "TFLOP/s", "mfma_flops_per_algorithmic_flop": flop_mult,
+        "frac": round(flop_mult * kern[dom]["tflops"] / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flop_per_launch": round(kern[dom]["flops"] / max(kern[dom]["launches"], 1)),
         "avg_launch_us": round(kern[dom]["avg_us"], 2), "launches_per_step": kern[dom]["launches"] // max(nsteps_timed, 1),
         "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2) if tot_sec else 0.0,
         "gemm_seconds_per_step": round(tot_sec / max(nsteps_timed, 1), 6),
         "algorithmic_gflop_per_image": round(tot_fl / max(nsteps_timed, 1) / args.batch / 1e9, 3),
         "other_kernels": {k: {"tflops": round(v["tflops"], 2), "avg_us": round(v["avg_us"], 2)} for k, v in kern.items() if k != dom},
-        "step_mfma_frac": round((tot_fl / max(nsteps_timed, 1)) / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "step_mfma_frac": round(flop_mult * (tot_fl / max(nsteps_timed, 1)) / (elapsed / args.steps) / 1e12 / peak_tf, 4),
     }
 
     if rank == 0:
@@ -253,12 +263,12 @@ def main():
         out = {
             "metric": "depth-images/sec (train step)", "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s-deconv NYU-shape 128x128 J=14 train step (GT-map+fwd+head+Huber+bwd+Adam), batch %d/GPU" % (args.net, args.batch)
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
                        "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": bool(args.graph), "wgrad_streams": args.wgrad_streams,
-                       "device_cus": n_cu.value, "final_loss": loss},
+                       "gemm_products": nprod, "device_cus": n_cu.value, "final_loss": loss},
             "roofline": roofline,
         }
         if world == 1 and not args.no_parity:
@@ -266,6 +276,30 @@ def main():
             out["joint_err_mm_vs_oracle"] = {"mean": round(mean_mm, 6), "max": round(max_mm, 6)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.net, ks, args.batch)
+        if world == 1 and nprod == 1 and not args.no_split_mode:
+            # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)
+            awr_amd.set_gemm_products(6)
+            torch.manual_seed(0)
+            net6 = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
+            eng6 = TrainEngine(net6, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, use_graph=args.graph,
+                               wgrad_streams=args.wgrad_streams)
+            for _ in range(max(args.warmup, 3 if args.graph else 0)):
+                eng6.step(img, jt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng6.step(img, jt)
+            torch.cuda.synchronize()
+            el6 = time.perf_counter() - t0
+            sm = {"gemm_products": 6, "dtype": "f32 operands cut exactly into 3 bf16 pieces, 6 bf16 MFMA partial products per f32 product, f32 accumulate",
+                  "value": round(args.batch * args.steps / el6, 2), "unit": "images/s", "ms_per_step": round(1e3 * el6 / args.steps, 3),
+                  "final_loss": float(eng6.losses[2]),
+                  "step_mfma_frac_of_bf16_peak": round(6 * (tot_fl / max(nsteps_timed, 1)) / (el6 / args.steps) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+            if not args.no_parity:
+                mean6, max6 = parity_mm(args.net, ks, dev)
+                sm["joint_err_mm_vs_oracle"] = {"mean": round(mean6, 6), "max": round(max6, 6)}
+            awr_amd.set_gemm_products(1)
+            out["split_mode"] = sm
         print(json.dumps(out), flush=True)
     if pg is not None:
         torch.distributed.destroy_process_group()

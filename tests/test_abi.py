@@ -53,9 +53,11 @@ def test_argument_validation_without_gpu(lib):
 
 def test_struct_layout_matches_header(lib):
     import ctypes as C
-    # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 12 pointers + 15 ints + 4 phases
+    # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 12 pointers + 17 ints + 4 phases + pad + w_split
     assert C.sizeof(lib.Phase) == 76
-    assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4   # trailing pad to 8-byte alignment
+    assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4 + 8   # 4 bytes of padding before the trailing pointer
+    assert lib.ConvArgs.w_split.offset == 472
+    assert C.sizeof(lib.PackJob) == 3 * 8 + 6 * 4 + 8
     assert C.sizeof(lib.WgradArgs) == 8 * 8 + 15 * 4 + 32 + 4
 
 

@@ -428,3 +428,17 @@ def test_train_engine_optimizer_variants_vs_torch(amd, dev, optimizer, wd):
         opt.step()
         d = (m.flat_params()[:m.n_active] - shadow.detach()).abs().max()
         assert float(d) <= 2e-6, (optimizer, wd, float(d))
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
+def test_split_operand_mode_meets_the_same_golden_bars(amd, dev, golden_dir, net):
+    """awr_amd.set_gemm_products(6): every conv GEMM of forward, dgrad and wgrad on the bf16 matrix pipe with exactly split
+    fp32 operands.  Same golden vectors, same tolerances as the FP32-MFMA mode (forward maps, joints, BN statistics,
+    losses, gradient norms, two Adam steps)."""
+    amd.set_gemm_products(6)
+    try:
+        assert amd.get_gemm_products() == 6
+        test_backbone_forward_golden(amd, dev, golden_dir, net)
+        test_fused_train_step_golden(amd, dev, golden_dir, net, "c1", 1.0)
+    finally:
+        amd.set_gemm_products(1)

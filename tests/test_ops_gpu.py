@@ -340,3 +340,34 @@ def test_batch_chunking_above_4gb(ops, dev):
     gw = ops.conv_wgrad(spec, x, y)
     gw2 = ops.conv_wgrad(spec, x[:64].contiguous(), y[:64].contiguous()) + ops.conv_wgrad(spec, x[64:].contiguous(), y[64:].contiguous())
     assert rel_err(gw.cpu(), gw2.cpu()) < 1e-4
+
+
+def test_split_mode_accuracy_matches_fp32_mfma(ops, L, dev):
+    """The 6-product split mode (awr_set_gemm_products(6)) against the FP32-MFMA mode, both measured against an fp64
+    reference on a long contraction (K = 9*256 forward / dgrad, K = 2*24*24 pixels for the weight gradient) with wide
+    dynamic range.  Dropping the m*l, l*m, l*l partial products costs <= 2^-23 per product -- below the rounding of the
+    fp32 accumulation both modes share -- so the two errors must be of the same size."""
+    spec = ops.ConvSpec("conv", 256, 256, 3, 1, 1)
+    B, H = 2, 24
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 256, H, H, generator=g) * torch.exp(2.0 * torch.randn(B, 256, H, H, generator=g))     # heavy-tailed
+    w = torch.randn(256, 256, 3, 3, generator=g) * (256 * 9) ** -0.5
+    gy = torch.randn(B, 256, H, H, generator=g) * torch.exp(1.5 * torch.randn(B, 256, H, H, generator=g))
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = TF.conv2d(xd, wd, None, 1, 1)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [xd, wd], gy.double())
+    errs = {}
+    try:
+        for n in (1, 6):
+            L.call("awr_set_gemm_products", n)
+            wg = w.to(dev)
+            y = ops.conv_forward(spec, ops.nhwc(x).to(dev), ops.pack_weight(wg, spec.fwd_pack()))
+            gx = ops.conv_dgrad(spec, ops.nhwc(gy).to(dev), ops.pack_weight(wg, spec.dgrad_pack()), H, H)
+            gw = ops.conv_wgrad(spec, ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev))
+            errs[n] = (rel_err(ops.nchw(y).cpu(), y_ref.detach()), rel_err(ops.nchw(gx).cpu(), gx_ref), rel_err(gw.cpu(), gw_ref))
+    finally:
+        L.call("awr_set_gemm_products", 1)
+    print("rel. error vs fp64 (fwd, dgrad, wgrad): f32 MFMA %s | 6-product split %s" % (errs[1], errs[6]))
+    for e1, e6 in zip(errs[1], errs[6]):
+        assert e6 <= 2.0 * e1 + 1e-7, (errs[1], errs[6])
+        assert e6 < 5e-6
