@@ -30,6 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;        // K-slice (floats)
 constexpr int LDK = BK + 4;   // padded LDS row (floats) : 144 B, conflict-free for ds_read_b128
+#ifndef AWR_WBK
+#define AWR_WBK 32
+#endif
+constexpr int WBK = AWR_WBK;  // K-slice of the fp32 weight-gradient kernel (pixels)
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     // bijective "each XCD gets a contiguous chunk" remap (hardware places block b on XCD b % 8)
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BK = WBK;        // pixels per K-slice (shadows the channel-slice constant of the forward kernel)
     constexpr int LDM = BM + 4, LDN = BN + 4;
     constexpr int FM = BM / 4, FN = BN / 4;          // float4 per pixel row
     constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows staged per pass
@@ -1026,11 +1031,11 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     static const int target_blocks = []() { const char* e = getenv("AWR_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning hook
     const int want_blocks = a->target_blocks > 0 ? a->target_blocks : target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
     int64_t nsplit = (want_blocks + tiles - 1) / tiles;
-    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 8 K-slices per workgroup
+    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 256 pixels per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     int64_t chunk = (M + nsplit - 1) / nsplit;
-    chunk = (chunk + BK - 1) / BK * BK;
+    chunk = (chunk + 63) / 64 * 64;
     nsplit = (M + chunk - 1) / chunk;
     const dim3 grid((unsigned)tiles, (unsigned)nsplit);
     hipStream_t st = as_stream(stream);

@@ -610,15 +610,18 @@ class Plan:
         """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena: one batched launch for the
         plain layers, a few extra calls for the fused heads."""
         s = L.stream()
+        want_split = L.lib.awr_get_gemm_products() != 1      # split images are only written (132 MB per ResNet18 step) for the mode that reads them
         if self._pack_tab is None:
+            self._pack_tab = {}
+        if want_split not in self._pack_tab:
             jobs, total = [], 0
             for layer in self.layers:
                 if layer.batchable:
                     for name, args, split in layer.pack_calls():
-                        jobs.append(L.PackJob(args[0], args[7], split, args[1], args[2], args[3], args[4], args[5], args[6], total))
+                        jobs.append(L.PackJob(args[0], args[7], split if want_split else None, args[1], args[2], args[3], args[4], args[5], args[6], total))
                         total += args[5] * args[3] * args[6]
-            self._pack_tab = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
-        tab, njobs, total = self._pack_tab
+            self._pack_tab[want_split] = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
+        tab, njobs, total = self._pack_tab[want_split]
         if njobs:
             L.check(L.lib.awr_pack_weights_batched(tab.data_ptr(), njobs, total, s), "awr_pack_weights_batched")
         for layer in self.layers:
@@ -627,7 +630,7 @@ class Plan:
             for name, args, *_ in layer.pack_calls():
                 if name == "__copy__":
                     args[0].copy_(args[1])
-                else:
+                elif name != "awr_split_weight" or want_split:
                     L.check(getattr(L.lib, name)(*args, s), name)
         for fn, args, name in self.pack_ops:
             L.check(fn(*args[:-1], s), name)
