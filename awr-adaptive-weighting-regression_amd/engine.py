@@ -578,6 +578,8 @@ class Plan:
                     cands += [(2, 1, 1536), (2, 1, 2048)]
                 if a.Cg > 64:
                     cands += [(1, 2, 2048)]
+                if a.Cd > 64 and a.Cg > 64 and L.lib.awr_get_gemm_products() != 1:
+                    cands += [(2, 2, 1024), (2, 2, 2048)]     # the split-mode kernel stages less per MFMA on the big tile
             best, best_t = None, 1e30
             for tm, tn, tb in cands:
                 a.tile_m, a.tile_n = tm, tn
