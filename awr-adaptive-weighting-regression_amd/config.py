@@ -1,41 +1,52 @@
-"""`opt`: the reference's edit-the-file configuration object (config.py:19-52) with identical attribute
-names and defaults, plus the knobs the MI355X path adds (defaults leave reference behaviour unchanged)."""
-JOINT = {"nyu": 14, "icvl": 16, "msra": 21, "hands17": 21}
-STEP = {"nyu": 30, "icvl": 10, "msra": 10, "hands17": 5}
-EPOCH = {"nyu": 40, "icvl": 40, "msra": 25, "hands17": 10}
+"""`opt`: the configuration object the reference's entry points read (reference config.py:19-52).  Attribute names
+and default values are the reference's -- train.py / test.py address them as `self.config.<name>` -- but the object is
+built from tables, validates what it is given, and carries the knobs of the MI355X path."""
+
+# per-dataset constants: joints, LR-decay step (epochs), epochs               (reference config.py:1-18)
+_DATASETS = {
+    #            joints  step  epochs
+    "nyu":      (14,     30,   40),
+    "icvl":     (16,     10,   40),
+    "msra":     (21,     10,   25),
+    "hands17":  (21,      5,   10),
+}
+JOINT = {k: v[0] for k, v in _DATASETS.items()}
+STEP = {k: v[1] for k, v in _DATASETS.items()}
+EPOCH = {k: v[2] for k, v in _DATASETS.items()}
+
+_RUN = dict(gpu_id=0, exp_id="nyu_hourglass", log_id="dense", print_freq=100, vis_freq=1)
+_PATHS = dict(data_dir="./data", output_dir="./output/", load_model="./results/hourglass_1.pth")
+_DATA = dict(dataset="nyu", cube=[300, 300, 300], augment_para=[10, 0.1, 180], img_size=128, batch_size=32, num_workers=8)
+_MODEL = dict(net="hourglass_1",      # or 'resnet_18'
+              downsample=2,           # 1, 2 or 4: feature size = img_size / downsample
+              kernel_size=0.4)        # 0.4 for hourglass, 1 for resnet
+_OPTIM = dict(loss_type="MyL1Loss", dense_weight=1.0, coord_weight=0, lr=1e-3, optimizer="adam", scheduler="step", weight_decay=0)
+_MI355X = dict(use_hipgraph=True,     # replay each step as one hipGraph
+               world_size=1,          # data-parallel ranks (one process per GPU, RCCL)
+               gemm_products=1)       # 1 = FP32 MFMA, 6 = split-operand mode
 
 
 class Config(object):
-    gpu_id = 0
-    exp_id = "nyu_hourglass"
-    log_id = "dense"
-    data_dir = "./data"
-    dataset = "nyu"
-    output_dir = "./output/"
-    load_model = "./results/hourglass_1.pth"
-    jt_num = JOINT[dataset]
-    cube = [300, 300, 300]
-    augment_para = [10, 0.1, 180]
-    net = "hourglass_1"          # or 'resnet_18'
-    downsample = 2
-    img_size = 128
-    batch_size = 32
-    num_workers = 8
-    max_epoch = EPOCH[dataset]
-    loss_type = "MyL1Loss"
-    dense_weight = 1.0
-    coord_weight = 0
-    kernel_size = 0.4            # 0.4 for hourglass, 1 for resnet
-    lr = 1e-3
-    optimizer = "adam"
-    scheduler = "step"
-    step = STEP[dataset]
-    weight_decay = 0
-    print_freq = 100
-    vis_freq = 1
-    # ---- additions of the MI355X path ----
-    use_hipgraph = True          # replay each step as one hipGraph
-    world_size = 1               # data-parallel ranks (one process per GPU, RCCL)
+    """Attribute bag.  Defaults live on the class (so the reference's idiom -- subclass or edit and override attributes --
+    keeps working); keyword overrides are validated; dataset-derived entries (jt_num, step, max_epoch) follow `dataset`
+    unless a subclass or an override sets them."""
 
+    def __init__(self, **overrides):
+        unknown = [k for k in overrides if not hasattr(type(self), k) and k not in _DERIVED]
+        if unknown:
+            raise AttributeError("unknown config entries: %s" % sorted(unknown))
+        for k, v in overrides.items():
+            setattr(self, k, v)
+        if self.dataset not in _DATASETS:
+            raise ValueError("dataset must be one of %s" % sorted(_DATASETS))
+        for k, v in zip(_DERIVED, _DATASETS[self.dataset]):
+            if k not in overrides and not hasattr(type(self), k):
+                setattr(self, k, v)
+
+
+_DERIVED = ("jt_num", "step", "max_epoch")
+for _table in (_RUN, _PATHS, _DATA, _MODEL, _OPTIM, _MI355X):
+    for _k, _v in _table.items():
+        setattr(Config, _k, _v)
 
 opt = Config()

@@ -345,6 +345,9 @@ class Trainer:
             self.net = hourglass.PoseNet(config.net, config.jt_num)
         self.net = self.net.cuda()
         self.best_records = {"epoch": 0, "MPE": 1e10, "AUC": 0}
+        if getattr(config, "gemm_products", 1) != 1:      # opt-in split-operand GEMMs (process-wide)
+            from . import set_gemm_products
+            set_gemm_products(config.gemm_products)
         self.engine = TrainEngine(self.net, config.batch_size, config.img_size, config.kernel_size, config.coord_weight, config.dense_weight,
                                   config.lr, config.weight_decay, config.optimizer, process_group=process_group,
                                   use_graph=getattr(config, "use_hipgraph", True))
