@@ -333,9 +333,8 @@ class Trainer:
         os.makedirs(self.result_dir, exist_ok=True)
         self.log = open(os.path.join(self.work_dir, "%s_%s.log" % (config.net, config.log_id)), "a") if self.rank == 0 else None
         self._msg("-------------------start programming-------------------", stdout=False)
-        for k, v in config.__class__.__dict__.items():
-            if not k.startswith("_"):
-                self._msg(str(k) + ":" + str(v))
+        for k in sorted(k for k in dir(config) if not k.startswith("_") and not callable(getattr(config, k))):     # train.py:44-46
+            self._msg(str(k) + ":" + str(getattr(config, k)))
         if "resnet" in config.net:
             self.net = resnet_deconv.get_deconv_net(int(config.net.split("_")[1]), config.jt_num, config.downsample)
             self.stacks = 1
