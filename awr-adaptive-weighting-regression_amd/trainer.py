@@ -326,6 +326,16 @@ class Trainer:
         from . import resnet_deconv, hourglass
         from .evaluator import EvalUtil
         self.config, self.EvalUtil = config, EvalUtil
+        if train_data is None and test_data is None:      # train.py:58-61: datasets come from the config
+            if config.dataset != "nyu":
+                raise ValueError("only the NYU loader is provided (dataset=%r): pass train_data / test_data objects" % config.dataset)
+            from .nyu_data import NYU
+            root = os.path.join(config.data_dir, config.dataset)
+            if not os.path.isdir(os.path.join(root, "test")):
+                raise FileNotFoundError("NYU data not found under %s (expects train/ test/ center_*_refined.txt, dataloader/nyu_loader.py:38-49)" % root)
+            if os.path.isdir(os.path.join(root, "train")):
+                train_data = NYU(root, "train", img_size=config.img_size, aug_para=config.augment_para, cube=config.cube, jt_num=config.jt_num)
+            test_data = NYU(root, "test", img_size=config.img_size, cube=config.cube, jt_num=config.jt_num)
         self.trainData, self.testData, self.pg = train_data, test_data, process_group
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         self.work_dir = os.path.join(config.output_dir, config.dataset, "checkpoint_" + config.exp_id)
@@ -370,8 +380,16 @@ class Trainer:
             print(msg)
         print(msg, file=self.log)
 
-    def _loader(self, data, shuffle):
-        return torch.utils.data.DataLoader(data, batch_size=self.config.batch_size, shuffle=shuffle, num_workers=0, drop_last=shuffle)
+    def _loader(self, data, shuffle, epoch=0):
+        """train.py:109: DataLoader(batch_size, shuffle=True, num_workers); data parallel: every rank iterates its own
+        1/world shard of the epoch's permutation (DistributedSampler), batch_size images per rank and step."""
+        sampler = None
+        if self.pg is not None:
+            sampler = torch.utils.data.distributed.DistributedSampler(data, num_replicas=torch.distributed.get_world_size(self.pg), rank=self.rank,
+                                                                      shuffle=shuffle, drop_last=shuffle)
+            sampler.set_epoch(epoch)
+        return torch.utils.data.DataLoader(data, batch_size=self.config.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                           num_workers=int(getattr(self.config, "num_workers", 0)), drop_last=shuffle)
 
     def train(self):
         cfg, eng = self.config, self.engine
@@ -379,7 +397,7 @@ class Trainer:
             self.net.train()
             ev = self.EvalUtil(self.trainData.img_size, self.trainData.paras, self.trainData.flip, self.trainData.jt_num)
             lsum, lcnt, pend, last_mean = torch.zeros(3, device=self.net.device), 0, [], float("nan")
-            for ii, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(self._loader(self.trainData, True)):
+            for ii, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(self._loader(self.trainData, True, epoch)):
                 losses, jt_pred = eng.step(img.cuda(non_blocking=True), jt_uvd_gt.cuda(non_blocking=True))
                 lsum += losses                                      # device-side meter: no loss.item() per iteration
                 lcnt += 1

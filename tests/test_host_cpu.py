@@ -158,3 +158,26 @@ def test_gradient_bucket_planner(amd):
         assert ready >= max(r for (wlo, whi, r) in writes if lo <= wlo < hi)    # nothing is reduced before it is final
     assert plan_buckets(writes, 1000, 1) == [(0, 1000, 50)]
     assert len(plan_buckets(writes, 1000, 16)) <= 6
+
+
+def test_entry_point_overrides_and_dataset_lookup(tmp_path):
+    """train.py / test.py entry points: `--set` parsing, config validation, and the reference's behaviour of building the
+    NYU datasets from the config (train.py:58-61) -- here: a clear error when the directory is absent."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("awr_train_entry", os.path.join(repo, "train.py"))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    ov = entry.parse_overrides(["net=resnet_18", "kernel_size=1", "cube=[250,250,250]", "lr=5e-4", "exp_id=run_a"])
+    assert ov == {"net": "resnet_18", "kernel_size": 1, "cube": [250, 250, 250], "lr": 5e-4, "exp_id": "run_a"}
+    from awr_amd.config import Config
+    cfg = Config(data_dir=str(tmp_path), dataset="nyu", **ov)
+    assert (cfg.jt_num, cfg.step, cfg.max_epoch) == (14, 30, 40) and cfg.net == "resnet_18"
+    assert Config(dataset="msra").jt_num == 21 and Config(dataset="icvl", max_epoch=3).max_epoch == 3
+    with pytest.raises(AttributeError):
+        Config(no_such_entry=1)
+    with pytest.raises(ValueError):
+        Config(dataset="bighand")
+    from awr_amd.trainer import Trainer
+    with pytest.raises(FileNotFoundError):
+        Trainer(cfg)

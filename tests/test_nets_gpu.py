@@ -258,6 +258,7 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
         net = "resnet_18"
         kernel_size = 1.0
         batch_size = 8
+        num_workers = 0
         max_epoch = 3
         step = 2
         print_freq = 2
@@ -442,3 +443,22 @@ def test_split_operand_mode_meets_the_same_golden_bars(amd, dev, golden_dir, net
         test_fused_train_step_golden(amd, dev, golden_dir, net, "c1", 1.0)
     finally:
         amd.set_gemm_products(1)
+
+
+def test_train_and_test_entry_points(dev, tmp_path):
+    """`python train.py` / `python test.py` (reference train.py:231-236, test.py:113-116) as subprocesses on a synthetic
+    dataset: one epoch, checkpoint written, test.py reloads it and writes the results file."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--synthetic", "32", "--set", "net=resnet_18", "kernel_size=1", "batch_size=8", "num_workers=0", "max_epoch=1", "print_freq=2",
+              "output_dir=%s" % tmp_path, "exp_id=entry", "use_hipgraph=False", "coord_weight=1.0"]
+    r = subprocess.run([sys.executable, os.path.join(repo, "train.py")] + common + ["load_model="], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ckpt = os.path.join(str(tmp_path), "nyu", "checkpoint_entry", "epoch_1.pth")
+    assert os.path.exists(ckpt), r.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(repo, "test.py")] + common + ["load_model=%s" % ckpt], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "loading model from" in r.stdout and "[test mpe" in r.stdout, r.stdout[-2000:]
+    res = os.listdir(os.path.join(str(tmp_path), "nyu", "checkpoint_entry"))
+    assert any(f.startswith("test_") and f.endswith(".txt") for f in res), res
