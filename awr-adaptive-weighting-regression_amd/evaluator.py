@@ -5,18 +5,22 @@ import numpy as np
 
 
 def uvd2xyz(pts, paras, flip=1):
-    """Pinhole back-projection (util/util.py:13-20); paras = (fx, fy, u0, v0)."""
-    p = np.array(pts, dtype=np.float32).reshape(-1, 3).copy()
-    p[:, :2] = (p[:, :2] - np.asarray(paras[2:], np.float32)) * p[:, 2:] / np.asarray(paras[:2], np.float32)
+    """Pinhole back-projection (util/util.py:13-20); paras = (fx, fy, u0, v0).  Like the reference, the arithmetic runs in
+    float64 against the intrinsics and is stored in the dtype of `pts` (float32 from the evaluator, float64 from the loader)
+    before the final float32 cast."""
+    p = np.array(pts).reshape(-1, 3).copy()
+    par = np.asarray(paras, np.float64)
+    p[:, :2] = (p[:, :2] - par[2:]) * p[:, 2:] / par[:2]
     p[:, 1] *= flip
     return p.reshape(np.shape(pts)).astype(np.float32)
 
 
 def xyz2uvd(pts, paras, flip=1):
-    """util/util.py:3-10."""
-    p = np.array(pts, dtype=np.float32).reshape(-1, 3).copy()
+    """util/util.py:3-10 (same dtype behaviour as uvd2xyz)."""
+    p = np.array(pts).reshape(-1, 3).copy()
+    par = np.asarray(paras, np.float64)
     p[:, 1] *= flip
-    p[:, :2] = p[:, :2] * np.asarray(paras[:2], np.float32) / p[:, 2:] + np.asarray(paras[2:], np.float32)
+    p[:, :2] = p[:, :2] * par[:2] / p[:, 2:] + par[2:]
     return p.reshape(np.shape(pts)).astype(np.float32)
 
 

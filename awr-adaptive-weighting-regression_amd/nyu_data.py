@@ -7,11 +7,13 @@
 What is provided: PNG depth decode (depth = G*256 + B, computed in float -- the reference's uint8 arithmetic at
 nyu_loader.py:73 overflows on numpy >= 2), cube crop around the refined hand centre, nearest-neighbour resize with
 cv2.INTER_NEAREST index semantics, depth normalisation to [-1,1], label transforms, the per-frame test cube rule
-(frames >= 2440 use 5/6 of the cube, nyu_loader.py:31-32).  What is NOT provided: the training-time augmentation
-(random translate / scale / rotate through cv2.warpPerspective / warpAffine, loader.py:53-179): `phase='train'`
-yields un-augmented crops.  The numpy-only helpers are pinned against the reference by tools/gen_golden.py
-(tests/golden/loader_fns.npz); the resize follows OpenCV's documented index rule and is not pinned (cv2 is not
-installable here).
+(frames >= 2440 use 5/6 of the cube, nyu_loader.py:31-32), and the training-time augmentation (one of translate /
+scale / rotate / nothing per sample, loader.py:53-179) with the reference's random stream (RandomState(23455),
+loader.py:11) and label arithmetic.  The numpy-only helpers, the random stream and the augmentation's label / matrix /
+cube outputs are pinned against the reference by tools/gen_golden.py (tests/golden/loader_fns.npz, loader_aug.npz).
+The three image resamplers -- cv2.resize(INTER_NEAREST), cv2.warpAffine and cv2.warpPerspective with INTER_LINEAR /
+BORDER_CONSTANT -- are restated from OpenCV's published fixed-point scheme (coordinates in 1/32 pixel, 10-bit affine
+deltas) and are NOT pinned: cv2 cannot be installed here.
 """
 import os
 from glob import glob
@@ -117,6 +119,174 @@ def transform_jt_uvd(jt_uvd, M):
     return np.hstack([pts[:, :2], jt_uvd[:, 2:]]).astype(np.float32)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# bilinear warps with OpenCV's sampling rule (imgwarp.cpp): source coordinates are quantised to 1/32 pixel
+# (INTER_BITS = 5), the four taps are weighted with (1 - fx/32, fx/32) x (1 - fy/32, fy/32), taps outside the image
+# read the constant border value.
+# ---------------------------------------------------------------------------------------------------------------
+_INTER_BITS, _AB_BITS = 5, 10
+_TAB = 1 << _INTER_BITS
+
+
+def _bilinear_q5(img, X, Y, border):
+    """img sampled at fixed-point coordinates X, Y (int64 arrays, 1/32 pixel)."""
+    h, w = img.shape
+    sx, sy = X >> _INTER_BITS, Y >> _INTER_BITS
+    fx = (X & (_TAB - 1)).astype(np.float32) / _TAB
+    fy = (Y & (_TAB - 1)).astype(np.float32) / _TAB
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        return np.where(ok, img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], np.float32(border)).astype(np.float32)
+    top = tap(sy, sx) * (1 - fx) + tap(sy, sx + 1) * fx
+    bot = tap(sy + 1, sx) * (1 - fx) + tap(sy + 1, sx + 1) * fx
+    return (top * (1 - fy) + bot * fy).astype(np.float32)
+
+
+def _invert_affine(M):
+    """cv2.warpAffine without WARP_INVERSE_MAP maps dst -> src through the inverse of the 2x3 matrix."""
+    M = np.asarray(M, np.float64)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22, A12, A21 = M[1, 1] * D, M[0, 0] * D, -M[0, 1] * D, -M[1, 0] * D
+    return np.array([[A11, A12, -A11 * M[0, 2] - A12 * M[1, 2]], [A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]])
+
+
+def warp_affine(img, M, dsize, border=0.0):
+    """cv2.warpAffine(img, M, (w, h), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=border)."""
+    w, h = int(dsize[0]), int(dsize[1])
+    iM = _invert_affine(M)
+    scale = float(1 << _AB_BITS)
+    rd = (1 << _AB_BITS) // _TAB // 2
+    xs, ys = np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64)
+    adelta = np.rint(iM[0, 0] * xs * scale).astype(np.int64)
+    bdelta = np.rint(iM[1, 0] * xs * scale).astype(np.int64)
+    X0 = np.rint((iM[0, 1] * ys + iM[0, 2]) * scale).astype(np.int64) + rd
+    Y0 = np.rint((iM[1, 1] * ys + iM[1, 2]) * scale).astype(np.int64) + rd
+    X = (X0[:, None] + adelta[None, :]) >> (_AB_BITS - _INTER_BITS)
+    Y = (Y0[:, None] + bdelta[None, :]) >> (_AB_BITS - _INTER_BITS)
+    return _bilinear_q5(np.asarray(img, np.float32), X, Y, border)
+
+
+def warp_perspective(img, H, dsize, border=0.0):
+    """cv2.warpPerspective(img, H, (w, h), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=border)."""
+    w, h = int(dsize[0]), int(dsize[1])
+    iH = np.linalg.inv(np.asarray(H, np.float64))
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    W = iH[2, 0] * xs + iH[2, 1] * ys + iH[2, 2]
+    W = np.where(W != 0, _TAB / np.where(W != 0, W, 1.0), 0.0)
+    fX = np.clip((iH[0, 0] * xs + iH[0, 1] * ys + iH[0, 2]) * W, -2.0 ** 31, 2.0 ** 31 - 1)
+    fY = np.clip((iH[1, 0] * xs + iH[1, 1] * ys + iH[1, 2]) * W, -2.0 ** 31, 2.0 ** 31 - 1)
+    return _bilinear_q5(np.asarray(img, np.float32), np.rint(fX).astype(np.int64), np.rint(fY).astype(np.int64), border)
+
+
+def rotation_matrix_2d(center, angle_deg, scale=1.0):
+    """cv2.getRotationMatrix2D: positive angles rotate counter-clockwise in image coordinates (origin top-left)."""
+    a = np.deg2rad(angle_deg)
+    alpha, beta = scale * np.cos(a), scale * np.sin(a)
+    return np.array([[alpha, beta, (1 - alpha) * center[0] - beta * center[1]], [-beta, alpha, beta * center[0] + (1 - alpha) * center[1]]])
+
+
+def rotate_pts(pt, center, angle_deg):
+    """loader.py:242-252."""
+    a = angle_deg * np.pi / 180.0
+    out = pt.copy()
+    dx, dy = pt[:, 0] - center[0], pt[:, 1] - center[1]
+    out[:, 0] = dx * np.cos(a) - dy * np.sin(a)        # stored in pt's dtype (float32 from xyz2uvd) before the centre is
+    out[:, 1] = dx * np.sin(a) + dy * np.cos(a)        # added back: two roundings, like the reference
+    out[:, :2] += center[:2]
+    return out.astype(np.float32)
+
+
+class Augmenter:
+    """The reference's per-sample augmentation (loader.py:53-179): one of translate (3D shift of the crop centre), scale
+    (cube size) or rotate (in-plane, about the crop centre), or nothing, drawn from ONE RandomState(23455) per dataset
+    object (loader.py:11 -- DataLoader workers therefore replay identical streams, as in the reference)."""
+
+    OPS = ("trans", "scale", "rot", None)
+
+    def __init__(self, paras=PARAS, flip=-1, seed=23455):
+        self.paras, self.flip = paras, flip
+        self.seed = np.random.RandomState(seed)
+
+    def random_aug(self, sigma_trans=None, sigma_scale=None, sigma_rot=None):
+        """loader.py:53-73 (same draws in the same order)."""
+        sigma_trans = 35.0 if sigma_trans is None else sigma_trans
+        sigma_scale = 0.05 if sigma_scale is None else sigma_scale
+        sigma_rot = 180.0 if sigma_rot is None else sigma_rot
+        op = self.OPS[self.seed.randint(0, len(self.OPS))]
+        trans = self.seed.randn(3) * sigma_trans
+        scale = abs(1.0 + self.seed.randn() * sigma_scale)
+        rot = self.seed.uniform(-sigma_rot, sigma_rot)
+        return op, trans, scale, rot
+
+    def _xyz(self, uvd):
+        return uvd2xyz(uvd, self.paras, self.flip)
+
+    def _uvd(self, xyz):
+        return xyz2uvd(xyz, self.paras, self.flip)
+
+    def recrop(self, img, center, cube, M, M_inv, dsize, thresh_z=True, bg=0.0, nv_val=0.0):
+        """loader.py:123-137: re-sample the crop for a new centre / cube, clean the interpolation fringe, clamp to the cube."""
+        img = warp_perspective(img, np.dot(M, M_inv), dsize, border=float(bg))
+        img[img < nv_val] = bg
+        if thresh_z:
+            _, _, _, _, zstart, zend = center2bounds(center, cube, self.paras)
+            near = np.logical_and(img < zstart, img != 0)
+            far = np.logical_and(img > zend, img != 0)
+            img[near] = zstart
+            img[far] = 0.0
+        return img.astype(np.float32)
+
+    def translate(self, img, jt_xyz, center, cube, M, trans, pad_value=0):
+        """loader.py:103-121."""
+        if np.allclose(trans, 0.0):
+            return img, jt_xyz, center, M
+        new_center = self._uvd(self._xyz(center) + trans)
+        if not np.allclose(center[2], 0.0) or np.allclose(new_center[2], 0.0):
+            new_M = center2transmat(new_center, cube, np.array(img.shape), self.paras)
+            img = self.recrop(img, new_center, cube, new_M, np.linalg.inv(M), img.shape, thresh_z=True, bg=pad_value,
+                              nv_val=np.min(img[img > 0]) - 1)
+        else:
+            new_M = M
+        jt_xyz = jt_xyz + self._xyz(center) - self._xyz(new_center)
+        return img, jt_xyz, new_center, new_M
+
+    def rotate(self, img, jt_xyz, center, rot, pad_value=0):
+        """loader.py:140-160."""
+        if np.allclose(rot, 0.0):
+            return img, jt_xyz
+        rot = np.mod(rot, 360)
+        rotM = rotation_matrix_2d((img.shape[1] // 2, img.shape[0] // 2), -rot, 1)
+        img = warp_affine(img, rotM, (img.shape[1], img.shape[0]), border=pad_value)
+        center_xyz = self._xyz(center)
+        jt_uvd = rotate_pts(self._uvd(jt_xyz + center_xyz), center, rot)
+        return img, self._xyz(jt_uvd) - center_xyz
+
+    def scale(self, img, center, cube, M, scale, pad_value=0):
+        """loader.py:163-179."""
+        if np.allclose(scale, 1.0):
+            return img, cube, M
+        new_cube = cube * scale
+        if not np.allclose(center[2], 0.0):
+            new_M = center2transmat(center, new_cube, np.array(img.shape), self.paras)
+            img = self.recrop(img, center, new_cube, new_M, np.linalg.inv(M), img.shape, bg=pad_value, nv_val=np.min(img[img > 0]) - 1)
+        else:
+            new_M = M
+        return img, new_cube, new_M
+
+    def augment(self, img, jt_xyz, center, cube, M, op, trans, scale, rot):
+        """loader.py:75-86."""
+        depth_max = img.max()
+        if op == "trans":
+            img, jt_xyz, center, M = self.translate(img, jt_xyz, center, cube, M, trans)
+        elif op == "rot":
+            img, jt_xyz = self.rotate(img, jt_xyz, center, rot)
+        elif op == "scale":
+            img, cube, M = self.scale(img, center, cube, M, scale)
+        return normalize(depth_max, img, center, cube), jt_xyz, cube, center, M
+
+
 class NYU(torch.utils.data.Dataset):
     def __init__(self, root, phase, val=False, img_size=128, aug_para=None, cube=(300, 300, 300), jt_num=14):
         assert phase in ("train", "test")
@@ -135,6 +305,7 @@ class NYU(torch.utils.data.Dataset):
         self.files, self.centers = files[:n], centers[:n]
         self.test_cube = np.ones([max(n, 8252), 3]) * self.cube
         self.test_cube[2440:, :] = self.test_cube[2440:, :] * 5.0 / 6.0           # nyu_loader.py:31-32
+        self.aug = Augmenter(self.paras, self.flip)
         print("loading dataset, containing %d images." % n)
 
     def __len__(self):
@@ -148,7 +319,12 @@ class NYU(torch.utils.data.Dataset):
         center_uvd = xyz2uvd(center_xyz, self.paras, self.flip).astype(np.float64)
         jt_xyz -= center_xyz
         img, M = crop(img, center_uvd, cube, self.dsize, self.paras)
-        img = normalize(img.max(), img, center_xyz, cube)
+        if self.phase == "train" and not self.val:                               # nyu_loader.py:55-60
+            op, trans, scale, rot = self.aug.random_aug(*(self.aug_para or (None, None, None)))
+            img, jt_xyz, cube, center_uvd, M = self.aug.augment(img, jt_xyz, center_uvd, cube, M, op, trans, scale, rot)
+            center_xyz = uvd2xyz(center_uvd, self.paras, self.flip)
+        else:
+            img = normalize(img.max(), img, center_xyz, cube)
         jt_uvd = transform_jt_uvd(xyz2uvd(jt_xyz + center_xyz, self.paras, self.flip), M)
         jt_uvd[:, :2] = jt_uvd[:, :2] / (self.img_size / 2.0) - 1
         jt_uvd[:, 2] = (jt_uvd[:, 2] - center_xyz[2]) / (cube[2] / 2.0)

@@ -83,3 +83,79 @@ def test_dataset_end_to_end_on_synthetic_directory(ND, tmp_path):
     ev = EvalUtil(128, ND.PARAS, -1, 14)
     ev.feed(jt_uvd.numpy(), jt_xyz.numpy(), center_xyz.numpy(), M.numpy(), cube.numpy())
     assert ev.get_measures()[0] < 0.05                                               # mm
+
+
+def test_warps_follow_opencv_sampling_rule(ND):
+    """cv2.warpAffine / warpPerspective (INTER_LINEAR, BORDER_CONSTANT) restated: identity, whole-pixel shifts, half-pixel
+    interpolation, border value, 1/32-pixel coordinate quantisation."""
+    rng = np.random.RandomState(0)
+    img = (rng.rand(32, 40) * 100 + 500).astype(np.float32)
+    eye2 = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    assert np.array_equal(ND.warp_affine(img, eye2, (40, 32)), img)
+    assert np.array_equal(ND.warp_perspective(img, np.eye(3), (40, 32)), img)
+    sh = ND.warp_affine(img, np.array([[1.0, 0, 3], [0, 1.0, -2]]), (40, 32), border=7.0)        # dst(x,y) = src(x-3, y+2)
+    assert np.array_equal(sh[:30, 3:], img[2:, :37]) and np.all(sh[:, :3] == 7.0) and np.all(sh[30:, :] == 7.0)
+    half = ND.warp_affine(img, np.array([[1.0, 0, 0.5], [0, 1.0, 0]]), (40, 32))                 # dst(x) = src(x - 0.5)
+    np.testing.assert_allclose(half[:, 1:], 0.5 * (img[:, :-1] + img[:, 1:]), rtol=1e-6)
+    np.testing.assert_allclose(half[:, 0], 0.5 * img[:, 0], rtol=1e-6)                             # the other tap is the border (0)
+    # coordinates are quantised to 1/32 pixel: a 1/100-pixel shift samples at round(0.01 * 32) / 32 = 0
+    tiny = ND.warp_perspective(img, np.array([[1.0, 0, 0.01], [0, 1.0, 0], [0, 0, 1.0]]), (40, 32))
+    assert np.array_equal(tiny, img)
+    # rotating twice by 180 degrees about the pixel centre (w//2, h//2) returns the interior
+    R = ND.rotation_matrix_2d((20, 16), 180, 1)
+    back = ND.warp_affine(ND.warp_affine(img, R, (40, 32)), R, (40, 32))
+    np.testing.assert_allclose(back[1:, 1:], img[1:, 1:], rtol=1e-6)
+    np.testing.assert_allclose(R, [[-1, 0, 40], [0, -1, 32]], atol=1e-12)
+
+
+def test_augmentation_matches_reference_vectors(ND, golden_dir):
+    """tests/golden/loader_aug.npz: the reference's Loader.random_aug / augment (dataloader/loader.py:53-179) run on the same
+    inputs with cv2's three resamplers delegated to the numpy restatements: random stream, chosen op, joints, cube, centre and
+    crop matrix agree exactly."""
+    g = np.load(os.path.join(golden_dir, "loader_aug.npz"))
+    aug = ND.Augmenter(ND.PARAS, -1)
+    rng = np.random.RandomState(int(g["seed"]))
+    yy, xx = np.mgrid[0:480, 0:640]
+    ops_seen = set()
+    for i, d in enumerate(g["draws"]):
+        op, trans, scale, rot = aug.random_aug(10, 0.1, 180)
+        assert ND.Augmenter.OPS.index(op) == int(d[0])
+        np.testing.assert_array_equal(np.concatenate([trans, [scale, rot]]), d[1:])
+        ops_seen.add(op)
+        c_xyz = np.array([rng.uniform(-120, 120), rng.uniform(-90, 90), rng.uniform(600, 900)])
+        c_uvd = ND.xyz2uvd(c_xyz, ND.PARAS, -1).astype(np.float64)
+        depth = np.full((480, 640), 1400.0, np.float32)
+        hand = (xx - c_uvd[0]) ** 2 + (yy - c_uvd[1]) ** 2 < (60 * 750.0 / c_xyz[2]) ** 2
+        depth[hand] = (c_xyz[2] + 0.25 * (xx[hand] - c_uvd[0]) - 0.15 * (yy[hand] - c_uvd[1])).astype(np.float32)
+        cube = np.array([300.0, 300.0, 300.0])
+        jt = rng.uniform(-100, 100, (14, 3))
+        img, M = ND.crop(depth.copy(), c_uvd, cube, np.array([128, 128]))
+        out = aug.augment(img.copy(), jt.copy(), c_uvd.copy(), cube.copy(), M.copy(), op, trans, scale, rot)
+        flat = np.concatenate([np.asarray(out[k], np.float64).ravel() for k in (1, 2, 3, 4)])
+        np.testing.assert_array_equal(flat, g["case%d" % i])
+        assert abs(float(np.asarray(out[0], np.float64).sum()) - float(g["imgsum%d" % i])) <= 1e-6 * abs(float(g["imgsum%d" % i]))
+        assert out[0].min() >= -1.0 and out[0].max() <= 1.0
+    assert ops_seen == {"trans", "scale", "rot", None}
+
+
+def test_train_phase_yields_augmented_consistent_samples(ND, tmp_path):
+    """phase='train': one of translate / scale / rotate / nothing per sample; whatever was drawn, image and labels stay
+    consistent -- the joints (normalised uvd through the crop matrix) still sit on the hand pixels of the augmented crop."""
+    rng = np.random.RandomState(5)
+    root = str(tmp_path)
+    centers, xyz = _write_fake_nyu(root, 6, rng)
+    os.rename(os.path.join(root, "test"), os.path.join(root, "train"))
+    os.rename(os.path.join(root, "center_test_refined.txt"), os.path.join(root, "center_train_refined.txt"))
+    data = ND.NYU(root, "train", img_size=128, aug_para=[10, 0.1, 180])
+    plain = ND.NYU(root, "train", val=True, img_size=128)
+    changed = 0
+    for i in range(6):
+        img, jt_xyz, jt_uvd, center_xyz, M, cube = data[i]
+        img0 = plain[i][0]
+        assert img.shape == (1, 128, 128) and torch.isfinite(img).all() and torch.isfinite(jt_uvd).all()
+        assert float(img.max()) <= 1.0 and float(img.min()) >= -1.0
+        changed += int(not torch.equal(img, img0))
+        # the synthetic hand is a disc of radius 55 px around the centre in the original image: the crop centre (label 0,0
+        # after normalisation = the hand centre) must be foreground, the far corner background
+        assert float(img[0, 64, 64]) < 0.99 and float(img[0, 2, 2]) > 0.999
+    assert changed >= 3            # RandomState(23455): trans, scale, scale, None, scale, trans

@@ -293,6 +293,55 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "loader_fns.npz"), centers_xyz=centers_xyz, center_uvd=np.array(u_ref), bounds=np.array(b_ref),
                         M=np.array(m_ref), crop_shape=np.array(c_ref), norm=np.array(n_ref), seed=7)
 
+    # ---- f2 augmentation (dataloader/loader.py:53-179): random stream + label / matrix / cube arithmetic --------------------
+    # The reference calls cv2.warpPerspective / warpAffine / getRotationMatrix2D; cv2 is not installable here, so the stub module
+    # forwards those three to the numpy restatements (nyu_data.py).  What this pins: the RandomState(23455) stream, the choice
+    # logic, centre / joint / cube / matrix arithmetic and the post-warp clean-up.  What it cannot pin: the resamplers themselves.
+    print("[loader augmentation f2]")
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT, cv2.INTER_NEAREST = 1, 0, 0
+    cv2.resize = lambda img, size, interpolation=None: ND.resize_nearest(img, size)
+    cv2.warpPerspective = lambda img, M, dsize, flags=None, borderMode=None, borderValue=0: ND.warp_perspective(img, M, dsize, border=borderValue)
+    cv2.warpAffine = lambda img, M, dsize, flags=None, borderMode=None, borderValue=0: ND.warp_affine(img, M, dsize, border=borderValue)
+    cv2.getRotationMatrix2D = lambda c, a, sc: ND.rotation_matrix_2d(c, a, sc)
+    import dataloader.loader as RL
+    RL.cv2 = cv2
+    ld2 = Loader("unused", "train", 128, "nyu")                # sets RandomState(23455) and aug_ops (loader.py:8-17)
+    ld2.paras, ld2.flip = np.array(ND.PARAS), -1
+    mine = ND.Augmenter(ND.PARAS, -1)
+    draws = []
+    rng = np.random.RandomState(11)
+    yy, xx = np.mgrid[0:480, 0:640]
+    aug_out = {}
+    n_ops = {"trans": 0, "scale": 0, "rot": 0, None: 0}
+    for i in range(12):
+        r = ld2.random_aug(10, 0.1, 180)
+        m = mine.random_aug(10, 0.1, 180)
+        assert r[0] == m[0]
+        check("random_aug", np.concatenate([m[1], [m[2], m[3]]]), np.concatenate([r[1], [r[2], r[3]]]), 0.0)
+        draws.append(np.concatenate([[ld2.aug_ops.index(r[0])], r[1], [r[2], r[3]]]))
+        c_xyz = np.array([rng.uniform(-120, 120), rng.uniform(-90, 90), rng.uniform(600, 900)])
+        c_uvd = ref_xyz2uvd(c_xyz, ld2.paras, ld2.flip).astype(np.float64)
+        depth = np.full((480, 640), 1400.0, np.float32)
+        hand = (xx - c_uvd[0]) ** 2 + (yy - c_uvd[1]) ** 2 < (60 * 750.0 / c_xyz[2]) ** 2
+        depth[hand] = (c_xyz[2] + 0.25 * (xx[hand] - c_uvd[0]) - 0.15 * (yy[hand] - c_uvd[1])).astype(np.float32)
+        cube = np.array([300.0, 300.0, 300.0])
+        jt = rng.uniform(-100, 100, (14, 3))
+        img_r, M_r = ld2.crop(depth.copy(), c_uvd, cube, np.array([128, 128]))
+        img_m, M_m = ND.crop(depth.copy(), c_uvd, cube, np.array([128, 128]))
+        check("crop (resize rule shared)", img_m, img_r, 0.0)
+        check("crop M", M_m, M_r, 0.0)
+        out_r = ld2.augment(img_m.copy(), jt.copy(), c_uvd.copy(), cube.copy(), M_m.copy(), *r)
+        out_m = mine.augment(img_m.copy(), jt.copy(), c_uvd.copy(), cube.copy(), M_m.copy(), *m)
+        for name, a_, b_ in zip(("img", "jt_xyz", "cube", "center", "M"), out_m, out_r):
+            check("augment/%s/%s" % (r[0], name), np.asarray(a_, np.float64), np.asarray(b_, np.float64), 0.0)
+        n_ops[r[0]] += 1
+        aug_out["case%d" % i] = np.concatenate([np.asarray(out_r[1], np.float64).ravel(), np.asarray(out_r[2], np.float64).ravel(),
+                                                np.asarray(out_r[3], np.float64).ravel(), np.asarray(out_r[4], np.float64).ravel()])
+        aug_out["imgsum%d" % i] = np.float64(np.asarray(out_r[0], np.float64).sum())
+    assert all(v > 0 for v in n_ops.values()), n_ops
+    np.savez_compressed(os.path.join(GOLD, "loader_aug.npz"), draws=np.array(draws), seed=11, **aug_out)
+
     json.dump(report, open(os.path.join(GOLD, "pin_report.json"), "w"), indent=1)
     print("golden vectors written to", GOLD)
     os.system("du -sh %s" % GOLD)
