@@ -61,3 +61,8 @@ class EvalUtil:
         pck = (e[None, :, :] <= th[:, None, None]).mean(1).T            # (J, 100)
         auc = np.mean([trapz(pck[j], th) / norm for j in range(e.shape[1])])
         return mean, med, auc, pck.mean(0), th
+
+    def plot_pck(self, path, pck_curve_all, thresholds):
+        """eval_tool.py:124-135 (PIL instead of matplotlib)."""
+        from .vis_tool import plot_pck
+        plot_pck(path, pck_curve_all, thresholds)

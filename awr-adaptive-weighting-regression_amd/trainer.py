@@ -354,6 +354,11 @@ class Trainer:
             self.net = hourglass.PoseNet(config.net, config.jt_num)
         self.net = self.net.cuda()
         self.best_records = {"epoch": 0, "MPE": 1e10, "AUC": 0}
+        try:
+            from .vis_tool import VisualUtil
+            self._vis = VisualUtil(config.dataset)                   # train.py:43
+        except ValueError:
+            self._vis = None
         if getattr(config, "gemm_products", 1) != 1:      # opt-in split-operand GEMMs (process-wide)
             from . import set_gemm_products
             set_gemm_products(config.gemm_products)
@@ -445,8 +450,16 @@ class Trainer:
                 img = torch.cat([img, img[-1:].expand(cfg.batch_size - nb, -1, -1, -1)])
             jt = inf(img.cuda().float())[:nb].cpu().numpy()
             ev.feed_batch(jt, jt_xyz_gt.numpy(), center_xyz.numpy(), M.numpy(), cube.numpy())
+            ib = i0 // cfg.batch_size + 1
+            if self.rank == 0 and getattr(cfg, "vis_freq", 0) and ib % cfg.vis_freq == 0 and self._vis is not None:    # train.py:203-213
+                half = cfg.img_size / 2.0
+                self._vis.plot(items[0][0].numpy() if torch.is_tensor(items[0][0]) else np.asarray(items[0][0]),
+                               os.path.join(self.result_dir, "test_epoch_{}_iter_{}.png".format(epoch, ib)),
+                               (jt[0] + 1) * half, (np.asarray(items[0][2], np.float32) + 1) * half)
         self.net.train()
         mpe, mid, auc, pck, thresh = ev.get_measures()
+        if self.rank == 0:
+            ev.plot_pck(os.path.join(self.work_dir, "test_pck_epoch_{}.png".format(epoch)), pck, thresh)                # train.py:216
         if epoch in (0, -1) and self.rank == 0:                      # train.py:217-221 / test.py:103-108
             jt_uvd = np.array(ev.jt_uvd_pred, dtype=np.float32)
             np.savetxt(os.path.join(self.work_dir, "test_%.3f.txt" % mpe), jt_uvd.reshape([jt_uvd.shape[0], cfg.jt_num * 3]), fmt="%.3f")

@@ -181,3 +181,42 @@ def test_entry_point_overrides_and_dataset_lookup(tmp_path):
     from awr_amd.trainer import Trainer
     with pytest.raises(FileNotFoundError):
         Trainer(cfg)
+
+
+def test_visualisation_and_pck_plot_without_cv2_or_matplotlib(tmp_path):
+    """util/vis_tool.py:17-60 and util/eval_tool.py:124-135 restated with PIL: files are written, the overlay paints the
+    prediction in red and the ground truth in blue at the joint pixels, the PCK curve is a rising line inside the axes."""
+    from PIL import Image
+    from awr_amd.vis_tool import VisualUtil, plot_pck
+    from awr_amd.evaluator import EvalUtil
+    rng = np.random.RandomState(0)
+    img = np.full((1, 128, 128), 1.0, np.float32)
+    img[0, 40:90, 40:90] = -0.2
+    pred = np.concatenate([rng.uniform(30, 100, (14, 2)), np.zeros((14, 1))], 1).astype(np.float32)
+    gt = pred + np.array([6.0, -5.0, 0.0], np.float32)
+    path = os.path.join(str(tmp_path), "overlay.png")
+    VisualUtil("nyu").plot(img, path, pred)
+    rgb = np.asarray(Image.open(path).convert("RGB")).astype(np.int64)
+    assert rgb.shape == (128, 128, 3)
+    for j in range(14):
+        u, v = int(pred[j, 0]), int(pred[j, 1])
+        assert rgb[v, u, 0] > rgb[v, u, 2], j                         # red dominates at predicted joints
+    VisualUtil("nyu").plot(img, path, pred, gt)                        # ground truth is painted on top, in blue
+    rgb = np.asarray(Image.open(path).convert("RGB")).astype(np.int64)
+    for j in range(14):
+        u, v = int(gt[j, 0]), int(gt[j, 1])
+        assert rgb[v, u, 2] > rgb[v, u, 0], j
+    assert tuple(rgb[2, 2]) == (200, 200, 200)                          # background depth 1.0 -> (1 + 1) * 100
+    with pytest.raises(ValueError):
+        VisualUtil("unknown-set")
+    assert len(VisualUtil("hands17").fingers) == 5 and VisualUtil("hands17").fingers[4][0][-1] == 0
+    thr = np.linspace(0, 50, 100)
+    pck = 1.0 - np.exp(-thr / 10.0)
+    p2 = os.path.join(str(tmp_path), "pck.png")
+    plot_pck(p2, pck, thr)
+    EvalUtil(128, (588.03, 587.07, 320.0, 240.0), -1, 14).plot_pck(os.path.join(str(tmp_path), "pck2.png"), pck, thr)
+    chart = np.asarray(Image.open(p2).convert("RGB")).astype(np.int64)
+    blue = (chart[:, :, 2] > 150) & (chart[:, :, 0] < 80)
+    cols = np.where(blue.any(0))[0]
+    first_row = np.array([np.where(blue[:, c])[0].min() for c in cols])
+    assert cols.size > 200 and first_row[0] > first_row[-1] + 100      # the curve climbs from the bottom-left to the top-right

@@ -274,10 +274,12 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     log = open(os.path.join(work, "resnet_18_dense.log")).read()
     assert "[epoch 01], [train loss" in log and "[epoch  3], [test mpe" in log and "learning rate: 1.0e-03" in log
     assert abs(tr.engine.lr - 1e-3 * 0.1 ** (3 // 2)) < 1e-12                     # StepLR(step_size=2, gamma=0.1).step(3)
+    assert os.path.exists(os.path.join(work, "test_pck_epoch_0.png"))                 # train.py:216
+    assert any(f.startswith("test_epoch_0_iter_") for f in os.listdir(os.path.join(work, "results")))   # train.py:203-213 (vis_freq = 1)
     losses = [float(l.split("[train loss ")[1].split("]")[0]) for l in log.splitlines() if l.startswith("[epoch 0") and "train mpe" in l]
     assert len(losses) == 3 and losses[-1] < losses[0]
     assert np.isfinite(mpe0) and any(f.startswith("test_") and f.endswith(".txt") for f in os.listdir(work))
-    txt = np.loadtxt(os.path.join(work, [f for f in os.listdir(work) if f.startswith("test_")][0]))
+    txt = np.loadtxt(os.path.join(work, [f for f in os.listdir(work) if f.startswith("test_") and f.endswith(".txt")][0]))
     assert txt.shape == (12, 42)                                                   # results/*.txt format (test.py:105-108)
     pth = torch.load(os.path.join(work, "epoch_3.pth"), weights_only=False)
     assert set(pth) == {"model", "optimizer", "best_records"} and len(pth["model"]) == 142
