@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
-    const int r0 = tid >> 3;            // first row it stages (then +32, +64, ...)
+    // first row it stages (then +32, +64, ...).  Split mode: the 8-byte LDS stores of a 16-lane group cover two rows; with rows
+    // r, r+1 (208-byte pitch = 52 banks) they collide on 4 of 32 banks (PMC: 6.5 M conflict cycles per launch, though no
+    // measurable time: LDS stores are paced by the VGPR -> LDS transfer); rows r, r+4 sit exactly 16 banks apart, so bits 0 and
+    // 2 of the row index are swapped.
+    const int r0 = NP ? (((tid >> 3) & 0x1a) | (((tid >> 3) & 1) << 2) | (((tid >> 3) >> 2) & 1)) : (tid >> 3);
 
     // decode the A rows this thread stages (fixed for the whole K loop); byte offsets are 32-bit (tensors < 4 GB)
     int a_iy[RA], a_ix[RA];
@@ -323,7 +327,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     if constexpr (NP != 0) {
 #pragma unroll
         for (int i = 0; i < RB3; ++i) {
-            const int q = tid + 256 * i, row = q / 12, piece = q - 12 * row;
+            // 12 sixteen-byte pieces per row: pieces 0-7 as one 8-lane store group per row (a full 32-bank line), pieces 8-11 as
+            // groups of two rows that are 4 rows (= 16 banks) apart -> every 16-byte LDS store group touches 32 distinct banks
+            int row, piece;
+            if (i < 2 * TN) {
+                const int q = tid + 256 * i;
+                row = q >> 3;
+                piece = q & 7;
+            } else {
+                const int q = tid + 256 * (i - 2 * TN), g = q >> 3, t = q & 7;
+                row = (((g >> 2) << 3) | (g & 3)) + 4 * (t >> 2);
+                piece = 8 + (t & 3);
+            }
             w3_off[i] = (unsigned)(tile_n * BN + row) * a.T * (a.Cin / BK) * (6u * BK) + 16u * piece;
             w3_lds[i] = (unsigned)(row * ROWB + 16 * piece);
         }
