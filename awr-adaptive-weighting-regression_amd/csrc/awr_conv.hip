@@ -85,9 +85,9 @@ __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __b
 
 // four consecutive k of one LDS row: three 8-byte stores (h, m, l planes)
 #ifndef AWR_PROBE
-#define AWR_PROBE 0      // bottleneck probes (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores / 2nd barrier,
-#endif                   // 3 = both, 4 = both + no LDS fragment reads (MFMA only); split mode: 6 = activation split free.
-                         // Results are wrong by construction; never shipped.
+#define AWR_PROBE 0      // bottleneck probes of the FP32 K loop (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores /
+#endif                   // 2nd barrier, 3 = both, 4 = both + no LDS fragment reads (MFMA only); 6 = split-mode weight-gradient staging without
+                         // the split arithmetic.  Results are wrong by construction; never shipped.
 __device__ __forceinline__ void store_split4(char* row_k, float4 v) {
     if (AWR_PROBE == 6) {      // probe: the three stores without the split arithmetic
         *reinterpret_cast<uint2*>(row_k) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
