@@ -1,0 +1,40 @@
+"""Worker of tests/test_dp_gpu.py: one rank of a 2-rank data-parallel TrainEngine run.  Both ranks share GPU 0; the process
+group is gloo (it accepts CUDA tensors and stages them through the host), which exercises exactly the code path RCCL takes on a
+multi-GPU node: rank-0 broadcast of parameters / BN buffers, bucket hooks inside the backward, async all-reduce + wait, 1/world
+in the optimiser."""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+
+def main():
+    rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import awr_amd
+    import awr_oracle as O
+    from awr_amd.trainer import TrainEngine
+    res = {}
+    for mode, steps in (("same", 2), ("split", 1)):
+        torch.manual_seed(1234 + rank)                   # different initial weights per rank: the broadcast must fix that
+        net = awr_amd.get_deconv_net(18, 14, 2).cuda()
+        eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, process_group=torch.distributed.group.WORLD, use_graph=False, autotune=False)
+        assert eng.dp and eng.world == world and len(eng.sync.buckets) > 1
+        losses = []
+        for s in range(steps):
+            img, jt = O.synth_batch(2, 128, 14, seed=70 + s + (0 if mode == "same" else 10 * rank))
+            l, _ = eng.step(img.cuda(), jt.cuda())
+            losses.append(float(l[2]))
+        torch.cuda.synchronize()
+        res[mode] = {"params": net.flat_params()[:net.n_active].cpu(), "buffers": net._barena.cpu(), "losses": losses}
+    torch.save(res, "%s.rank%d" % (out, rank))
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

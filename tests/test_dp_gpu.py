@@ -1,0 +1,60 @@
+"""GPU: the complete data-parallel TrainEngine path with TWO real ranks (both on GPU 0, gloo process group over CUDA tensors):
+what the 8-GPU RCCL run does, minus the transport."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(str(tmp_path), "dp")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    return [torch.load("%s.rank%d" % (out, r)) for r in range(2)]
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_data_parallel_engine(tmp_path):
+    """(a) Both ranks feed the SAME shard: the averaged gradient equals each rank's own, so two data-parallel steps must land on
+    the parameters of a single-process run from rank 0's initial weights (the broadcast replaced rank 1's).  (b) Different shards
+    per rank: losses differ, parameters do not (every rank applies the same averaged gradient), BN running statistics stay
+    rank-local (what stock DDP does)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import awr_amd
+    import awr_oracle as O
+    from awr_amd.trainer import TrainEngine
+    r0, r1 = _run(tmp_path)
+    a0, a1 = r0["same"], r1["same"]
+    assert torch.equal(a0["params"], a1["params"]) and torch.equal(a0["buffers"], a1["buffers"])
+    torch.manual_seed(1234)
+    net = awr_amd.get_deconv_net(18, 14, 2).cuda()
+    eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, use_graph=False, autotune=False)
+    ref_losses = []
+    for s in range(2):
+        img, jt = O.synth_batch(2, 128, 14, seed=70 + s)
+        ref_losses.append(float(eng.step(img.cuda(), jt.cuda())[0][2]))
+    ref = net.flat_params()[:net.n_active].cpu()
+    assert abs(a0["losses"][0] - ref_losses[0]) <= 1e-6 * abs(ref_losses[0])
+    d = (a0["params"] - ref).abs()
+    # same arithmetic up to the summation order of atomics; two Adam steps move every weight by <= 2 lr
+    assert float(d.quantile(0.99)) <= 2e-4 and float(d.max()) <= 2.1e-3, (float(d.quantile(0.99)), float(d.max()))
+    b0, b1 = r0["split"], r1["split"]
+    assert b0["losses"] != b1["losses"]
+    assert torch.equal(b0["params"], b1["params"])
+    assert not torch.equal(b0["buffers"], b1["buffers"])
