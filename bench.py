@@ -114,7 +114,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("AWR_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # AWR_FORCE_DEVICE: test hook (several ranks on one GPU)
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -123,7 +123,8 @@ def main():
     pg = None
     if world > 1 or os.environ.get("AWR_FORCE_DP") == "1":      # AWR_FORCE_DP: exercise the data-parallel path on a 1-rank group (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("AWR_DIST_BACKEND", "nccl")        # "nccl" is RCCL on ROCm; tests run the same path over gloo on one GPU
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
         pg = torch.distributed.group.WORLD
 
     import awr_amd

@@ -42,3 +42,20 @@ def test_bench_under_torchrun_with_forced_dp_path():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp1" and d["value"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_exactly_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: two real ranks (sharing GPU 0, gloo instead of
+    RCCL -- the only difference to the 8-GPU run): one JSON line from rank 0, whole-job throughput, weak scaling."""
+    env = dict(os.environ, AWR_DIST_BACKEND="gloo", AWR_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=1100, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = _last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "cpu_baseline" not in d and "split_mode" not in d            # rank-0-at-N=1 extras only
