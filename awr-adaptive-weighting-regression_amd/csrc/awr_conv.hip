@@ -525,29 +525,58 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             for (int i = 0; i < RB3; ++i) st4(reinterpret_cast<float*>(Bs + w3_lds[i]), rb[i]);
         };
         float4 sc, sh;
+        float4 r2[RA];
+        unsigned ok2 = 0;
+        int c2 = 0;
         load_a(r1, 0); ok1 = tapmask; c1 = 0;
         load_b(0);
         coef(0, sc, sh);
         split_rows(r1, ok1, sc, sh, 0, RA);
         store_sb();
+        if (ksteps > 1) {            // slice 1: activation rows into r1, weight pieces into rb
+            advance();
+            load_a(r1, c0); ok1 = tapmask; c1 = c0;
+            load_b(c0);
+        }
         __syncthreads();
         // one basic block: fragment reads and MFMAs of the slice in LDS, the cut of the next slice inside the second half
-        auto multiply_and_cut = [&]() {
+        auto multiply_and_cut = [&](const float4 (&rows)[RA], unsigned okm) {
             bf16x8 fa[TM][3], fb[TN][3];
             load_split_frags<TM, TN>(a_frag, b_frag, fa, fb);
             mfma_split16<TM, TN, NP>(fa, fb, acc);
             load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
             __builtin_amdgcn_sched_barrier(0);
             mfma_split16<TM, TN, NP>(fa, fb, acc, [&](int q) {
-                if (q < RA) split_rows(r1, ok1, sc, sh, q, q + 1);
+                if (q < RA) split_rows(rows, okm, sc, sh, q, q + 1);
             });
         };
-        for (int ks = 0; ks + 1 < ksteps; ++ks) {
+        // Activation rows travel two slices ahead in two register sets that swap roles every slice (the loop is unrolled
+        // by two, no register copies): the rows cut during slice k were requested during slice k-1.
+        int ks = 0;
+        for (; ks + 2 < ksteps; ks += 2) {
             advance();
-            load_a(r1, c0); ok1 = tapmask; c1 = c0;
-            load_b(c0);
+            load_a(r2, c0); ok2 = tapmask; c2 = c0;        // slice ks+2
             coef(c1, sc, sh);
-            multiply_and_cut();
+            multiply_and_cut(r1, ok1);                      // slice ks from LDS, cut slice ks+1 (r1)
+            __syncthreads();
+            store_sb();
+            load_b(c2);                                     // weight pieces of slice ks+2 (same tap state as r2)
+            __syncthreads();
+            const bool more3 = ks + 3 < ksteps;
+            if (more3) {
+                advance();
+                load_a(r1, c0); ok1 = tapmask; c1 = c0;    // slice ks+3
+            }
+            coef(c2, sc, sh);
+            multiply_and_cut(r2, ok2);                      // slice ks+1 from LDS, cut slice ks+2 (r2)
+            __syncthreads();
+            store_sb();
+            if (more3) load_b(c1);
+            __syncthreads();
+        }
+        if (ks + 1 < ksteps) {       // one slice left to stage (r1 holds it)
+            coef(c1, sc, sh);
+            multiply_and_cut(r1, ok1);
             __syncthreads();
             store_sb();
             __syncthreads();
