@@ -253,7 +253,12 @@ class AwrBackbone(nn.Module):
         return plan
 
     def _sig(self):
-        return (self._arena._version, self._barena._version, self._stats_version, self._arena.data_ptr())
+        # Version counters of the Parameter / buffer OBJECTS, not of the arenas: `_rebind()` re-points `param.data` at arena
+        # views, which keeps each parameter's own counter, so an in-place update through the parameters (stock
+        # torch.optim step, nn.init, load_state_dict) never bumps `self._arena._version`.
+        pv = sum(p._version for p in self.parameters())
+        bv = sum(b._version for b in self.buffers())
+        return (pv, bv, self._arena._version, self._barena._version, self._stats_version, self._arena.data_ptr())
 
     def weights_changed(self):
         """Tell the module that kernels modified parameters / running stats through raw pointers."""
@@ -285,7 +290,9 @@ class AwrBackbone(nn.Module):
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, plan, x, *params):
-        net.sync_weights(plan)
+        # training forwards always re-pack (one batched launch): the weights normally changed since the last step, and a
+        # missed update (e.g. through `p.data`) would silently train on stale packed copies
+        net.sync_weights(plan, force=plan.training)
         plan.img.copy_(x.detach().float())
         plan.forward()
         if plan.training:

@@ -19,6 +19,7 @@ its own shard of the minibatch, gradients are summed with RCCL all-reduce (torch
 "nccl" == RCCL over xGMI) on the flat gradient arena and scaled by 1/world inside the optimiser
 kernel.  BatchNorm statistics stay rank-local (what stock DDP does).
 """
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -49,10 +50,20 @@ class GradSync:
             for lo, hi in self.buckets:
                 torch.distributed.all_reduce(flat_grad[lo:hi], group=self.pg)
 
+    def global_mean(self, total, count, device=None):
+        """sum(total over ranks) / sum(count over ranks): every rank gets the SAME epoch metric (what drives the LR
+        scheduler and the log lines), whatever its own shard looked like."""
+        if self.world > 1:
+            t = torch.tensor([float(total), float(count)], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, group=self.pg)
+            total, count = float(t[0]), float(t[1])
+        return total / count if count else float("nan")
+
 
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
-                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True, wgrad_streams=2):
+                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True, wgrad_streams=2,
+                 _share=None):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -78,18 +89,24 @@ class TrainEngine:
         self.acc = torch.zeros(2, device=dev, dtype=torch.float64)
         self.losses = torch.zeros(3, device=dev)          # [coord, dense, total]
         n = net.n_active
-        self.m = torch.zeros(n, device=dev)
-        self.v = torch.zeros(n, device=dev) if optimizer == "adam" else None
+        self._children = {}
+        if _share is not None:          # ragged-batch child: optimiser state lives in the parent engine
+            self.m, self.v = _share.m, _share.v
+        else:
+            self.m = torch.zeros(n, device=dev)
+            self.v = torch.zeros(n, device=dev) if optimizer == "adam" else None
         self.step_count = 0
         self.use_graph = use_graph
         self.graph = None
         self._warm = 0
         self.sync = GradSync(n, process_group, n_buckets)
+        self._n_buckets = n_buckets
         self.world = self.sync.world
         self._works = []
         if self.dp:             # identical initial parameters and BN buffers on every rank
-            self.sync.broadcast(net.flat_params(), net._barena)
-            net.weights_changed()
+            if _share is None:
+                self.sync.broadcast(net.flat_params(), net._barena)
+                net.weights_changed()
             self.use_graph = False          # the bucket markers interleave RCCL calls with the backward: run it eagerly
             g = net.flat_grads()
             # torch's NCCL work stream waits for the compute stream at the point of the call and runs concurrently with
@@ -132,9 +149,28 @@ class TrainEngine:
             L.call("awr_sgd_step", L.ptr(net.flat_params()), L.ptr(net.flat_grads()), L.ptr(self.m), n, self.lr, self.momentum, self.wd,
                    self.step_count, scale, s)
 
+    def _ragged(self, b):
+        """Engine for a smaller (last-of-epoch) batch: its own static plan, the SAME optimiser state and step counter
+        (the reference's DataLoader keeps the ragged last batch, train.py:109 drop_last=False)."""
+        eng = self._children.get(b)
+        if eng is None:
+            eng = TrainEngine(self.net, b, self.H, self.ks, self.cw, self.dw, self.lr, self.wd, self.opt, self.momentum,
+                              process_group=self.sync.pg, use_graph=False, n_buckets=self._n_buckets, autotune=False,
+                              wgrad_streams=0, _share=self)
+            self._children[b] = eng
+        eng.lr, eng.step_count = self.lr, self.step_count
+        return eng
+
     def step(self, img, jt_uvd_gt):
         """One optimisation step on this rank's shard.  Returns (losses[coord,dense,total], jt_uvd_pred)
         as device tensors that are valid until the next step; nothing is synchronised."""
+        if img.shape[0] != self.B:
+            if not 0 < img.shape[0] < self.B:
+                raise L.AwrError("TrainEngine built for batches of %d got %d images" % (self.B, img.shape[0]))
+            eng = self._ragged(int(img.shape[0]))
+            out = eng.step(img, jt_uvd_gt)
+            self.step_count = eng.step_count
+            return out
         plan = self.plan
         plan.img.copy_(img, non_blocking=True)
         self.jt_gt.copy_(jt_uvd_gt, non_blocking=True)
@@ -386,43 +422,64 @@ class Trainer:
         print(msg, file=self.log)
 
     def _loader(self, data, shuffle, epoch=0):
-        """train.py:109: DataLoader(batch_size, shuffle=True, num_workers); data parallel: every rank iterates its own
-        1/world shard of the epoch's permutation (DistributedSampler), batch_size images per rank and step."""
+        """train.py:109: DataLoader(batch_size, shuffle=True, num_workers) -- drop_last=False like the reference: the ragged last
+        batch of an epoch is trained on (TrainEngine keeps a second static plan for it).  Data parallel: every rank iterates its
+        own 1/world shard of the epoch's permutation (DistributedSampler pads the shards to equal length, so all ranks see the
+        same batch sizes and the 1/world gradient average stays the global mean), batch_size images per rank and step."""
         sampler = None
         if self.pg is not None:
             sampler = torch.utils.data.distributed.DistributedSampler(data, num_replicas=torch.distributed.get_world_size(self.pg), rank=self.rank,
-                                                                      shuffle=shuffle, drop_last=shuffle)
+                                                                      shuffle=shuffle, drop_last=False)
             sampler.set_epoch(epoch)
         return torch.utils.data.DataLoader(data, batch_size=self.config.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                                           num_workers=int(getattr(self.config, "num_workers", 0)), drop_last=shuffle)
+                                           num_workers=int(getattr(self.config, "num_workers", 0)), drop_last=False)
 
     def train(self):
         cfg, eng = self.config, self.engine
+        dev = self.net.device
+        # train.py:102: ONE evaluator for the whole run -- the reference's `train mpe` (which drives ReduceLROnPlateau) is the
+        # running mean over every frame fed since the start of training, not a per-epoch value.  Reproduced on purpose.
+        ev = self.EvalUtil(self.trainData.img_size, self.trainData.paras, self.trainData.flip, self.trainData.jt_num)
         for epoch in range(self.best_records["epoch"] + 1, cfg.max_epoch + 1):
             self.net.train()
-            ev = self.EvalUtil(self.trainData.img_size, self.trainData.paras, self.trainData.flip, self.trainData.jt_num)
-            lsum, lcnt, pend, last_mean = torch.zeros(3, device=self.net.device), 0, [], float("nan")
+            lsum, lcnt, pend, last_mean = torch.zeros(3, device=dev), 0, [], float("nan")
+
+            def drain():
+                for jt, a, b, c, d in pend:
+                    ev.feed_batch(jt.cpu().numpy(), a.numpy(), b.numpy(), c.numpy(), d.numpy())
+                del pend[:]
+
+            def meter():                # mean of the per-step losses since the last print, identical on every rank
+                if self.pg is None or not lcnt:
+                    return (lsum / max(lcnt, 1)).tolist()
+                t = torch.cat([lsum.double(), torch.tensor([float(lcnt)], dtype=torch.float64, device=dev)])
+                torch.distributed.all_reduce(t, group=self.pg)
+                return (t[:3] / t[3]).tolist()
             for ii, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(self._loader(self.trainData, True, epoch)):
                 losses, jt_pred = eng.step(img.cuda(non_blocking=True), jt_uvd_gt.cuda(non_blocking=True))
                 lsum += losses                                      # device-side meter: no loss.item() per iteration
                 lcnt += 1
                 pend.append((jt_pred.clone(), jt_xyz_gt, center_xyz, M, cube))
                 if (ii + 1) % cfg.print_freq == 0:
-                    l = (lsum / lcnt).tolist()
+                    l = meter()
                     last_mean = l[2]
                     self._msg("[epoch: {:02d}][train loss: {:.5f}][offset_loss: {:.5f}][coord_loss: {:.5f}]".format(epoch, l[2], l[1], l[0]))
                     lsum.zero_()
                     lcnt = 0
-                    for jt, a, b, c, d in pend:
-                        ev.feed_batch(jt.cpu().numpy(), a.numpy(), b.numpy(), c.numpy(), d.numpy())
-                    pend = []
-            for jt, a, b, c, d in pend:
-                ev.feed_batch(jt.cpu().numpy(), a.numpy(), b.numpy(), c.numpy(), d.numpy())
-            train_mpe = ev.get_measures()[0]
-            last = (lsum / lcnt).tolist()[2] if lcnt else last_mean      # meter is reset at every print (train.py:139)
+                    drain()
+            drain()
+            # rank-uniform metric: every rank must feed the SAME number to its LR scheduler, or the replicas would step the
+            # (identical, all-reduced) gradients with different learning rates and silently diverge
+            if ev._err:
+                e = np.concatenate(ev._err, 0).astype(np.float64)
+                train_mpe = eng.sync.global_mean(e.mean(1).sum(), e.shape[0], device=dev)
+            else:
+                train_mpe = eng.sync.global_mean(0.0, 0, device=dev)    # an epoch without a single batch (empty shard)
+            last = meter()[2] if lcnt else last_mean                     # meter is reset at every print (train.py:139)
             self._msg("[epoch {:02d}], [train loss {:.5f}], [train mpe {:.5f}], [lr {:.1e}]".format(epoch, last, train_mpe, eng.lr))
             if cfg.scheduler == "auto":
-                eng.set_lr(self._plateau.step(train_mpe))
+                if train_mpe == train_mpe:                               # NaN (nothing evaluated yet) never steps the plateau counter
+                    eng.set_lr(self._plateau.step(train_mpe))
             elif cfg.scheduler == "step":                          # StepLR(step_size=cfg.step, gamma=0.1).step(epoch)
                 eng.set_lr(cfg.lr * 0.1 ** (epoch // cfg.step))
             if self.testData is not None:

@@ -39,6 +39,9 @@ def _worker(rank, world, port, n, q):
         grads = torch.randn(n, generator=g)
         mine = grads.clone()
         sync.allreduce(grads)
+        # epoch metric that drives the LR scheduler: rank-local error sums / frame counts -> the same global mean everywhere
+        gm = sync.global_mean(10.0 * (rank + 1), 4 + rank)
+        assert abs(gm - 30.0 / 9.0) < 1e-12, gm
         q.put((rank, params[:5].tolist(), bufs[:3].tolist(), mine.double().sum().item(), grads.double().sum().item(),
                (grads * sync.grad_scale)[:4].tolist()))
     finally:
@@ -71,6 +74,7 @@ def test_single_process_is_a_noop():
     g = torch.arange(5000.0)
     s.allreduce(g)
     s.broadcast(g)
+    assert s.global_mean(6.0, 4) == 1.5 and s.global_mean(0.0, 0) != s.global_mean(0.0, 0)      # NaN for an empty epoch
     assert s.world == 1 and s.grad_scale == 1.0 and torch.equal(g, torch.arange(5000.0))
 
 

@@ -159,3 +159,34 @@ def test_train_phase_yields_augmented_consistent_samples(ND, tmp_path):
         # after normalisation = the hand centre) must be foreground, the far corner background
         assert float(img[0, 64, 64]) < 0.99 and float(img[0, 2, 2]) > 0.999
     assert changed >= 3            # RandomState(23455): trans, scale, scale, None, scale, trans
+
+
+def test_resamplers_reproduce_analytic_known_answers(ND):
+    """The three cv2 resamplers are UNPINNED (no cv2 here: tests/golden/pin_report.json "unpinned").  What CAN be pinned without
+    OpenCV: transformations whose exact result any correct nearest / bilinear implementation must produce bit for bit."""
+    rng = np.random.RandomState(3)
+    sq = (rng.rand(24, 24) * 300 + 400).astype(np.float32)
+    img = (rng.rand(32, 40) * 300 + 400).astype(np.float32)
+    # quarter turns about the centre of the pixel grid ((n-1)/2, (n-1)/2): a pure permutation of pixels
+    c = ((24 - 1) / 2.0, (24 - 1) / 2.0)
+    for k in (1, 2, 3):
+        out = ND.warp_affine(sq, ND.rotation_matrix_2d(c, 90 * k, 1.0), (24, 24))
+        assert np.array_equal(out, np.rot90(sq, k)), k                 # cv2: positive angle = counter-clockwise, like np.rot90
+    # half turn of a rectangle about its grid centre: both axes flipped
+    out = ND.warp_affine(img, ND.rotation_matrix_2d(((40 - 1) / 2.0, (32 - 1) / 2.0), 180, 1.0), (40, 32))
+    assert np.array_equal(out, img[::-1, ::-1])
+    # whole-pixel shift through the perspective path, with a border value
+    sh = ND.warp_perspective(img, np.array([[1.0, 0, -4], [0, 1.0, 5], [0, 0, 1.0]]), (40, 32), border=2.5)   # dst(x,y) = src(x+4, y-5)
+    assert np.array_equal(sh[5:, :36], img[:27, 4:]) and np.all(sh[:5] == 2.5) and np.all(sh[:, 36:] == 2.5)
+    # exact x2 magnification (dst(x) = src(x/2)): even samples are the source pixels, odd samples the mean of two neighbours
+    up = ND.warp_affine(img, np.array([[2.0, 0, 0], [0, 2.0, 0]]), (80, 64))
+    assert np.array_equal(up[::2, ::2], img)
+    assert np.array_equal(up[::2, 1:-1:2], (img[:, :-1] * np.float32(0.5) + img[:, 1:] * np.float32(0.5)).astype(np.float32))
+    assert np.array_equal(up[::2, -1], (img[:, -1] * np.float32(0.5)).astype(np.float32))       # right neighbour = border (0)
+    # exact x1/2 minification samples the even source pixels
+    dn = ND.warp_affine(img, np.array([[0.5, 0, 0], [0, 0.5, 0]]), (20, 16))
+    assert np.array_equal(dn, img[::2, ::2])
+    # INTER_NEAREST: integer zoom factors are pure index arithmetic
+    assert np.array_equal(ND.resize_nearest(img, (20, 16)), img[::2, ::2])
+    assert np.array_equal(ND.resize_nearest(img, (80, 64)), np.repeat(np.repeat(img, 2, 0), 2, 1))
+    assert np.array_equal(ND.resize_nearest(img, (120, 96)), np.repeat(np.repeat(img, 3, 0), 3, 1))
