@@ -63,22 +63,39 @@ __device__ __forceinline__ void store_split_elem(void* split, int64_t idx, float
     o[64] = (unsigned short)(l >> 16);
 }
 
-__global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* __restrict__ jobs, int n, int64_t total) {
-    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gidx >= total) return;
-    const awr_pack_job jb = jobs[find_job(jobs, n, gidx)];
-    const int64_t idx = gidx - jb.first;
-    const int c = (int)(idx % jb.ld);
-    const int t = (int)((idx / jb.ld) % jb.T);
-    const int r = (int)(idx / ((int64_t)jb.ld * jb.T));
-    float v = 0.f;
-    if (!jb.transpose) {
-        if (r < jb.d0 && c < jb.d1) v = jb.src[((int64_t)r * jb.d1 + c) * jb.T + t];
-    } else {
-        if (r < jb.d1 && c < jb.d0) v = jb.src[((int64_t)c * jb.d1 + r) * jb.T + t];
+// Batched repack, one workgroup per packed ROW r (all taps, all inner channels): the row's source elements are read in the
+// order they lie in the checkpoint tensor (contiguous for transpose == 0, T-float pieces for transpose != 0), bounced through
+// an LDS tile laid out [c][t] with an odd pitch, and written as T contiguous ld-float lines.  (The first version gathered one
+// element per thread with a stride of T floats: 9x the read traffic on 3x3 layers, 222 us per ResNet18 step.)
+constexpr int PACK_TILE = 8192;      // floats of LDS per workgroup
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* __restrict__ jobs, int n) {
+    __shared__ float tile[PACK_TILE + 64];
+    const awr_pack_job jb = jobs[find_job(jobs, n, (int64_t)blockIdx.x)];
+    const int r = (int)((int64_t)blockIdx.x - jb.first);
+    const int T = jb.T, TS = T | 1, ld = jb.ld;
+    const int inner = jb.transpose ? jb.d0 : jb.d1, valid_rows = jb.transpose ? jb.d1 : jb.d0;
+    const bool rok = r < valid_rows;
+    const int cch = (PACK_TILE / TS) & ~31;
+    for (int c0 = 0; c0 < ld; c0 += cch) {
+        const int cc = ld - c0 < cch ? ld - c0 : cch;
+        for (int i = threadIdx.x; i < cc * T; i += 256) {
+            const int c = i / T, t = i - c * T;
+            float v = 0.f;
+            if (rok && c0 + c < inner)
+                v = jb.transpose ? jb.src[((int64_t)(c0 + c) * jb.d1 + r) * T + t] : jb.src[((int64_t)r * jb.d1 + c0 + c) * T + t];
+            tile[c * TS + t] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cc * T; i += 256) {
+            const int t = i / cc, c = i - t * cc;
+            const float v = tile[c * TS + t];
+            const int64_t o = ((int64_t)r * T + t) * ld + c0 + c;
+            jb.dst[o] = v;
+            if (jb.split) store_split_elem(jb.split, o, v);
+        }
+        __syncthreads();
     }
-    jb.dst[idx] = v;
-    if (jb.split) store_split_elem(jb.split, idx, v);
 }
 
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ packed, void* __restrict__ split, int64_t n) {
@@ -86,15 +103,27 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
     if (idx < n) store_split_elem(split, idx, packed[idx]);
 }
 
-__global__ __launch_bounds__(256) void unpack_batched_kernel(const awr_unpack_job* __restrict__ jobs, int n, int64_t total) {
-    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gidx >= total) return;
-    const awr_unpack_job jb = jobs[find_job(jobs, n, gidx)];
-    const int64_t idx = gidx - jb.first;
-    const int t = (int)(idx % jb.T);
-    const int b = (int)((idx / jb.T) % jb.d1);
-    const int a = (int)(idx / ((int64_t)jb.T * jb.d1));
-    jb.grad[idx] = jb.packed[((int64_t)a * jb.T + t) * jb.ld + b];
+// grad[a][b][t] = packed[a][t][b]: one workgroup per gradient row a, same LDS bounce (reads T lines of d1 floats, writes the
+// row's d1*T contiguous floats)
+__global__ __launch_bounds__(256) void unpack_batched_kernel(const awr_unpack_job* __restrict__ jobs, int n) {
+    __shared__ float tile[PACK_TILE + 64];
+    const awr_unpack_job jb = jobs[find_job(jobs, n, (int64_t)blockIdx.x)];
+    const int a = (int)((int64_t)blockIdx.x - jb.first);
+    const int T = jb.T, TS = T | 1, d1 = jb.d1;
+    const int cch = (PACK_TILE / TS) & ~31;
+    for (int c0 = 0; c0 < d1; c0 += cch) {
+        const int cc = d1 - c0 < cch ? d1 - c0 : cch;
+        for (int i = threadIdx.x; i < cc * T; i += 256) {
+            const int t = i / cc, c = i - t * cc;
+            tile[c * TS + t] = jb.packed[((int64_t)a * T + t) * jb.ld + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cc * T; i += 256) {
+            const int c = i / T, t = i - c * T;
+            jb.grad[((int64_t)a * d1 + c0 + c) * T + t] = tile[c * TS + t];
+        }
+        __syncthreads();
+    }
 }
 
 // cols[b][y][x][k] = img[b][y+k/5-2][x+k%5-2] for k < 25, 0 for k in [25,32) and outside the image
@@ -538,15 +567,15 @@ int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* 
     return check_launch("unpack_wgrad_kernel");
 }
 
-int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total, void* stream) {
-    AWR_REQUIRE(jobs_dev && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");
-    hipLaunchKernelGGL(pack_batched_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), jobs_dev, njobs, total);
+int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total_rows, void* stream) {
+    AWR_REQUIRE(jobs_dev && njobs > 0 && total_rows > 0 && total_rows < (1LL << 31), "pack_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total_rows), dim3(256), 0, as_stream(stream), jobs_dev, njobs);
     return check_launch("pack_batched_kernel");
 }
 
-int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total, void* stream) {
-    AWR_REQUIRE(jobs_dev && njobs > 0 && total > 0, "unpack_wgrads_batched: bad arguments");
-    hipLaunchKernelGGL(unpack_batched_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), jobs_dev, njobs, total);
+int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total_rows, void* stream) {
+    AWR_REQUIRE(jobs_dev && njobs > 0 && total_rows > 0 && total_rows < (1LL << 31), "unpack_wgrads_batched: bad arguments");
+    hipLaunchKernelGGL(unpack_batched_kernel, dim3((unsigned)total_rows), dim3(256), 0, as_stream(stream), jobs_dev, njobs);
     return check_launch("unpack_batched_kernel");
 }
 

@@ -1,0 +1,356 @@
+// Fused ResNet18-deconv stem for gfx950 (model/resnet_deconv.py:31-36, :118-121):
+//
+//     conv 5x5 pad 2 (1 -> 64 channels, no bias) -> BatchNorm -> ReLU -> MaxPool(3, 2, 1)
+//
+// The stem's full-resolution output (64 channels at HxW: 4 MB per 128x128 image, 268 MB at batch 64) used to be
+// written once and re-read six times per train step (im2col GEMM out, BN statistics, max-pool, pool backward, BN
+// backward reduce + apply, weight gradient).  A 5x5 conv of a ONE-channel image costs 25 MACs per output -- cheaper to
+// recompute from the 64 KB image than to move: the kernels below never materialise that tensor.
+//
+//   forward   stem_stats_kernel    conv -> per-channel sum / sum of squares (BatchNorm batch statistics)
+//             stem_pool_kernel     conv -> scale/shift -> ReLU -> 3x3/2 max-pool (+ argmax) : writes the POOLED map only
+//   backward  stem_bwd_kernel<0>   conv again -> ReLU mask, pool-backward gather -> sum g, sum g*xhat (BN backward sums)
+//             stem_bwd_kernel<1>   conv again -> dY = BN backward -> dW[64][25] += dY^T * im2col(image)
+//
+// The conv runs on the FP32 matrix pipe (v_mfma_f32_32x32x2_f32, exact f32): a workgroup stages its image patch in LDS,
+// the A operand of K-step kk is ONE ds_read_b32 per lane (pixel row of the lane + the tap offset of k = 2 kk + lane/32),
+// the B operand (the 64x25 filter bank, 13 K-steps of two taps) lives in 13 registers for the whole kernel.  In the
+// weight-gradient kernel the accumulator registers of the conv (lane = channel, register = pixel) ARE, register for
+// register, the A operand of the second GEMM (dY^T x im2col): no transposition, no LDS round trip.
+#include "awr_common.h"
+
+namespace awr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ST_T = 25;         // taps
+constexpr int ST_KS = 13;        // MFMA K-steps (2 taps each; tap 25 carries a zero weight)
+constexpr int ST_PW = 48;        // patch pitch of the 16x16-pixel kernels: the two 16-pixel runs of a half-wave sit 16 banks apart
+constexpr int ST_PH = 20;        // patch rows / used columns (16 + 2 * 2)
+constexpr int SP_PW = 24;        // patch pitch of the pooling kernel (21 used columns)
+constexpr int SP_R = 17;         // conv rows / columns under an 8x8 tile of pooled pixels (2 * 8 + 1)
+
+// MFMA 32x32 C/D layout: lane = column (l & 31), register r of half-wave h = row (r & 3) + 8 (r >> 2) + 4 h
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct stem_lane {
+    float w[ST_KS];      // filter taps k = 2 kk + h of channel ch0 + (lane & 31)
+    int koff[ST_KS];     // patch offset of tap k
+};
+
+template <int PW>
+__device__ __forceinline__ void stem_lane_init(stem_lane& s, const float* __restrict__ w, int ch, int h) {
+#pragma unroll
+    for (int kk = 0; kk < ST_KS; ++kk) {
+        const int k = 2 * kk + h;
+        s.w[kk] = k < ST_T ? w[ch * ST_T + k] : 0.f;
+        s.koff[kk] = k < ST_T ? (k / 5) * PW + (k % 5) : 0;
+    }
+}
+
+// y[32 pixels][32 channels] of one tile: pixel row of this lane starts at patch[base]
+__device__ __forceinline__ f32x16 stem_conv_tile(const float* patch, int base, const stem_lane& s) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < ST_KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(patch[base + s.koff[kk]], s.w[kk], acc, 0, 0, 0);
+    return acc;
+}
+
+// 20x20 image patch under a 16x16 tile of conv pixels (zero outside the image = the conv's padding)
+__device__ __forceinline__ void stem_load_patch16(float* patch, const float* __restrict__ img, int b, int y0, int x0, int H, int W) {
+    for (int i = threadIdx.x; i < ST_PH * ST_PH; i += blockDim.x) {
+        const int py = i / ST_PH, px = i - py * ST_PH;
+        const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+        patch[py * ST_PW + px] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm batch statistics of the (never stored) conv output
+// ------------------------------------------------------------------------------------------
+// grid (tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32 channels
+__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, int H, int W,
+                                                         double* __restrict__ stats) {
+    __shared__ float patch[ST_PH * ST_PW];
+    __shared__ float red[4][2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int tiles_x = W >> 4, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z, ch0 = blockIdx.y * 32;
+    stem_load_patch16(patch, img, b, ty * 16, tx * 16, H, W);
+    stem_lane sl;
+    stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int q = 32 * (wave * 2 + ti) + m;
+        const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s1 += acc[r];
+            s2 += acc[r] * acc[r];
+        }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0) {
+        red[wave][0][m] = s1;
+        red[wave][1][m] = s2;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int st = tid >> 5, c = tid & 31;
+        const double v = (double)red[0][st][c] + (double)red[1][st][c] + (double)red[2][st][c] + (double)red[3][st][c];
+        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+        atomicAdd(stats + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv -> affine (BatchNorm) -> ReLU -> MaxPool(3,2,1): writes the pooled NHWC map (+ argmax)
+// ------------------------------------------------------------------------------------------
+// grid (tiles of 8x8 POOLED pixels, channel half, image); 320 threads = 5 waves x 2 tiles of 32 conv pixels: the 17x17 conv
+// pixels under the tile (289, padded to 320) go through LDS as act[pixel][32 channels], then 256 threads pool them.
+__global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
+                                                        float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+    __shared__ float patch[21 * SP_PW];
+    __shared__ __attribute__((aligned(16))) float act[320 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tiles_x = Wo >> 3, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z, ch0 = blockIdx.y * 32;
+    const int oy0 = ty * 8, ox0 = tx * 8;
+    for (int i = tid; i < 21 * 21; i += 320) {
+        const int py = i / 21, px = i - py * 21;
+        const int gy = 2 * oy0 - 3 + py, gx = 2 * ox0 - 3 + px;
+        patch[py * SP_PW + px] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
+    }
+    stem_lane sl;
+    stem_lane_init<SP_PW>(sl, w, ch0 + m, h);
+    const float sc = scale[ch0 + m], sh = shift[ch0 + m];
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int i = wave * 2 + ti;
+        int q = 32 * i + m;
+        q = q < SP_R * SP_R ? q : SP_R * SP_R - 1;       // rows 289..319 of the last tile: recomputed, never pooled
+        const int qy = q / SP_R, qx = q - qy * SP_R;
+        const f32x16 acc = stem_conv_tile(patch, qy * SP_PW + qx, sl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[(32 * i + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
+    }
+    __syncthreads();
+    for (int o = tid; o < 512; o += 320) {
+        const int c4 = o & 7, pp = o >> 3, py = pp >> 3, px = pp & 7;
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int am[4] = {0, 0, 0, 0};
+        // window row dy <-> conv row 2 oy - 1 + dy: only row / column -1 can fall outside (H, W even), torch pads with -inf
+        for (int dy = (oy0 + py == 0) ? 1 : 0; dy < 3; ++dy)
+            for (int dx = (ox0 + px == 0) ? 1 : 0; dx < 3; ++dx) {
+                const float4 v = ld4(&act[((2 * py + dy) * SP_R + 2 * px + dx) * 32 + 4 * c4]);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (vv[c] > mx[c]) {      // first maximum in scan order wins (ATen)
+                        mx[c] = vv[c];
+                        am[c] = dy * 3 + dx;
+                    }
+            }
+        const size_t oidx = (((size_t)b * Ho + oy0 + py) * Wo + ox0 + px) * 64 + ch0 + 4 * c4;
+        st4(pooled + oidx, make_float4(mx[0], mx[1], mx[2], mx[3]));
+        if (argmax) *reinterpret_cast<uchar4*>(argmax + oidx) = make_uchar4((uint8_t)am[0], (uint8_t)am[1], (uint8_t)am[2], (uint8_t)am[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: pool-backward gather + ReLU mask + BatchNorm backward, on the recomputed conv output
+// ------------------------------------------------------------------------------------------
+// WGRAD = 0: sums[slot][0][c] += sum g, sums[slot][1][c] += sum g * xhat          (g = d loss / d bn-output, masked)
+// WGRAD = 1: dY = gi (g - k1 - xhat k2);  dw[slot][c][tap] += sum_pixels dY[pixel][c] * image[pixel + tap]
+// grid (groups of TPW tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels per 16x16 tile
+template <int WGRAD>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ coef4,
+                                                       const float* __restrict__ bcoef, const float* __restrict__ dpool,
+                                                       const uint8_t* __restrict__ argmax, int H, int W, int tiles_per_wg,
+                                                       double* __restrict__ sums, float* __restrict__ dw) {
+    __shared__ float patch[ST_PH * ST_PW];
+    __shared__ __attribute__((aligned(16))) float dpw[81 * 32];       // pooled-gradient windows [wy][wx][channel]
+    __shared__ __attribute__((aligned(16))) uint8_t amw[81 * 32];     // their argmax codes
+    __shared__ float red[WGRAD ? 4 * 1024 : 4 * 2 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tiles_x = W >> 4;
+    const int b = blockIdx.z, ch0 = blockIdx.y * 32;
+    stem_lane sl;
+    stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
+    const float sc = coef4[ch0 + m], sh = coef4[64 + ch0 + m], mu = coef4[128 + ch0 + m], is = coef4[192 + ch0 + m];
+    float k1 = 0.f, k2 = 0.f, gi = 0.f;
+    if (WGRAD) { k1 = bcoef[ch0 + m]; k2 = bcoef[64 + ch0 + m]; gi = bcoef[128 + ch0 + m]; }
+    const int tm = m < ST_T ? m : 0;
+    const int toff = (tm / 5) * ST_PW + (tm % 5);          // second GEMM: this lane's column = tap m
+    const int hoff = 64 * h + m;                            // window address part that depends on the lane
+    float s1 = 0.f, s2 = 0.f;
+    f32x16 wacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
+
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const int tile = blockIdx.x * tiles_per_wg + tt;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        if (tt) __syncthreads();           // the previous tile's readers are done with the LDS arrays
+        stem_load_patch16(patch, img, b, y0, x0, H, W);
+        for (int i = tid; i < 81 * 8; i += 256) {
+            const int c4 = i & 7, win = i >> 3, wy = win / 9, wx = win - wy * 9;
+            const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+            float4 d = make_float4(0, 0, 0, 0);
+            uchar4 a = make_uchar4(255, 255, 255, 255);
+            if (oy < Ho && ox < Wo) {
+                const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * 64 + ch0 + 4 * c4;
+                d = ld4(dpool + o);
+                a = *reinterpret_cast<const uchar4*>(argmax + o);
+            }
+            st4(&dpw[win * 32 + 4 * c4], d);
+            *reinterpret_cast<uchar4*>(&amw[win * 32 + 4 * c4]) = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int i = wave * 2 + ti;
+            const int q = 32 * i + m;
+            f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl);
+            // pixel of register r: ly = 2 i + (r >> 3), lx = 8 ((r >> 2) & 1) + (r & 3) + 4 h   (parities are compile-time)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ly = 2 * i + (r >> 3);
+                const int lx0 = 8 * ((r >> 2) & 1) + (r & 3);      // + 4 h
+                // windows holding row ly: even -> (ly/2, ky 1); odd -> ((ly-1)/2, ky 2), ((ly+1)/2, ky 0); same for columns
+                const int ny = (r >> 3) & 1 ? 2 : 1, nx = (r & 1) ? 2 : 1;
+                float g = 0.f;
+#pragma unroll
+                for (int a = 0; a < ny; ++a) {
+                    const int wy = ny == 1 ? ly >> 1 : ((ly - 1) >> 1) + a;
+                    const int ky = ny == 1 ? 1 : (a == 0 ? 2 : 0);
+#pragma unroll
+                    for (int c = 0; c < nx; ++c) {
+                        const int wx0 = nx == 1 ? lx0 >> 1 : ((lx0 - 1) >> 1) + c;      // + 2 h
+                        const int kx = nx == 1 ? 1 : (c == 0 ? 2 : 0);
+                        const int wa = (wy * 9 + wx0) * 32 + hoff;
+                        g += amw[wa] == ky * 3 + kx ? dpw[wa] : 0.f;
+                    }
+                }
+                const float y = acc[r];
+                g = y * sc + sh > 0.f ? g : 0.f;
+                const float xh = (y - mu) * is;
+                if (WGRAD) {
+                    acc[r] = gi * (g - k1 - xh * k2);
+                } else {
+                    s1 += g;
+                    s2 += g * xh;
+                }
+            }
+            if (WGRAD) {
+                // dW[channel][tap] += sum over the tile's 32 pixels: K-step r contracts the pixels of register r (one per half-wave)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pb = (2 * i + (r >> 3)) * ST_PW + 8 * ((r >> 2) & 1) + (r & 3) + 4 * h;
+                    wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], patch[pb + toff], wacc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (WGRAD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = wacc[r];
+        __syncthreads();
+        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+        for (int e = tid; e < 1024; e += 256) {
+            const int r = e >> 6, l = e & 63, t = l & 31;
+            if (t < ST_T) {
+                const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+                atomicAdd(dw + ((size_t)slot * 64 + ch0 + mfma_row(r, l >> 5)) * ST_T + t, v);
+            }
+        }
+    } else {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+            red[(wave * 2 + 0) * 32 + m] = s1;
+            red[(wave * 2 + 1) * 32 + m] = s2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int st = tid >> 5, c = tid & 31;
+            const double v = (double)red[(0 * 2 + st) * 32 + c] + (double)red[(1 * 2 + st) * 32 + c] + (double)red[(2 * 2 + st) * 32 + c] +
+                             (double)red[(3 * 2 + st) * 32 + c];
+            const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+            atomicAdd(sums + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
+        }
+    }
+}
+
+// grad[c][tap] = sum over the slot copies; re-arms the accumulator for the next step
+__global__ void stem_dw_finalize_kernel(float* __restrict__ dw_slots, float* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * ST_T) return;
+    float s = 0.f;
+    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {
+        s += dw_slots[k * 64 * ST_T + i];
+        dw_slots[k * 64 * ST_T + i] = 0.f;
+    }
+    grad[i] = s;
+}
+
+}  // namespace awr
+
+using namespace awr;
+
+extern "C" {
+
+#define AWR_STEM_GEOMETRY(name)                                                                                              \
+    AWR_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, name ": H=%d, W=%d must be positive multiples of 16", H, W); \
+    AWR_REQUIRE((int64_t)B * H * W < (1LL << 31), name ": batch too large")
+
+int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, void* stream) {
+    AWR_REQUIRE(img && w && stats, "stem_stats: null pointer");
+    AWR_STEM_GEOMETRY("stem_stats");
+    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, H, W, stats);
+    return check_launch("stem_stats_kernel");
+}
+
+int awr_stem_pool(const float* img, const float* w, const float* scale, const float* shift, int B, int H, int W, float* pooled,
+                  uint8_t* argmax, void* stream) {
+    AWR_REQUIRE(img && w && scale && shift && pooled, "stem_pool: null pointer");
+    AWR_STEM_GEOMETRY("stem_pool");
+    hipLaunchKernelGGL(stem_pool_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(320), 0, as_stream(stream), img, w, scale, shift, H, W, pooled,
+                       argmax);
+    return check_launch("stem_pool_kernel");
+}
+
+int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool, const uint8_t* argmax, int B, int H, int W,
+                        double* sums, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && dpool && argmax && sums, "stem_bwd_reduce: null pointer");
+    AWR_STEM_GEOMETRY("stem_bwd_reduce");
+    hipLaunchKernelGGL(stem_bwd_kernel<0>, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, (const float*)nullptr,
+                       dpool, argmax, H, W, 1, sums, (float*)nullptr);
+    return check_launch("stem_bwd_kernel<0>");
+}
+
+int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef, const float* dpool, const uint8_t* argmax,
+                       int B, int H, int W, float* dw_slots, float* grad, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && bwd_coef && dpool && argmax && dw_slots && grad, "stem_bwd_wgrad: null pointer");
+    AWR_STEM_GEOMETRY("stem_bwd_wgrad");
+    const int tiles = (H / 16) * (W / 16);
+    int tpw = 8;                                   // tiles per workgroup: fewer, longer workgroups = fewer atomics on the 64x25 result
+    while (tiles % tpw) tpw >>= 1;
+    hipLaunchKernelGGL(stem_bwd_kernel<1>, dim3(tiles / tpw, 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, bwd_coef, dpool, argmax, H, W, tpw,
+                       (double*)nullptr, dw_slots);
+    if (int e = check_launch("stem_bwd_kernel<1>")) return e;
+    hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3((64 * ST_T + 255) / 256), dim3(256), 0, as_stream(stream), dw_slots, grad);
+    return check_launch("stem_dw_finalize_kernel");
+}
+
+}  // extern "C"

@@ -100,9 +100,14 @@ class ConvLayer:
     def bias_ptr(self):
         return self.bias
 
-    def wgrad_unpack_calls(self, R, ld):
+    def wgrad_unpack_jobs(self, R, ld, bsum):
+        """(packed pointer, gradient view, d0, d1, T, ld) scatter jobs: packed split-K result -> checkpoint layout."""
         prob_d0, prob_d1 = (self.spec.cout, self.spec.cin) if self.spec.kind == "conv" else (self.spec.cin, self.spec.cout)
-        return [("awr_unpack_wgrad", (L.ptr(R), prob_d0, prob_d1, self.spec.T, ld, L.ptr(self.gw), 0))]
+        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld)]
+        if bsum is not None:
+            n = self.gbias.numel()
+            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n))
+        return jobs
 
     def bias_grad_target(self):
         return self.gbias
@@ -120,7 +125,6 @@ class HeadLayer(ConvLayer):
         super().__init__(spec, w1, gw1, None, None, name)
         self.w1, self.gw1, self.b1, self.gb1, self.w2, self.gw2, self.b2, self.gb2 = w1, gw1, b1, gb1, w2, gw2, b2, gb2
         self.bias_cat = torch.zeros(self.cp, device=w1.device, dtype=torch.float32)
-        self.gbias_cat = torch.zeros(self.cp, device=w1.device, dtype=torch.float32)
 
     def pack_calls(self):
         J, cin = self.J, self.cin
@@ -140,17 +144,12 @@ class HeadLayer(ConvLayer):
     def bias_ptr(self):
         return self.bias_cat
 
-    def wgrad_unpack_calls(self, R, ld):
+    def wgrad_unpack_jobs(self, R, ld, bsum):
         J, cin = self.J, self.cin
-        return [("awr_unpack_wgrad", (R.data_ptr(), 3 * J, cin, 1, ld, L.ptr(self.gw1), 0)),
-                ("awr_unpack_wgrad", (R.data_ptr() + 3 * J * ld * 4, J, cin, 1, ld, L.ptr(self.gw2), 0))]
-
-    def bias_grad_target(self):
-        return self.gbias_cat
-
-    def bias_grad_post(self):
-        J = self.J
-        return [("__copy__", (self.gb1, self.gbias_cat[:3 * J])), ("__copy__", (self.gb2, self.gbias_cat[3 * J:4 * J]))]
+        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld)]
+        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels
+            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J)]
+        return jobs
 
 
 class BNLayer:
@@ -298,16 +297,13 @@ class Plan:
         B, H, W, _ = x.shape
         dy = y.grad
         assert dy is not None, "no gradient reached %s" % y.name
-        fused_bias = has_bias and layer.batchable and spec.kind == "conv"
+        # the bias gradient (column sums of dY) falls out of the slices a conv's wgrad kernel stages anyway; only a biased
+        # TRANSPOSED conv (none in the reference nets) needs the stand-alone reduction
+        fused_bias = has_bias and spec.kind == "conv"
         if has_bias and not fused_bias:
             tgt = layer.bias_grad_target()
             self._b("awr_bias_grad", L.ptr(dy), y.npix, y.shape[3], L.ptr(tgt), 0)
-            if hasattr(layer, "bias_grad_post"):
-                for _, (dst, src) in layer.bias_grad_post():
-                    self.bwd_ops.append((None, (dst, src), "__copy__"))
-                    self._note_grad(dst)
-            else:
-                self._note_grad(tgt)
+            self._note_grad(tgt)
         # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
         wp = spec.wgrad_problem(H, W)
         ld = wp["Cg"]
@@ -315,7 +311,7 @@ class Plan:
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
         xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
         bsum = None
-        if fused_bias:      # the bias gradient (column sums of dY) falls out of the slices the wgrad kernel stages anyway
+        if fused_bias:
             bsum = self._scratch(y.shape[3])
             xa["d_colsum"] = bsum
         wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
@@ -327,21 +323,11 @@ class Plan:
             # again.  With a fused residual, d(res) ALIASES dY and later nodes accumulate into it in place -> stays on the main stream.
             self._side_ok.add("awr_conv_wgrad:" + layer.name)
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
-        if layer.batchable:        # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
-            for name, args in layer.wgrad_unpack_calls(R, ld):
-                job = L.UnpackJob(args[0], args[5], args[1], args[2], args[3], args[4], 0)
-                self._unpack_jobs.append(job)
-                self._note_grad(layer.gw, job)
-            if bsum is not None:
-                n = layer.gbias.numel()
-                job = L.UnpackJob(L.ptr(bsum), L.ptr(layer.gbias), 1, n, 1, n, 0)
-                self._unpack_jobs.append(job)
-                self._note_grad(layer.gbias, job)
-        else:
-            for name, args in layer.wgrad_unpack_calls(R, ld):
-                self._b(name, *args)
-            self._note_grad(layer.gw1)
-            self._note_grad(layer.gw2)
+        # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
+        for packed_ptr, grad, d0, d1, T_, ld_ in layer.wgrad_unpack_jobs(R, ld, bsum):
+            job = L.UnpackJob(packed_ptr, L.ptr(grad), d0, d1, T_, ld_, 0)
+            self._unpack_jobs.append(job)
+            self._note_grad(grad, job)
         # data gradient
         if x.needs_grad:
             dp = spec.dgrad_problem(H, W)
@@ -510,9 +496,9 @@ class Plan:
             self.bwd_ops[first] = (None, (self.alloc(4),), "__zero__")
         def unpack_op(jobs):
             total = 0
-            for jb in jobs:
+            for jb in jobs:           # one workgroup per gradient row
                 jb.first = total
-                total += jb.d0 * jb.d1 * jb.T
+                total += jb.d0
             tab = L.job_table(jobs, self.dev)
             self._bufs.append(tab)
             return (L.lib.awr_unpack_wgrads_batched, (tab.data_ptr(), len(jobs), total, None), "awr_unpack_wgrads_batched")
@@ -621,7 +607,7 @@ class Plan:
                 if layer.batchable:
                     for name, args, split in layer.pack_calls():
                         jobs.append(L.PackJob(args[0], args[7], split if want_split else None, args[1], args[2], args[3], args[4], args[5], args[6], total))
-                        total += args[5] * args[3] * args[6]
+                        total += args[5]                     # one workgroup per packed row
             self._pack_tab[want_split] = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
         tab, njobs, total = self._pack_tab[want_split]
         if njobs:

@@ -81,7 +81,8 @@ class TrainEngine:
                                  n_buckets=n_buckets if self.dp else 1)
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off)
         self.plan.side_streams = [torch.cuda.Stream(device=dev) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
-        self._tune_pending = bool(autotune) and not self.plan.tuned      # runs right after the first step (buffers then hold real data)
+        self._autotune = bool(autotune)
+        self._compiled = False
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
         self.jt_pred = torch.zeros(batch_size, self.J, 3, device=dev)
         self.stat = torch.zeros(batch_size, self.J, 2, device=dev)
@@ -98,7 +99,6 @@ class TrainEngine:
         self.step_count = 0
         self.use_graph = use_graph
         self.graph = None
-        self._warm = 0
         self.sync = GradSync(n, process_group, n_buckets)
         self._n_buckets = n_buckets
         self.world = self.sync.world
@@ -174,15 +174,12 @@ class TrainEngine:
         plan = self.plan
         plan.img.copy_(img, non_blocking=True)
         self.jt_gt.copy_(jt_uvd_gt, non_blocking=True)
-        if self.use_graph and self.graph is None and self._warm >= 2:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._core()
+        if not self._compiled:
+            self.compile()
         if self.graph is not None:
             self.graph.replay()
         else:
             self._core()
-            self._warm += 1
         for bn in plan.bns:
             bn.counter += plan.bn_repeat
         if self.dp:
@@ -192,15 +189,34 @@ class TrainEngine:
         self.step_count += 1
         self._optimizer()
         self.net.weights_changed()
-        if self._tune_pending:
-            # one-off: time the GEMM tile candidates in place.  The step above is complete (losses, predictions and the
-            # optimiser update are final); the activation / gradient buffers the tuner scribbles on are rebuilt by the next step
-            self._tune_pending = False
-            keep = (self.losses.clone(), self.jt_pred.clone())
-            self.plan.autotune(cache_key="train/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
-            self.losses.copy_(keep[0])
-            self.jt_pred.copy_(keep[1])
         return self.losses, self.jt_pred
+
+    def compile(self, img=None, jt_uvd_gt=None):
+        """One-off set-up of the static plan, NOT an optimisation step: runs the captured part once eagerly on the batch in the
+        input buffers (kernel warm-up; its only side effect -- the BatchNorm running statistics -- is rolled back), times the GEMM
+        tile candidates of every launch in place (engine.Plan.autotune) and captures repack + forward + head + losses + backward,
+        with the weight-gradient side streams forked and joined inside the capture, as ONE hipGraph.  `step()` calls it on its
+        first use; call it directly (optionally with a representative batch) to keep that cost out of the first step."""
+        if self._compiled:
+            return
+        if img is not None:
+            self.plan.img.copy_(img, non_blocking=True)
+            self.jt_gt.copy_(jt_uvd_gt, non_blocking=True)
+        self._compiled = True
+        if not (self.use_graph or (self._autotune and not self.plan.tuned)):
+            return
+        hook, self.plan.bucket_hook = self.plan.bucket_hook, None          # no collectives during set-up
+        keep = self.net._barena.clone()
+        self._core()
+        if self._autotune and not self.plan.tuned:
+            self.plan.autotune(cache_key="train/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
+        if self.use_graph:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._core()
+        self.net._barena.copy_(keep)
+        self.plan.bucket_hook = hook
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -261,11 +277,11 @@ class InferEngine:
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
-        self._tune_pending = bool(autotune) and not self.plan.tuned
+        self._autotune, self._compiled = bool(autotune), False
         self.J, self.F = net.J, img_size // getattr(net, "downsample", 2)
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)
         self.stage = net.nstage - 1
-        self.use_graph, self.graph, self._warm = use_graph, None, 0
+        self.use_graph, self.graph = use_graph, None
 
     def _core(self):
         plan = self.plan
@@ -276,20 +292,21 @@ class InferEngine:
     def __call__(self, img):
         self.net.sync_weights(self.plan)
         self.plan.img.copy_(img, non_blocking=True)
-        if self.use_graph and self.graph is None and self._warm >= 2:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+        if not self._compiled:           # one-off: eager warm-up run, GEMM tile autotune, hipGraph capture
+            self._compiled = True
+            if self.use_graph or (self._autotune and not self.plan.tuned):
                 self._core()
+                if self._autotune and not self.plan.tuned:
+                    self.plan.autotune(cache_key="infer/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
+                if self.use_graph:
+                    torch.cuda.synchronize()
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        self._core()
         if self.graph is not None:
             self.graph.replay()
         else:
             self._core()
-            self._warm += 1
-        if self._tune_pending:
-            self._tune_pending = False
-            keep = self.jt.clone()
-            self.plan.autotune(cache_key="infer/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
-            self.jt.copy_(keep)
         return self.jt
 
 

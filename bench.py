@@ -53,26 +53,74 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(net, ks, batch, target_seconds=20.0):
-    """Oracle train step on the host cores (kind 'port'); a bounded sample of the same workload."""
+def _host_cpu():
+    """(physical cores, model string) of the box bench.py runs on."""
+    model, cores = "unknown", None
+    try:
+        pairs = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        cores = len(pairs) or None
+    except OSError:
+        pass
+    if not cores:
+        try:
+            import psutil
+            cores = psutil.cpu_count(logical=False)
+        except Exception:
+            cores = None
+    return int(cores or os.cpu_count() or 1), model
+
+
+def cpu_baseline():
+    """the CPU restatement of the path (oracle, kind 'port') on the host cores of the GPU box --
+    (i) config 1: ResNet18-deconv, B=4, eval under no_grad, head included; (ii) the same net, B=4, one full train step
+    (coord_weight 0, dense_weight 1, Adam lr 1e-3, kernel_size 1).  Synthetic inputs seed 1234, all physical cores,
+    3 warm-up iterations, median of 10.  `value` is the train step (the unit of BASELINE.json's metric)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import awr_oracle as O
-    threads = torch.get_num_threads()
-    b = min(batch, 16)
-    img, jt = O.synth_batch(b, 128, 14, seed=1234)
-    sd = O.reference_init_state(net, 14, seed=0)
-    ost = {"step": 0, "m": {}, "v": {}}
-    O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0)          # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > target_seconds or n >= 20:
-            break
-    return {"value": round(n * b / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%d oracle train steps (torch-CPU fp32 restatement of train.py:107-131), batch %d, %s, %.1f s" % (n, b, net, el)}
+    cores, model = _host_cpu()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        net, ks, b = "resnet_18", 1.0, 4
+        img, jt = O.synth_batch(b, 128, 14, seed=1234)
+        sd = O.reference_init_state(net, 14, seed=0)
+
+        def med(fn, warm=3, reps=10):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return 0.5 * (ts[reps // 2 - 1] + ts[reps // 2]) if reps % 2 == 0 else ts[reps // 2]
+
+        def infer():
+            with torch.no_grad():
+                O.offset2joint_softmax(O.resnet18_forward(sd, img, False), img, ks)
+        t_eval = med(infer)
+        ost = {"step": 0, "m": {}, "v": {}}
+        t_train = med(lambda: O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0))
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(b / t_train, 2), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "eval_value": round(b / t_eval, 2), "eval_ms": round(1e3 * t_eval, 2), "train_ms": round(1e3 * t_train, 2),
+            "sample": "BASELINE.md section 4: ResNet18-deconv B=4, (i) eval forward + head under no_grad [eval_value], (ii) one full train step "
+                      "GT-map+fwd+head+Huber+bwd+Adam, coord_weight 0 [value]; torch-CPU fp32 restatement (oracle/awr_oracle.py, pinned bit-exact to "
+                      "the reference), %d threads = physical cores, 3 warm-up, median of 10" % cores}
 
 
 def parity_mm(net_name, ks, dev):
@@ -93,6 +141,44 @@ def parity_mm(net_name, ks, dev):
     return float(d.mean()), float(d.max())
 
 
+def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None):
+    """test.py:67-86 path: eval-mode BatchNorm folded into the GEMM epilogues, img -> dense map -> joints.  Returns images/s, ms per
+    batch and the fraction of the MFMA roofline (algorithmic conv FLOPs of the forward / time / peak)."""
+    from awr_amd.trainer import InferEngine
+    ks = 1.0 if net_name.startswith("resnet") else 0.4
+    if net is None:
+        torch.manual_seed(0)
+        net = (awr_amd.get_deconv_net(18, 14, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, 14)).cuda()
+    inf = InferEngine(net, batch, 128, ks, use_graph=graph)
+    imgs, _ = O.synth_batch(batch, 128, 14, seed=1234 + rank)
+    imgs = imgs.to(dev)
+    for _ in range(warmup):
+        inf(imgs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        inf(imgs)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    macs = sum(v for k, v in inf.plan.macs.items())
+    if per_layer:
+        tm = KernelTimer()
+        inf.plan.timer = tm
+        inf.use_graph, inf.graph = False, None
+        for _ in range(5):
+            inf(imgs)
+        torch.cuda.synchronize()
+        inf.plan.timer = None
+        with open(per_layer, "w") as f:
+            f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
+            for n, (sec, c) in sorted(tm.collect().items(), key=lambda kv: -kv[1][0]):
+                f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / sec))
+    return {"workload": "%s eval forward + head (img -> joints), batch %d" % (net_name, batch), "value": round(batch * steps / el, 2), "unit": "images/s",
+            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "hipgraph": bool(graph),
+            "algorithmic_gflop_per_image": round(2e-9 * macs / batch, 3),
+            "mfma_frac": round(flop_mult * 2 * macs / (el / steps) / 1e12 / peak_tf, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +186,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--net", default="resnet_18")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (roofline then comes from a separate eager pass)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as ONE hipGraph (weight-gradient side streams forked / joined inside the capture) instead of issuing every launch "
+                         "eagerly.  Measured slower on this stack (15.80 vs 14.93 ms / step, profiles/r02_summary.md): the eager two-stream issue stays the default")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inference / config-3 measurements reported under 'forward' and 'config3'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the small HIP-vs-oracle joint check (keeps profiler traces to the timed workload)")
     ap.add_argument("--coord-weight", type=float, default=0.0, help="reference default config.py:41")
@@ -142,36 +231,12 @@ def main():
     torch.manual_seed(0)
     net = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
     if args.mode == "infer":
-        from awr_amd.trainer import InferEngine
-        inf = InferEngine(net, args.batch, 128, ks, use_graph=args.graph)
-        imgs, _ = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)
-        imgs = imgs.to(dev)
-        for _ in range(max(args.warmup, 3)):
-            inf(imgs)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            inf(imgs)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        macs = sum(v for k, v in inf.plan.macs.items())
-        if args.per_layer:
-            tm = KernelTimer()
-            inf.plan.timer = tm
-            inf.use_graph, inf.graph = False, None
-            for _ in range(5):
-                inf(imgs)
-            torch.cuda.synchronize()
-            inf.plan.timer = None
-            with open(args.per_layer, "w") as f:
-                f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
-                for n, (sec, c) in sorted(tm.collect().items(), key=lambda kv: -kv[1][0]):
-                    f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / sec))
-        print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": round(args.batch * args.steps / el, 2), "unit": "images/s",
-                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-                          "dtype": dtype, "data": "synthetic", "config": {"workload": "%s eval forward + head, batch %d" % (args.net, args.batch),
-                                                                          "hipgraph": bool(args.graph), "gemm_products": nprod},
-                          "mfma_frac": round(flop_mult * 2 * macs / (el / args.steps) / 1e12 / peak_tf, 4)}), flush=True)
+        res = measure_inference(awr_amd, O, args.net, args.batch, dev, rank, args.steps, max(args.warmup, 3), args.graph, peak_tf, flop_mult,
+                                per_layer=args.per_layer, net=net)
+        print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": res["value"], "unit": "images/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                          "dtype": dtype, "data": "synthetic", "config": {"workload": res["workload"], "hipgraph": bool(args.graph), "gemm_products": nprod},
+                          "mfma_frac": res["mfma_frac"]}), flush=True)
         return
     eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
                       use_graph=args.graph, wgrad_streams=args.wgrad_streams)
@@ -183,11 +248,14 @@ def main():
         if pg is not None:
             torch.distributed.barrier()
 
-    for _ in range(max(args.warmup, 3 if args.graph else 0)):
+    graph = bool(eng.use_graph)          # the engine falls back to eager issue in data-parallel mode (RCCL calls inside the backward)
+    eng.compile(img, jt)                 # set-up, not a step: kernel warm-up run (rolled back), GEMM tile autotune, hipGraph capture
+    warm = args.warmup
+    for _ in range(warm):
         eng.step(img, jt)
     # per-kernel HIP events only make sense when kernels do not share the GPU: with stream overlap (the default) or graph
     # replay the timed region runs untouched and the per-kernel roofline comes from a serialised pass right after it
-    serial = not args.graph and args.wgrad_streams == 0
+    serial = not graph and args.wgrad_streams == 0
     timer = None
     if serial:
         timer = KernelTimer()
@@ -236,17 +304,18 @@ def main():
     # separate rocprofv3 --pmc runs of this same command: tools/gpu_pmc.sh) cannot be collected from inside the
     # process, so the committed summary of the last PMC run is reported (null when absent).
     traffic, traffic_src = None, None
-    tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
-    if os.path.exists(tpath) and args.net.startswith("resnet") and args.batch == 64:
+    tfiles = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))
+    tpath = os.path.join(REPO, "profiles", tfiles[-1]) if tfiles else ""
+    if tpath and args.net.startswith("resnet") and args.batch == 64 and nprod == 1:      # the PMC passes profile exactly this command
         tj = json.load(open(tpath))
         key = "conv_gemm_kernel" if dom.startswith("conv_gemm") else "conv_wgrad_kernel"
         ent = [v for k, v in tj.items() if key in k]
         nl = sum(v["launches"] for v in ent)
         if nl:
             traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_x2"] + v["write_MB_per_launch"]) for v in ent) / nl * 1e6)
-            traffic_src = "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+            traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 per the gfx950 note, bytes per launch)" % os.path.basename(tpath)
     roofline = {
-        "bound": "mfma", "kernel": dom, "event_pass": "timed region" if serial else "serialised pass after the timed region (kernels overlap on 2 streams in the timed region)",
+        "bound": "mfma", "kernel": dom, "event_pass": "timed region" if serial else "serialised eager pass right after the timed region (in the timed region the step is one hipGraph replay / kernels overlap on side streams)",
         "achieved": round(flop_mult * kern[dom]["tflops"], 2), "peak": peak_tf, "unit": "TFLOP/s", "mfma_flops_per_algorithmic_flop": flop_mult,
         "frac": round(flop_mult * kern[dom]["tflops"] / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flop_per_launch": round(kern[dom]["flops"] / max(kern[dom]["launches"], 1)),
@@ -263,12 +332,13 @@ def main():
         L.lib.awr_device_info(L.C.byref(n_cu), L.C.byref(mhz), None, 0)
         out = {
             "metric": "depth-images/sec (train step)", "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "%s-deconv NYU-shape 128x128 J=14 train step (GT-map+fwd+head+Huber+bwd+Adam), batch %d/GPU" % (args.net, args.batch)
+            "config": {"workload": "%s-deconv NYU-shape 128x128 J=14 train step (GT-map+fwd+head+Huber+bwd+Adam), batch %d/GPU%s" % (
+                           args.net, args.batch, {64: " = BASELINE configs[1]", 256: " = BASELINE configs[3] per-GPU shape"}.get(args.batch, ""))
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
-                       "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": bool(args.graph), "wgrad_streams": args.wgrad_streams,
+                       "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams,
                        "gemm_products": nprod, "device_cus": n_cu.value, "final_loss": loss},
             "roofline": roofline,
         }
@@ -276,7 +346,14 @@ def main():
             mean_mm, max_mm = parity_mm(args.net, ks, dev)
             out["joint_err_mm_vs_oracle"] = {"mean": round(mean_mm, 6), "max": round(max_mm, 6)}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(args.net, ks, args.batch)
+                out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extras:
+            # north_star's forward target (>= 40 % MFMA utilisation on the ResNet18-deconv forward) and BASELINE config 3, each ~1 s,
+            # outside the timed train region
+            del eng
+            torch.cuda.empty_cache()
+            out["forward"] = {"b%d" % b: measure_inference(awr_amd, O, "resnet_18", b, dev, rank, 30, 5, args.graph, peak_tf, flop_mult) for b in (64, 128)}
+            out["config3"] = measure_inference(awr_amd, O, "hourglass_1", 128, dev, rank, 20, 5, args.graph, peak_tf, flop_mult)
         if world == 1 and nprod == 1 and not args.no_split_mode:
             # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)
             awr_amd.set_gemm_products(6)
@@ -284,7 +361,8 @@ def main():
             net6 = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
             eng6 = TrainEngine(net6, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, use_graph=args.graph,
                                wgrad_streams=args.wgrad_streams)
-            for _ in range(max(args.warmup, 3 if args.graph else 0)):
+            eng6.compile(img, jt)
+            for _ in range(warm):
                 eng6.step(img, jt)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

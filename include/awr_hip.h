@@ -107,9 +107,10 @@ int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_
 int awr_unpack_wgrad(const float* packed, int d0, int d1, int T, int ld, float* grad, int accumulate,
                      void* stream);
 
-/* Batched forms of the two calls above: ONE launch repacks / scatters every layer of a network.  The
- * descriptor tables live in DEVICE memory (built once per plan); `first` is the running element offset of
- * each job (packed elements for pack jobs, gradient elements for unpack jobs), `total` their sum. */
+/* Batched forms of the two calls above: ONE launch repacks / scatters every layer of a network, one workgroup
+ * per row (pack: packed row of T*ld floats; unpack: gradient row of d1*T floats).  The descriptor tables live
+ * in DEVICE memory (built once per plan); `first` is the running ROW offset of each job (`rows` rows per pack
+ * job, d0 rows per unpack job), `total_rows` their sum = the number of workgroups. */
 typedef struct awr_pack_job {
     const float* src;
     float* dst;
@@ -128,8 +129,8 @@ typedef struct awr_unpack_job {
  * (truncating 8+8+8-bit cut of the fp32 significand).  Weights are split once per optimiser step instead of once per
  * workgroup that stages them. */
 int awr_split_weight(const float* packed, void* split, int64_t n, void* stream);
-int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total, void* stream);
-int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total, void* stream);
+int awr_pack_weights_batched(const awr_pack_job* jobs_dev, int njobs, int64_t total_rows, void* stream);
+int awr_unpack_wgrads_batched(const awr_unpack_job* jobs_dev, int njobs, int64_t total_rows, void* stream);
 
 /* Geometry of one implicit-GEMM convolution-like gather:
  *   out[b, qy*so+py, qx*so+px, n] = sum_{tap in phase} sum_c in[b, qy*si+dy, qx*si+dx, c] * P[n][wt][c]

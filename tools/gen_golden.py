@@ -287,14 +287,14 @@ def main():
             print("  %-46s max rel grad diff = %.3e" % ("c5 gradients", worst))
             assert worst < 5e-3
             out["loss0"], out["lcoord0"], out["ldense0"] = np.float32(loss.detach()), np.float32(l_coord.detach()), np.float32(l_dense.detach())
-            out["jt0"] = jt.detach().numpy()
+            out["jt0"] = jt.detach().numpy().copy()
             rsd = ref.state_dict()
             bn_keys = [k for k, _, kind in man_ if kind in ("bn_mean", "bn_var")]
             pick = [bn_keys[0], bn_keys[1], bn_keys[len(bn_keys) // 2], bn_keys[-2], bn_keys[-1]]
             out["bn_keys"] = np.array(pick)
             for i, k in enumerate(pick):                        # running stats after TWO momentum updates (one per stage forward)
                 check("c5 BN running stat " + k, sd[k], rsd[k], 1e-5 * max(1.0, float(rsd[k].abs().max())))
-                out["bn_%d" % i] = rsd[k].numpy()
+                out["bn_%d" % i] = rsd[k].numpy().copy()        # state_dict() hands out the LIVE buffers: the next iteration updates them in place
             cnt = [k for k, _, kind in man_ if kind == "counter"]
             assert all(int(rsd[k]) == 2 for k in cnt)
             out["num_batches_tracked"] = np.int64(2)
