@@ -58,7 +58,7 @@ class PackJob(C.Structure):
 
 class UnpackJob(C.Structure):
     _fields_ = [("packed", C.c_void_p), ("grad", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("ld", C.c_int),
-                ("first", C.c_int64)]
+                ("first", C.c_int64), ("slots", C.c_int), ("slot_stride", C.c_int)]
 
 
 def job_table(jobs, device):
@@ -73,7 +73,7 @@ class WgradArgs(C.Structure):
                 ("d_colsum", C.c_void_p), ("d_relu", C.c_int), ("g_relu", C.c_int),
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
                 ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
-                ("tile_m", C.c_int), ("tile_n", C.c_int), ("target_blocks", C.c_int),
+                ("tile_m", C.c_int), ("tile_n", C.c_int), ("target_blocks", C.c_int), ("algo", C.c_int),
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]
 
 
@@ -102,6 +102,11 @@ _SIGS = {
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
     "awr_get_gemm_products": ([], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "awr_stem_stats": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
+    "awr_stem_pool": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
+    "awr_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P], C.c_int),
+    "awr_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
+    "awr_bn_bwd_finalize": ([_P, _I, _L, _P, _P, _P, _P, _P, _I, _P], C.c_int),
     "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P], C.c_int),
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),
     "awr_channel_stats": ([_P, _L, _I, _P, _P], C.c_int),

@@ -21,6 +21,7 @@ SOURCES = {
     "awr_head.hip": ["-ffp-contract=off"],
     "awr_elem.hip": [],
     "awr_conv.hip": [],
+    "awr_stem.hip": [],
 }
 
 

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     const int cslices = a.Cin / BK;
     const int ksteps = ph.ntaps * cslices;
     float4 ra[RA], rb[NP ? RB3 : RB];
+    float4 rsc = make_float4(1, 1, 1, 1), rsh = make_float4(0, 0, 0, 0);     // fused input affine of the staged slice's channels
     unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
     int c0_staged = 0;
 
@@ -388,16 +389,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
 #pragma unroll
             for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
         }
+        if (a.in_scale) {      // requested together with the data: in registers by the time the slice is stored (no load -> wait in the store phase)
+            rsc = ld4(a.in_scale + c0 + kc);
+            rsh = ld4(a.in_shift + c0 + kc);
+        }
         okmask = tapmask;
         c0_staged = c0;
     };
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
     auto store_slice = [&]() {
         if (a.in_scale) {
-            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
+                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], rsc, rsh, a.relu_in);
         } else if (a.relu_in) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
@@ -745,7 +749,163 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
                 const float4 v = red[g * FM + tid];
                 tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
             }
-            float* o = a.d_colsum + tcd * BM + da_c;
+            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
+            atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient, one wave per filter tap
+// ------------------------------------------------------------------------------------------
+// The kernel above gives every (tap, channel tile, pixel chunk) its own workgroup: the KS*KS taps of a filter each re-stream
+// the same D pixels and a shifted window of the same G pixels (PMC, 64-channel 3x3 layer at batch 64: 411 MB of HBM traffic
+// per launch against 134 MB of operands), and a 64x64 workgroup tile carries only 16 MFMAs per wave between two barriers.
+// Here a workgroup owns a 64 x 64 (cd x cg) channel tile for ALL taps: its K-slices are PH x 8 patches of D pixels, staged in
+// LDS once together with the halo'd patch of G pixels they touch -- and a wave contracts them for ONE ROW of taps and one 32x32
+// quadrant of the channel tile (KS accumulator tiles): the B-operand fragment of tap (ty, tx) is the G pixel of the A-operand's
+// D pixel shifted by that tap, i.e. the same LDS address plus a constant.  4 KS waves per workgroup = KS per SIMD, evenly.
+// Per K-slice a wave issues KS x (pixels / 2) MFMAs between two barriers, operand bytes per MFMA fall by roughly the number
+// of taps, and the slices are double-buffered in LDS (one barrier each).
+//   SG: stride of the gathered operand (1: 3x3 conv; 2: strided 3x3 conv, 4x4 transposed conv); KS: taps per axis; PH: patch rows
+template <int SG, int KS, int PH>
+__global__ __launch_bounds__(64 * KS * 4) void conv_wgrad_taps_kernel(const awr_wgrad_args a, int patches_per_wg, int pc_log, int pr_log) {
+    constexpr int NW = KS * 4, NTHR = 64 * NW;
+    constexpr int PP = PH * 8;                          // D pixels per K-slice
+    constexpr int GH = (PH - 1) * SG + KS, GW = 7 * SG + KS, GP = GH * GW;     // halo'd G patch
+    constexpr int ND = PP * 16, NG = GP * 16;           // float4 per slice (64 channels = 16 float4 per pixel)
+    constexpr int RD = (ND + NTHR - 1) / NTHR, RG = (NG + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float Ds[2][PP * 64];
+    __shared__ __attribute__((aligned(16))) float Gs[2][GP * 64];
+
+    const int tiles_cg = (a.Cg + 63) >> 6;
+    const int tcg = blockIdx.x % tiles_cg, tcd = blockIdx.x / tiles_cg;
+    const int npatch = a.B << (pc_log + pr_log);
+    const int p_begin = blockIdx.y * patches_per_wg;
+    int p_end = p_begin + patches_per_wg;
+    if (p_end > npatch) p_end = npatch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int trow = wave >> 2, qi = (wave >> 1) & 1, qj = wave & 1;       // tap row, quadrant (cd half, cg half) of this wave
+    const int half = lane >> 5, l31 = lane & 31;
+    const int dmin_y = a.dy[0], dmin_x = a.dx[0];      // taps are listed row-major from the top-left one
+
+    // staging roles (fixed for the whole kernel): float4 e = tid + NTHR * i of the D patch / of the G patch
+    const int c4 = tid & 15;
+    const bool d_cok = tcd * 64 + 4 * c4 < a.Cd, g_cok = tcg * 64 + 4 * c4 < a.Cg;
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)a.B * a.Hd * a.Wd * a.Cd * 4u);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
+    int d_r[RD], d_c[RD], g_r[RG], g_c[RG];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+        const int e = tid + NTHR * i, p = e >> 4;
+        d_r[i] = e < ND ? p >> 3 : -1;
+        d_c[i] = p & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int e = tid + NTHR * i, gp = e >> 4;
+        g_r[i] = e < NG ? gp / GW : -(1 << 20);
+        g_c[i] = gp % GW;
+    }
+    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
+    if (a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * 64 + 4 * c4); dsh = ld4(a.d_shift + tcd * 64 + 4 * c4); }
+    if (a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * 64 + 4 * c4); gsh = ld4(a.g_shift + tcg * 64 + 4 * c4); }
+    const bool do_colsum = a.d_colsum != nullptr && tcg == 0;
+    float4 csum = make_float4(0, 0, 0, 0);
+
+    float4 rd[RD], rg[RG];
+    unsigned g_ok = 0;
+    auto load_slice = [&](int patch) {
+        const int pc = patch & ((1 << pc_log) - 1), pr = (patch >> pc_log) & ((1 << pr_log) - 1), b = patch >> (pc_log + pr_log);
+        const int py0 = pr * PH, px0 = pc * 8;
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+            const bool ok = d_r[i] >= 0 && d_cok;
+            rd[i] = buf_ld4(rs_d, ok ? (unsigned)((b * a.Hd + py0 + d_r[i]) * a.Wd + px0 + d_c[i]) * a.Cd * 4u + (unsigned)(tcd * 64 + 4 * c4) * 4u : OOB);
+        }
+        g_ok = 0;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int gy = py0 * SG + dmin_y + g_r[i], gx = px0 * SG + dmin_x + g_c[i];
+            const bool ok = g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
+            rg[i] = buf_ld4(rs_g, ok ? (unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg * 4u + (unsigned)(tcg * 64 + 4 * c4) * 4u : OOB);
+            g_ok |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto store_slice = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+            if (d_r[i] < 0) continue;
+            if (a.d_scale && d_cok) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
+            if (do_colsum) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
+            st4(&Ds[buf][((d_r[i] << 3) + d_c[i]) * 64 + 4 * c4], rd[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            if (g_r[i] < 0) continue;
+            if (a.g_scale && (g_ok & (1u << i))) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);      // padding stays zero
+            st4(&Gs[buf][(g_r[i] * GW + g_c[i]) * 64 + 4 * c4], rg[i]);
+        }
+    };
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // fragment addresses: D pixel p = 2 kp + half of the patch (row p >> 3, column p & 7); its G pixel for tap (trow, j) sits
+    // j G-pixels further along the row
+    const int a_lane = half * 64 + qi * 32 + l31;
+    const int b_lane = (trow * GW + half * SG) * 64 + qj * 32 + l31;
+
+    if (p_begin < p_end) {
+        load_slice(p_begin);
+        store_slice(0);
+    }
+    __syncthreads();
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        const int cur = (patch - p_begin) & 1;
+        const bool more = patch + 1 < p_end;
+        if (more) load_slice(patch + 1);
+        const float* dsl = &Ds[cur][a_lane];
+        const float* gsl = &Gs[cur][b_lane];
+#pragma unroll
+        for (int kp = 0; kp < PP / 2; ++kp) {
+            const int p0 = 2 * kp;
+            const int goff = ((p0 >> 3) * SG * GW + (p0 & 7) * SG) * 64;
+            const float fa = dsl[p0 * 64];
+            float fb[KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) fb[j] = gsl[goff + j * 64];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], acc[j], 0, 0, 0);
+        }
+        if (more) store_slice(cur ^ 1);
+        __syncthreads();
+    }
+
+    {
+        const int cg = tcg * 64 + qj * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = tcd * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + trow * KS + j) * a.ld + cg, acc[j][r]);
+            }
+    }
+    if (do_colsum) {      // fold the staging threads that share a channel chunk through LDS, one atomic per channel
+        float4* red = reinterpret_cast<float4*>(&Gs[0][0]);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 16 && d_cok) {
+            float4 tsum = make_float4(0, 0, 0, 0);
+            for (int g = tid; g < NTHR; g += 16) {
+                const float4 v = red[g];
+                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
+            }
+            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * 64 + 4 * tid;
             atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
         }
     }
@@ -936,7 +1096,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const awr_wgrad_a
             csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
         }
         if (upg[0] == 0 && ucol[0] != OOB) {
-            float* o = a.d_colsum + tcd * BM + uch[0];
+            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + uch[0];
             atomicAdd(o + 0, csum.x); atomicAdd(o + 1, csum.y); atomicAdd(o + 2, csum.z); atomicAdd(o + 3, csum.w);
         }
     }
@@ -1053,15 +1213,51 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
     return AWR_OK;
 }
 
+// geometry served by the one-wave-per-tap kernel: 3x3 (stride 1 / 2) and 4x4 stride-2 filters whose taps are listed row-major
+// from the top-left one, power-of-two D maps that a PH x 8 patch tiles
+static int wgrad_taps_patch_rows(const awr_wgrad_args* a) {
+    const int ks = a->T == 9 ? 3 : a->T == 16 ? 4 : 0;
+    if (!ks || (ks == 4 && a->sg != 2) || (a->sg != 1 && a->sg != 2)) return 0;
+    for (int t = 0; t < a->T; ++t)
+        if (a->dy[t] != a->dy[0] + t / ks || a->dx[t] != a->dx[0] + t % ks) return 0;
+    const int ph = a->sg == 1 ? 4 : 2;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!pow2(a->Hd) || !pow2(a->Wd) || a->Wd < 8 || a->Hd < ph) return 0;
+    return ph;
+}
+
 static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
     AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),
                 "conv_wgrad: scale/shift must come in pairs");
+    AWR_REQUIRE(a->algo >= 0 && a->algo <= 2, "conv_wgrad: algo must be 0 (automatic), 1 (workgroup per tap) or 2 (wave per tap)");
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
                 "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
+    static const int env_algo = []() { const char* e = getenv("AWR_WGRAD_ALGO"); return e ? atoi(e) : 0; }();      // study hook
+    const int ph = g_products == 1 ? wgrad_taps_patch_rows(a) : 0;
+    const int algo = a->algo ? a->algo : (env_algo ? env_algo : 1);
+    AWR_REQUIRE(a->algo != 2 || ph, "conv_wgrad: algo 2 (wave per tap) does not serve this geometry / product mode");
+    if (ph && algo == 2) {
+        auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
+        const int pc_log = log2i(a->Wd / 8), pr_log = log2i(a->Hd / ph);
+        const int64_t npatch = (int64_t)a->B << (pc_log + pr_log);
+        const int tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64);
+        const int want = a->target_blocks > 0 ? a->target_blocks : 256;
+        int64_t nsplit = (want + tiles - 1) / tiles;
+        if (nsplit > npatch / 4) nsplit = npatch / 4;            // at least 4 K-slices per workgroup
+        if (nsplit < 1) nsplit = 1;
+        const int64_t ppw = (npatch + nsplit - 1) / nsplit;
+        nsplit = (npatch + ppw - 1) / ppw;
+        const dim3 grid((unsigned)tiles, (unsigned)nsplit);
+        hipStream_t st = as_stream(stream);
+        if (a->T == 16) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 4, 2>), grid, dim3(1024), 0, st, *a, (int)ppw, pc_log, pr_log);
+        else if (a->sg == 2) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 3, 2>), grid, dim3(768), 0, st, *a, (int)ppw, pc_log, pr_log);
+        else hipLaunchKernelGGL((conv_wgrad_taps_kernel<1, 3, 4>), grid, dim3(768), 0, st, *a, (int)ppw, pc_log, pr_log);
+        return check_launch("conv_wgrad_taps_kernel");
+    }
     // measured (tools/microbench_gemm.py, AWR_WGRAD_BLOCKS sweep): 64x64 tiles with ~3072 workgroups win on the small
     // feature maps; the 128x64 (cd x cg) tile with ~2048 workgroups wins once there are >= 128K pixels to contract.
     int TM = (a->Cd > 64 && M >= 131072) ? 2 : 1, TN = 1;

@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void unpack_batched_kernel(const awr_unpack_jo
         const int cc = d1 - c0 < cch ? d1 - c0 : cch;
         for (int i = threadIdx.x; i < cc * T; i += 256) {
             const int t = i / cc, c = i - t * cc;
-            tile[c * TS + t] = jb.packed[((int64_t)a * T + t) * jb.ld + c0 + c];
+            const float* src = jb.packed + ((int64_t)a * T + t) * jb.ld + c0 + c;
+            float v = src[0];
+            for (int k = 1; k < jb.slots; ++k) v += src[(int64_t)k * jb.slot_stride];      // fixed order
+            tile[c * TS + t] = v;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < cc * T; i += 256) {
@@ -632,6 +635,14 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
                        coef, n4, C, dy, dy_add, g_out);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                        int accumulate, void* stream) {
+    AWR_REQUIRE(sums && invstd && coef && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), sums, C, 1.0 / (double)count, gamma, invstd,
+                       coef, dgamma, dbeta, accumulate);
+    return check_launch("bn_bwd_finalize_kernel");
 }
 
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream) {

@@ -28,7 +28,6 @@ constexpr int ST_KS = 13;        // MFMA K-steps (2 taps each; tap 25 carries a 
 constexpr int ST_PW = 48;        // patch pitch of the 16x16-pixel kernels: the two 16-pixel runs of a half-wave sit 16 banks apart
 constexpr int ST_PH = 20;        // patch rows / used columns (16 + 2 * 2)
 constexpr int SP_PW = 24;        // patch pitch of the pooling kernel (21 used columns)
-constexpr int SP_R = 17;         // conv rows / columns under an 8x8 tile of pooled pixels (2 * 8 + 1)
 
 // MFMA 32x32 C/D layout: lane = column (l & 31), register r of half-wave h = row (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -111,20 +110,23 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // conv -> affine (BatchNorm) -> ReLU -> MaxPool(3,2,1): writes the pooled NHWC map (+ argmax)
 // ------------------------------------------------------------------------------------------
-// grid (tiles of 8x8 POOLED pixels, channel half, image); 320 threads = 5 waves x 2 tiles of 32 conv pixels: the 17x17 conv
-// pixels under the tile (289, padded to 320) go through LDS as act[pixel][32 channels], then 256 threads pool them.
+// grid (tiles of 4 rows x 8 columns of POOLED pixels, channel half, image); 320 threads = 5 waves x one tile of 32 conv pixels:
+// the 9 x 17 conv pixels under the tile (153, padded to 160) go through LDS as act[pixel][32 channels] (20 KB: six workgroups
+// per CU keep the load -> conv -> pool -> store chains of different tiles overlapped), then 256 threads pool them.
+constexpr int SP_RH = 9, SP_RW = 17, SP_PY = 4, SP_PX = 8;      // conv rows / columns under a tile; pooled tile shape
+
 __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
                                                         float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
-    __shared__ float patch[21 * SP_PW];
-    __shared__ __attribute__((aligned(16))) float act[320 * 32];
+    __shared__ float patch[(SP_RH + 4) * SP_PW];
+    __shared__ __attribute__((aligned(16))) float act[160 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
-    const int tiles_x = Wo >> 3, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tiles_x = Wo / SP_PX, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int b = blockIdx.z, ch0 = blockIdx.y * 32;
-    const int oy0 = ty * 8, ox0 = tx * 8;
-    for (int i = tid; i < 21 * 21; i += 320) {
-        const int py = i / 21, px = i - py * 21;
+    const int oy0 = ty * SP_PY, ox0 = tx * SP_PX;
+    for (int i = tid; i < (SP_RH + 4) * (SP_RW + 4); i += 320) {
+        const int py = i / (SP_RW + 4), px = i - py * (SP_RW + 4);
         const int gy = 2 * oy0 - 3 + py, gx = 2 * ox0 - 3 + px;
         patch[py * SP_PW + px] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
     }
@@ -132,25 +134,23 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
     stem_lane_init<SP_PW>(sl, w, ch0 + m, h);
     const float sc = scale[ch0 + m], sh = shift[ch0 + m];
     __syncthreads();
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int i = wave * 2 + ti;
-        int q = 32 * i + m;
-        q = q < SP_R * SP_R ? q : SP_R * SP_R - 1;       // rows 289..319 of the last tile: recomputed, never pooled
-        const int qy = q / SP_R, qx = q - qy * SP_R;
+    {
+        int q = 32 * wave + m;
+        q = q < SP_RH * SP_RW ? q : SP_RH * SP_RW - 1;       // rows 153..159 of the last tile: recomputed, never pooled
+        const int qy = q / SP_RW, qx = q - qy * SP_RW;
         const f32x16 acc = stem_conv_tile(patch, qy * SP_PW + qx, sl);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[(32 * i + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
+        for (int r = 0; r < 16; ++r) act[(32 * wave + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
     }
     __syncthreads();
-    for (int o = tid; o < 512; o += 320) {
-        const int c4 = o & 7, pp = o >> 3, py = pp >> 3, px = pp & 7;
+    if (tid < SP_PY * SP_PX * 8) {
+        const int c4 = tid & 7, pp = tid >> 3, py = pp >> 3, px = pp & 7;
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int am[4] = {0, 0, 0, 0};
         // window row dy <-> conv row 2 oy - 1 + dy: only row / column -1 can fall outside (H, W even), torch pads with -inf
         for (int dy = (oy0 + py == 0) ? 1 : 0; dy < 3; ++dy)
             for (int dx = (ox0 + px == 0) ? 1 : 0; dx < 3; ++dx) {
-                const float4 v = ld4(&act[((2 * py + dy) * SP_R + 2 * px + dx) * 32 + 4 * c4]);
+                const float4 v = ld4(&act[((2 * py + dy) * SP_RW + 2 * px + dx) * 32 + 4 * c4]);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -170,15 +170,19 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------
 // WGRAD = 0: sums[slot][0][c] += sum g, sums[slot][1][c] += sum g * xhat          (g = d loss / d bn-output, masked)
 // WGRAD = 1: dY = gi (g - k1 - xhat k2);  dw[slot][c][tap] += sum_pixels dY[pixel][c] * image[pixel + tap]
-// grid (groups of TPW tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels per 16x16 tile
+// Max-pool backward as a SCATTER: every pooled window hands its gradient to the one pixel its argmax names, so the 9 x 9
+// windows that touch a 16x16 tile are routed into an LDS tile gt[pixel][channel] -- 81 (window, channel) items per channel
+// instead of testing, for each of the 256 pixels, the up to four windows that contain it.  Windows of equal row / column
+// parity never share a pixel (3 wide, 4 apart), so the four parity classes are added one after the other without atomics:
+// the sum order is fixed (deterministic).
+// grid (groups of tiles_per_wg tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels
 template <int WGRAD>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ coef4,
                                                        const float* __restrict__ bcoef, const float* __restrict__ dpool,
                                                        const uint8_t* __restrict__ argmax, int H, int W, int tiles_per_wg,
                                                        double* __restrict__ sums, float* __restrict__ dw) {
     __shared__ float patch[ST_PH * ST_PW];
-    __shared__ __attribute__((aligned(16))) float dpw[81 * 32];       // pooled-gradient windows [wy][wx][channel]
-    __shared__ __attribute__((aligned(16))) uint8_t amw[81 * 32];     // their argmax codes
+    __shared__ __attribute__((aligned(16))) float gt[256 * 32];       // pooled gradient routed to the tile's pixels [pixel][channel]
     __shared__ float red[WGRAD ? 4 * 1024 : 4 * 2 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     if (WGRAD) { k1 = bcoef[ch0 + m]; k2 = bcoef[64 + ch0 + m]; gi = bcoef[128 + ch0 + m]; }
     const int tm = m < ST_T ? m : 0;
     const int toff = (tm / 5) * ST_PW + (tm % 5);          // second GEMM: this lane's column = tap m
-    const int hoff = 64 * h + m;                            // window address part that depends on the lane
+    // scatter items of this thread, one per parity class (cy, cx): window (cy + 2 a, cx + 2 b), channels 4 c4 .. 4 c4 + 3
+    const int c4 = tid & 7, wi = tid >> 3;
     float s1 = 0.f, s2 = 0.f;
     f32x16 wacc;
 #pragma unroll
@@ -201,47 +206,50 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const int tile = blockIdx.x * tiles_per_wg + tt;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * 16, x0 = tx * 16;
+        float4 itd[4];
+        uchar4 ita[4];
+        int itp[4];                     // window (wy << 4 | wx) of the item, -1 = none
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int cy = cls >> 1, cx = cls & 1, nx = cx ? 4 : 5, ny = cy ? 4 : 5;
+            const int wy = cy + 2 * (wi / nx), wx = cx + 2 * (wi % nx);
+            const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+            itp[cls] = -1;
+            if (wi < nx * ny && oy < Ho && ox < Wo) {
+                const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * 64 + ch0 + 4 * c4;
+                itd[cls] = ld4(dpool + o);
+                ita[cls] = *reinterpret_cast<const uchar4*>(argmax + o);
+                itp[cls] = (wy << 4) | wx;
+            }
+        }
         if (tt) __syncthreads();           // the previous tile's readers are done with the LDS arrays
         stem_load_patch16(patch, img, b, y0, x0, H, W);
-        for (int i = tid; i < 81 * 8; i += 256) {
-            const int c4 = i & 7, win = i >> 3, wy = win / 9, wx = win - wy * 9;
-            const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-            float4 d = make_float4(0, 0, 0, 0);
-            uchar4 a = make_uchar4(255, 255, 255, 255);
-            if (oy < Ho && ox < Wo) {
-                const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * 64 + ch0 + 4 * c4;
-                d = ld4(dpool + o);
-                a = *reinterpret_cast<const uchar4*>(argmax + o);
-            }
-            st4(&dpw[win * 32 + 4 * c4], d);
-            *reinterpret_cast<uchar4*>(&amw[win * 32 + 4 * c4]) = a;
-        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st4(&gt[(tid + 256 * i) * 4], make_float4(0, 0, 0, 0));
         __syncthreads();
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            if (itp[cls] >= 0) {
+                const int ly0 = 2 * (itp[cls] >> 4) - 1, lx0 = 2 * (itp[cls] & 15) - 1;       // the window's top-left pixel (may be -1)
+                const float dv[4] = {itd[cls].x, itd[cls].y, itd[cls].z, itd[cls].w};
+                const int av[4] = {ita[cls].x, ita[cls].y, ita[cls].z, ita[cls].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ky = av[j] >= 6 ? 2 : (av[j] >= 3 ? 1 : 0), kx = av[j] - 3 * ky;
+                    const int ly = ly0 + ky, lx = lx0 + kx;
+                    if ((unsigned)ly < 16u && (unsigned)lx < 16u) gt[(ly * 16 + lx) * 32 + 4 * c4 + j] += dv[j];
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int i = wave * 2 + ti;
             const int q = 32 * i + m;
             f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl);
-            // pixel of register r: ly = 2 i + (r >> 3), lx = 8 ((r >> 2) & 1) + (r & 3) + 4 h   (parities are compile-time)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ly = 2 * i + (r >> 3);
-                const int lx0 = 8 * ((r >> 2) & 1) + (r & 3);      // + 4 h
-                // windows holding row ly: even -> (ly/2, ky 1); odd -> ((ly-1)/2, ky 2), ((ly+1)/2, ky 0); same for columns
-                const int ny = (r >> 3) & 1 ? 2 : 1, nx = (r & 1) ? 2 : 1;
-                float g = 0.f;
-#pragma unroll
-                for (int a = 0; a < ny; ++a) {
-                    const int wy = ny == 1 ? ly >> 1 : ((ly - 1) >> 1) + a;
-                    const int ky = ny == 1 ? 1 : (a == 0 ? 2 : 0);
-#pragma unroll
-                    for (int c = 0; c < nx; ++c) {
-                        const int wx0 = nx == 1 ? lx0 >> 1 : ((lx0 - 1) >> 1) + c;      // + 2 h
-                        const int kx = nx == 1 ? 1 : (c == 0 ? 2 : 0);
-                        const int wa = (wy * 9 + wx0) * 32 + hoff;
-                        g += amw[wa] == ky * 3 + kx ? dpw[wa] : 0.f;
-                    }
-                }
+                float g = gt[(32 * i + mfma_row(r, h)) * 32 + m];
                 const float y = acc[r];
                 g = y * sc + sh > 0.f ? g : 0.f;
                 const float xh = (y - mu) * is;
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                 }
             }
             if (WGRAD) {
-                // dW[channel][tap] += sum over the tile's 32 pixels: K-step r contracts the pixels of register r (one per half-wave)
+                // dW[channel][tap] += sum over the tile's 32 pixels: K-step r contracts the pixels of register r (one per half-wave):
+                // pixel row 2 i + (r >> 3), column 8 ((r >> 2) & 1) + (r & 3) + 4 h of the 16x16 tile
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pb = (2 * i + (r >> 3)) * ST_PW + 8 * ((r >> 2) & 1) + (r & 3) + 4 * h;
@@ -325,8 +334,8 @@ int awr_stem_pool(const float* img, const float* w, const float* scale, const fl
                   uint8_t* argmax, void* stream) {
     AWR_REQUIRE(img && w && scale && shift && pooled, "stem_pool: null pointer");
     AWR_STEM_GEOMETRY("stem_pool");
-    hipLaunchKernelGGL(stem_pool_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(320), 0, as_stream(stream), img, w, scale, shift, H, W, pooled,
-                       argmax);
+    hipLaunchKernelGGL(stem_pool_kernel, dim3((H / 2 / SP_PY) * (W / 2 / SP_PX), 2, B), dim3(320), 0, as_stream(stream), img, w, scale, shift, H, W,
+                       pooled, argmax);
     return check_launch("stem_pool_kernel");
 }
 

@@ -21,6 +21,8 @@ from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, alloc_pack
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 STAT_SLOTS = 16     # AWR_STAT_SLOTS in include/awr_hip.h
+# backward ops that neither read the weight-gradient scratch arena nor hand gradients out: the side streams need not be joined for them
+_NO_JOIN = ("awr_bn_bwd_reduce", "awr_bn_bwd_apply", "awr_bn_bwd_finalize", "awr_maxpool_bwd", "awr_upsample2_bwd", "awr_add", "__zero__")
 
 
 def plan_buckets(writes, n_active, n_buckets):
@@ -100,13 +102,14 @@ class ConvLayer:
     def bias_ptr(self):
         return self.bias
 
-    def wgrad_unpack_jobs(self, R, ld, bsum):
-        """(packed pointer, gradient view, d0, d1, T, ld) scatter jobs: packed split-K result -> checkpoint layout."""
+    def wgrad_unpack_jobs(self, R, ld, bsum, cd):
+        """(packed pointer, gradient view, d0, d1, T, ld, slots, slot stride) scatter jobs: packed split-K result -> checkpoint
+        layout; the bias column sums come as STAT_SLOTS copies of `cd` floats."""
         prob_d0, prob_d1 = (self.spec.cout, self.spec.cin) if self.spec.kind == "conv" else (self.spec.cin, self.spec.cout)
-        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld)]
+        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld, 1, 0)]
         if bsum is not None:
             n = self.gbias.numel()
-            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n))
+            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n, STAT_SLOTS, cd))
         return jobs
 
     def bias_grad_target(self):
@@ -144,11 +147,11 @@ class HeadLayer(ConvLayer):
     def bias_ptr(self):
         return self.bias_cat
 
-    def wgrad_unpack_jobs(self, R, ld, bsum):
+    def wgrad_unpack_jobs(self, R, ld, bsum, cd):
         J, cin = self.J, self.cin
-        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld)]
-        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels
-            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J)]
+        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld, 1, 0), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld, 1, 0)]
+        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels, STAT_SLOTS copies
+            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J, STAT_SLOTS, cd), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J, STAT_SLOTS, cd)]
         return jobs
 
 
@@ -262,6 +265,68 @@ class Plan:
         self._f("awr_stem_im2col", L.ptr(img_buf), self.B, H, W, L.ptr(cols.buf))
         return cols
 
+    # ---- forward branches that may run beside the main chain (ResNet downsample 1x1 + its BatchNorm) --------------------------
+    def fork(self, sid=0):
+        """Ops emitted until end_fork() only depend on tensors that are final now: `_run` issues them on side stream `sid`
+        (modulo the number of side streams the engine created; without side streams everything stays in order)."""
+        self._fork_sid = sid
+        self.fwd_ops.append((None, (sid,), "__fork__"))
+
+    def end_fork(self, result):
+        """`result` (a T) is what the branch produced; the first op that consumes it joins its side stream."""
+        self.fwd_ops.append((None, (self._fork_sid,), "__endfork__"))
+        if not hasattr(self, "_fork_results"):
+            self._fork_results = {}
+        self._fork_results[id(result)] = self._fork_sid
+
+    def _join_if(self, t):
+        sid = getattr(self, "_fork_results", {}).pop(id(t), None) if t is not None else None
+        if sid is not None:
+            self.fwd_ops.append((None, (sid,), "__join__"))
+
+    def stem_pool(self, img_buf, conv, bn, H, W):
+        """ResNet stem (resnet_deconv.py:31-36, :118-121): conv 5x5 (1 -> 64) -> BatchNorm -> ReLU -> MaxPool(3,2,1) as the fused
+        kernels of csrc/awr_stem.hip -- the full-resolution map is never written, forward or backward."""
+        B = self.B
+        assert conv.spec.cout == 64 and conv.bias is None, "the fused stem is the ResNet one: 64 channels, no conv bias"
+        y = self.new(B, H // 2, W // 2, 64, name=conv.name + ".pool")
+        w, tag = L.ptr(conv.w), ":" + conv.name
+        npix = B * H * W
+        if not self.training:
+            sc, sh = self.fold_bn(bn)
+            self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(sc), L.ptr(sh), B, H, W, L.ptr(y.buf), None, None), "awr_stem_pool" + tag))
+            self.macs["awr_stem_pool" + tag] = npix * 64 * 25
+            return y
+        stats = self.alloc(STAT_SLOTS, 2, 64, dtype=torch.float64, zero=True)
+        coef4 = self.alloc(4, 64)            # [scale | shift | mean | invstd]
+        arg = self.alloc(B, H // 2, W // 2, 64, dtype=torch.uint8)
+        mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
+        self.fwd_ops.append((L.lib.awr_stem_stats, (L.ptr(img_buf), w, B, H, W, L.ptr(stats), None), "awr_stem_stats" + tag))
+        self._f("awr_bn_finalize", L.ptr(stats), 64, npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom, BN_EPS,
+                L.ptr(coef4[0]), L.ptr(coef4[1]), L.ptr(coef4[2]), L.ptr(coef4[3]))
+        self.bns.append(bn)
+        self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(coef4[0]), L.ptr(coef4[1]), B, H, W, L.ptr(y.buf), L.ptr(arg), None),
+                             "awr_stem_pool" + tag))
+        # algorithmic work: the conv once forward, its weight gradient once backward (the recomputations are not algorithmic)
+        self.macs["awr_stem_pool" + tag] = self.macs["awr_stem_bwd_wgrad" + tag] = npix * 64 * 25
+        self.macs["awr_stem_stats" + tag] = self.macs["awr_stem_bwd_reduce" + tag] = 0
+
+        def bwd():
+            assert y.grad is not None, "no gradient reached the stem"
+            sums = self.alloc(STAT_SLOTS, 2, 64, dtype=torch.float64, zero=True)
+            coef = self.alloc(3, 64)
+            slots = self.alloc(STAT_SLOTS * 64 * 25, zero=True)
+            self.bwd_ops.append((L.lib.awr_stem_bwd_reduce, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(y.grad), L.ptr(arg), B, H, W, L.ptr(sums), None),
+                                 "awr_stem_bwd_reduce" + tag))
+            self._b("awr_bn_bwd_finalize", L.ptr(sums), 64, npix, L.ptr(bn.gamma), L.ptr(coef4[3]), L.ptr(coef), L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
+            self._note_grad(bn.ggamma)
+            self._note_grad(bn.gbeta)
+            self.bwd_ops.append((L.lib.awr_stem_bwd_wgrad, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(coef), L.ptr(y.grad), L.ptr(arg), B, H, W,
+                                                            L.ptr(slots), L.ptr(conv.gw), None), "awr_stem_bwd_wgrad" + tag))
+            self._note_grad(conv.gw)
+        self.nodes.append(bwd)
+        return y
+
     def conv(self, x, layer, in_affine=None, relu_in=False, out_affine=None, res=None, relu_out=False, want_stats=False,
              use_bias=True):
         """y = conv(x) [+bias] [*s+t] [+res] [relu].  in_affine/out_affine: (scale, shift) device vectors."""
@@ -275,6 +340,7 @@ class Plan:
             y.stats = self.alloc(STAT_SLOTS, 2, prob["N"], dtype=torch.float64, zero=True)
         bias = layer.bias_ptr() if use_bias else None
         assert res is None or res.lazy is None, "a fused residual must be a materialised tensor"
+        self._join_if(res)
         if x.lazy is not None:
             assert in_affine is None
             in_affine, relu_in = (x.lazy[0], x.lazy[1]), x.lazy[2]
@@ -311,8 +377,8 @@ class Plan:
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
         xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
         bsum = None
-        if fused_bias:
-            bsum = self._scratch(y.shape[3])
+        if fused_bias:           # STAT_SLOTS copies (the kernel spreads its atomics), summed by the scatter job
+            bsum = self._scratch(STAT_SLOTS * y.shape[3])
             xa["d_colsum"] = bsum
         wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
         self._keep.append(wa)
@@ -324,8 +390,8 @@ class Plan:
             self._side_ok.add("awr_conv_wgrad:" + layer.name)
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
-        for packed_ptr, grad, d0, d1, T_, ld_ in layer.wgrad_unpack_jobs(R, ld, bsum):
-            job = L.UnpackJob(packed_ptr, L.ptr(grad), d0, d1, T_, ld_, 0)
+        for packed_ptr, grad, d0, d1, T_, ld_, slots, sstride in layer.wgrad_unpack_jobs(R, ld, bsum, y.shape[3]):
+            job = L.UnpackJob(packed_ptr, L.ptr(grad), d0, d1, T_, ld_, 0, slots, sstride)
             self._unpack_jobs.append(job)
             self._note_grad(grad, job)
         # data gradient
@@ -376,6 +442,7 @@ class Plan:
             a = T(y.buf, True, bn.name + ".act(lazy)", lazy=(sc, sh, bool(relu)))
         else:
             a = self.new(B, H, W, C_, name=bn.name + ".act")
+            self._join_if(res)
             self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
                     y.npix, C_)
         self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh, coef4))
@@ -442,6 +509,7 @@ class Plan:
         """out = up1 + nearest_upsample_x2(low)   (hourglass.py:77,:88)"""
         B, Hl, Wl, C_ = low.shape
         assert up1.lazy is None and low.lazy is None
+        self._join_if(up1)
         y = self.new(B, 2 * Hl, 2 * Wl, C_, name=up1.name + ".upadd")
         self._f("awr_upsample2_add", L.ptr(up1.buf), L.ptr(low.buf), B, Hl, Wl, C_, L.ptr(y.buf))
         if self.training:
@@ -484,7 +552,7 @@ class Plan:
         for i, st in enumerate(self._head_states):
             st["used"] = i in supervised_stages
         # split-K scratch for every weight gradient, as one arena (capacity = all packed gradients of the used layers)
-        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) + round_up(l.spec.cout_pad, 4)
+        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) + STAT_SLOTS * round_up(l.spec.cout_pad, 4)
                                 for l in self.layers) + 64
         first = len(self.bwd_ops)
         self.bwd_ops.append(None)        # placeholder for the scratch fill (kept in place so recorded op indices stay valid)
@@ -629,20 +697,58 @@ class Plan:
     # prologue/epilogue/barrier bubbles are filled by the other's MFMAs (+4.6 % on the ResNet18 step).
     side_streams = None
 
+    # Data parallel + side streams: a bucket's scatter (awr_unpack_wgrads_batched) and its all-reduce are issued on THIS stream, which
+    # waits for the main chain and for the weight-gradient streams at the hand-off point -- the main stream itself never waits for
+    # the side streams in the middle of the backward, so the data-gradient chain keeps running under the bucket's collective.
+    comm_stream = None
+
     def _run(self, ops):
         s = L.stream()
         timer = self.timer
         side = self.side_streams if (ops is self.bwd_ops and timer is None) else None
-        pending, nside = False, 0
+        comm = self.comm_stream if (side is not None and self.bucket_hook is not None and self.n_buckets > 1) else None
+        pending, nside, handed = False, 0, False
         if side is not None:
             main = torch.cuda.current_stream()
+        fside = self.side_streams if (ops is self.fwd_ops and timer is None and self.side_streams) else None
+        if fside is not None:
+            main = torch.cuda.current_stream()
+
+        def hand_off():                          # everything the bucket needs (main chain so far + weight gradients) -> comm stream
+            comm.wait_stream(main)
+            for st in side:
+                comm.wait_stream(st)
         for fn, args, name in ops:
-            if side is not None and pending and not name.startswith("awr_conv_") and name not in ("awr_bn_bwd_reduce", "awr_bn_bwd_apply", "awr_maxpool_bwd", "awr_upsample2_bwd", "awr_add", "__zero__"):
+            if comm is not None and name == "awr_unpack_wgrads_batched":
+                hand_off()
+                handed = True
+                rc = fn(*args[:-1], comm.cuda_stream)
+                if rc != 0:
+                    raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
+                continue
+            if comm is not None and name == "__bucket__":
+                if not handed:
+                    hand_off()
+                handed = False
+                with torch.cuda.stream(comm):    # torch's RCCL stream orders itself after the CURRENT stream at the call
+                    self.bucket_hook(args[0], args[1])
+                continue
+            if side is not None and pending and not name.startswith("awr_conv_") and name not in _NO_JOIN and not name.startswith("awr_stem_"):
                 for st in side:                  # join before anything that consumes the weight-gradient scratch (unpack, buckets, copies)
                     main.wait_stream(st)
                 pending = False
             if fn is None:
-                if name == "__zero__":
+                if name in ("__fork__", "__endfork__", "__join__"):
+                    if fside is not None:
+                        st = fside[args[0] % len(fside)]
+                        if name == "__fork__":
+                            st.wait_stream(main)
+                            s = st.cuda_stream
+                        elif name == "__endfork__":
+                            s = main.cuda_stream
+                        else:
+                            main.wait_stream(st)
+                elif name == "__zero__":
                     args[0].zero_()
                 elif name == "__bucket__":
                     if self.bucket_hook is not None:
@@ -656,7 +762,7 @@ class Plan:
                 st.wait_stream(main)             # its operands (dY, x) are final at this point of the main stream
                 rc = fn(*args[:-1], st.cuda_stream)
                 pending = True
-            elif timer is not None and name.startswith("awr_conv_"):
+            elif timer is not None and name.startswith(("awr_conv_", "awr_stem_")):
                 timer.begin(name)
                 rc = fn(*args[:-1], s)
                 timer.end()
@@ -664,9 +770,11 @@ class Plan:
                 rc = fn(*args[:-1], s)
             if rc != 0:
                 raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
-        if side is not None and pending:
+        if side is not None and (pending or comm is not None):
             for st in side:
                 main.wait_stream(st)
+            if comm is not None:                 # next step's scratch fill / optimiser must see the scatters
+                main.wait_stream(comm)
 
     def forward(self):
         self._run(self.fwd_ops)

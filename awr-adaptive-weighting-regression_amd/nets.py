@@ -379,14 +379,18 @@ class ResNet18Deconv(AwrBackbone):
 
     def build(self, P, img, H):
         Lr = self._layers()
-        c = self._cbr(P, Lr, P.im2col5(img, H, H), "pre.0", "pre.1", True, lazy=True)     # consumed by the max-pool loader only
-        c = P.maxpool(c, 3, 2, 1)
+        c = P.stem_pool(img, Lr["pre.0"], Lr["pre.1"], H, H)      # conv 5x5 -> BN -> ReLU -> MaxPool(3,2,1), one fused kernel family
         for li in range(1, 5):
             for bi in range(2):
                 p = "layer%d.%d" % (li, bi)
                 # the downsample branch is emitted first so that, in the reversed (backward) order, conv1's
                 # full-coverage data gradient initialises d(block input) before the strided 1x1 accumulates
-                r = self._cbr(P, Lr, c, p + ".downsample.0", p + ".downsample.1", False) if (p + ".downsample.0") in Lr else c
+                if (p + ".downsample.0") in Lr:      # 1x1 stride-2 projection + its BatchNorm: independent of conv1 / conv2 until the residual add
+                    P.fork()
+                    r = self._cbr(P, Lr, c, p + ".downsample.0", p + ".downsample.1", False)
+                    P.end_fork(r)
+                else:
+                    r = c
                 o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=True)              # consumed by conv2 only
                 c = self._cbr(P, Lr, o, p + ".conv2", p + ".bn2", True, res=r)
         for i in range(self.ndeconv):
@@ -463,7 +467,11 @@ class HourglassNet(AwrBackbone):
         return P.conv(y, Lr[p + ".conv3"], in_affine=P.fold_bn(Lr[p + ".bn3"]), relu_in=True, res=r)
 
     def _hg(self, P, Lr, x, p, depth):
+        # the skip branch of a level only meets the low-resolution path again at the up-sampling add: issued on its own side
+        # stream, its full-resolution GEMMs fill the chip while the main stream walks the small (<= 16x16) levels
+        P.fork(depth)
         up1 = self._residual(P, Lr, x, p + ".up1")
+        P.end_fork(up1)
         low = self._residual(P, Lr, P.maxpool(x, 2, 2, 0), p + ".low1")
         low = self._hg(P, Lr, low, p + ".low2", depth - 1) if depth > 1 else self._residual(P, Lr, low, p + ".low2")
         low = self._residual(P, Lr, low, p + ".low3")

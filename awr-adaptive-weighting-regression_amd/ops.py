@@ -126,11 +126,12 @@ def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, 
     return a
 
 
-def make_wgrad_args(prob, B, D, G, R, ld, d_affine=None, g_affine=None, d_colsum=None):
+def make_wgrad_args(prob, B, D, G, R, ld, d_affine=None, g_affine=None, d_colsum=None, algo=0):
     """d_affine / g_affine: (scale, shift, relu) applied to the operand while staging (un-materialised BN+ReLU)."""
     a = L.WgradArgs()
     a.D, a.G, a.R = L.ptr(D), L.ptr(G), L.ptr(R)
     a.d_colsum = L.ptr(d_colsum)
+    a.algo = algo
     if d_affine is not None:
         a.d_scale, a.d_shift, a.d_relu = L.ptr(d_affine[0]), L.ptr(d_affine[1]), int(d_affine[2])
     if g_affine is not None:
@@ -194,7 +195,7 @@ def conv_dgrad(spec, dy, wp, hin, win, **kw):
     return out
 
 
-def conv_wgrad(spec, x, dy, grad=None, accumulate=False, x_affine=None, bias_grad=None):
+def conv_wgrad(spec, x, dy, grad=None, accumulate=False, x_affine=None, bias_grad=None, algo=0):
     """Returns the gradient in checkpoint layout (same shape as the layer's weight).  x_affine: (scale, shift, relu)
     when the layer input is relu(x*scale+shift) of the tensor passed as `x`."""
     B, H, W, _ = x.shape
@@ -202,14 +203,17 @@ def conv_wgrad(spec, x, dy, grad=None, accumulate=False, x_affine=None, bias_gra
     ld = prob["Cg"]
     R = torch.zeros(prob["Cd"], len(prob["taps"]), ld, device=x.device, dtype=torch.float32)
     D, G = (dy, x) if prob["D"] == "dy" else (x, dy)
+    bslots = None
     if bias_grad is not None:
         assert prob["D"] == "dy"
-        bias_grad.zero_()
-    a = make_wgrad_args(prob, B, D, G, R, ld, d_colsum=bias_grad, **({"g_affine" if prob["D"] == "dy" else "d_affine": x_affine} if x_affine else {}))
+        bslots = torch.zeros(16, prob["Cd"], device=x.device, dtype=torch.float32)      # AWR_STAT_SLOTS copies, summed below
+    a = make_wgrad_args(prob, B, D, G, R, ld, d_colsum=bslots, algo=algo, **({"g_affine" if prob["D"] == "dy" else "d_affine": x_affine} if x_affine else {}))
     L.call("awr_conv_wgrad", C.byref(a), L.stream())
     if grad is None:
         grad = torch.empty(prob["d0"], prob["d1"], spec.k, spec.k, device=x.device, dtype=torch.float32)
     L.call("awr_unpack_wgrad", L.ptr(R), prob["d0"], prob["d1"], spec.T, ld, L.ptr(grad), int(accumulate), L.stream())
+    if bias_grad is not None:
+        bias_grad.copy_(bslots.sum(0)[:bias_grad.numel()])
     return grad
 
 

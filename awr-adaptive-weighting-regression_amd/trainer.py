@@ -81,6 +81,7 @@ class TrainEngine:
                                  n_buckets=n_buckets if self.dp else 1)
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off)
         self.plan.side_streams = [torch.cuda.Stream(device=dev) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
+        self.plan.comm_stream = torch.cuda.Stream(device=dev) if (wgrad_streams > 0 and self.dp) else None
         self._autotune = bool(autotune)
         self._compiled = False
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
@@ -277,6 +278,8 @@ class InferEngine:
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
+        if self.plan.side_streams is None:          # forward branches (ResNet downsample projections) run beside the main chain
+            self.plan.side_streams = [torch.cuda.Stream(device=net.device) for _ in range(4)]
         self._autotune, self._compiled = bool(autotune), False
         self.J, self.F = net.J, img_size // getattr(net, "downsample", 2)
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)

@@ -284,7 +284,9 @@ def main():
         eng.plan.timer = None
     per = timer.collect()
     macs = eng.plan.macs
-    fam = {"conv_gemm_kernel(fwd+dgrad)": ("awr_conv_gemm:", "awr_conv_dgrad:"), "conv_wgrad_kernel": ("awr_conv_wgrad:",)}
+    fam = {"conv_gemm_kernel(fwd+dgrad)": ("awr_conv_gemm:", "awr_conv_dgrad:"), "conv_wgrad_kernel": ("awr_conv_wgrad:",),
+           "stem kernels (fused direct 5x5 conv+BN+ReLU+pool, fwd+bwd incl. recomputation)": ("awr_stem_",)}
+    per = {n: v for n, v in per.items() if n in macs}
     kern = {}
     for label, prefixes in fam.items():
         fl = sum(2.0 * macs[n] * c for n, (sec, c) in per.items() if n.startswith(prefixes))

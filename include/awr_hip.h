@@ -123,6 +123,7 @@ typedef struct awr_unpack_job {
     float* grad;
     int d0, d1, T, ld;
     int64_t first;
+    int slots, slot_stride; /* slots > 1: the value is the sum of `slots` copies of the packed buffer, slot_stride floats apart */
 } awr_unpack_job;
 /* Split image of a packed weight buffer of n fp32 elements (n % 32 == 0) for the 6- / 9-product modes of awr_conv_gemm:
  * every 32-element K-slice becomes 192 bytes [h: 32 bf16 | m: 32 bf16 | l: 32 bf16] with x == h + m + l exactly
@@ -200,15 +201,41 @@ typedef struct awr_wgrad_args {
     const float* d_shift;   /* then relu(t*scale+shift) of the stored tensor, i.e. a BatchNorm+ReLU output that  */
     const float* g_scale;   /* was never materialised (zero padding of the gather stays zero)                    */
     const float* g_shift;
-    float* d_colsum;        /* optional [Cd]: += column sums of D over all pixels (for conv wgrad, D = dY, this IS the
-                               bias gradient -- it falls out of the slices the kernel stages anyway); zeroed by caller */
+    float* d_colsum;        /* optional [AWR_STAT_SLOTS][Cd]: slot copies whose SUM += column sums of D over all pixels (for conv
+                               wgrad, D = dY, this IS the bias gradient -- it falls out of the slices the kernel stages anyway);
+                               zeroed by the caller.  Slots: hundreds of workgroups add to the same Cd addresses */
     int d_relu, g_relu;
     int B, Hd, Wd, Cd, Hg, Wg, Cg, sg, T, ld;
     int tile_m, tile_n;     /* (cd, cg) tile in units of 64; 0,0 = heuristic */
     int target_blocks;      /* split-K: aim for this many workgroups; 0 = heuristic */
+    int algo;               /* 0 = automatic; 1 = one workgroup per (tap, channel tile, pixel chunk); 2 = one WAVE per tap: a
+                               workgroup owns a 64x64 channel tile for all taps and stages D / halo'd G patches once
+                               (3x3 stride 1/2 and 4x4 stride-2 filters on power-of-two maps) */
     int8_t dy[16], dx[16];
 } awr_wgrad_args;
 int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
+
+/* Fused ResNet18-deconv stem: conv 5x5 pad 2 (1 -> 64 channels, no bias) -> BatchNorm -> ReLU -> MaxPool(3,2,1)
+ * (model/resnet_deconv.py:31-36, :118-121, their autograd and `pre.1`'s running-stat update).  The full-resolution
+ * conv output is NEVER written: every kernel recomputes it from the image on the FP32 matrix pipe.  img (B,1,H,W),
+ * H and W multiples of 16; w = `pre.0.weight` in checkpoint layout [64][25]; pooled / argmax NHWC (B,H/2,W/2,64).
+ *   awr_stem_stats       stats[AWR_STAT_SLOTS][2][64] += per-channel sum / sum of squares of the conv output
+ *                        (feed awr_bn_finalize with count = B*H*W)
+ *   awr_stem_pool        pooled = maxpool(relu(conv * scale + shift)); argmax (optional, training) = window code
+ *                        ky*3+kx of the first maximum, the format awr_maxpool_fwd writes
+ *   awr_stem_bwd_reduce  sums[AWR_STAT_SLOTS][2][64] += sum g, sum g*xhat with g = relu' * maxpool_backward(dpool);
+ *                        coef4 = [scale|shift|mean|invstd][64] of the forward (feed awr_bn_bwd_finalize)
+ *   awr_stem_bwd_wgrad   grad[64][25] = sum_pixels dY * image taps, dY = BatchNorm backward of g with
+ *                        bwd_coef = [mean g | mean g*xhat | gamma*invstd][64]; dw_slots: AWR_STAT_SLOTS*64*25 floats
+ *                        of scratch, zero before the first call (the call re-arms it) */
+int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, void* stream);
+int awr_stem_pool(const float* img, const float* w, const float* scale, const float* shift, int B, int H, int W,
+                  float* pooled, uint8_t* argmax, void* stream);
+int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool,
+                        const uint8_t* argmax, int B, int H, int W, double* sums, void* stream);
+int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef,
+                       const float* dpool, const uint8_t* argmax, int B, int H, int W, float* dw_slots,
+                       float* grad, void* stream);
 
 /* 5x5 stem (Cin=1): im2col of the depth image into (B,H,W,32) rows (25 taps + 7 zeros) so the
  * stem conv and its wgrad run on the same MFMA GEMMs (resnet_deconv.py:32, hourglass.py:112). */
@@ -243,6 +270,10 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
                      const float* mask_shift, double* sums, float* coef, int64_t npix, int C,
                      float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta,
                      int accumulate, void* stream);
+/* first half of awr_bn_bwd_apply on its own: collapse the slot-spread sums into coef = [mean g | mean g*xhat |
+ * gamma*invstd][C], emit dgamma / dbeta, zero the sums (for fused consumers such as awr_stem_bwd_wgrad) */
+int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, const float* invstd, float* coef,
+                        float* dgamma, float* dbeta, int accumulate, void* stream);
 /* plain ReLU backward / mask: g = dout * (act > 0) */
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream);
 /* out = a + b (n elements); out may alias a */

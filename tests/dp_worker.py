@@ -14,8 +14,10 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 def main():
     rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
-    torch.cuda.set_device(0)
-    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("AWR_TEST_BACKEND", "gloo")          # "nccl" (= RCCL) on a box with one GPU per rank
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group(backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
     import awr_amd
     import awr_oracle as O
     from awr_amd.trainer import TrainEngine
@@ -25,13 +27,14 @@ def main():
         net = awr_amd.get_deconv_net(18, 14, 2).cuda()
         eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, process_group=torch.distributed.group.WORLD, use_graph=False, autotune=False)
         assert eng.dp and eng.world == world and len(eng.sync.buckets) > 1
-        losses = []
+        losses, per_step = [], []
         for s in range(steps):
             img, jt = O.synth_batch(2, 128, 14, seed=70 + s + (0 if mode == "same" else 10 * rank))
             l, _ = eng.step(img.cuda(), jt.cuda())
             losses.append(float(l[2]))
+            per_step.append(net.flat_params()[:net.n_active].cpu())       # replicas must stay bitwise equal after EVERY step
         torch.cuda.synchronize()
-        res[mode] = {"params": net.flat_params()[:net.n_active].cpu(), "buffers": net._barena.cpu(), "losses": losses}
+        res[mode] = {"params": net.flat_params()[:net.n_active].cpu(), "buffers": net._barena.cpu(), "losses": losses, "per_step": per_step}
     torch.save(res, "%s.rank%d" % (out, rank))
     torch.distributed.destroy_process_group()
 

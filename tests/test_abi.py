@@ -57,8 +57,8 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(lib.Phase) == 76
     assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4 + 8   # 4 bytes of padding before the trailing pointer
     assert lib.ConvArgs.w_split.offset == 472
-    assert C.sizeof(lib.PackJob) == 3 * 8 + 6 * 4 + 8
-    assert C.sizeof(lib.WgradArgs) == 8 * 8 + 15 * 4 + 32 + 4
+    assert C.sizeof(lib.PackJob) == 3 * 8 + 6 * 4 + 8 and C.sizeof(lib.UnpackJob) == 2 * 8 + 4 * 4 + 8 + 2 * 4
+    assert C.sizeof(lib.WgradArgs) == 8 * 8 + 16 * 4 + 32 and lib.WgradArgs.dy.offset == 8 * 8 + 16 * 4
 
 
 def test_product_path_fails_loudly_on_cpu_tensors(lib):

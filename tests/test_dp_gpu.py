@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path):
+def _run(tmp_path, backend="gloo"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -20,7 +20,7 @@ def _run(tmp_path):
     out = os.path.join(str(tmp_path), "dp")
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AWR_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -57,4 +57,21 @@ def test_two_rank_data_parallel_engine(tmp_path):
     b0, b1 = r0["split"], r1["split"]
     assert b0["losses"] != b1["losses"]
     assert torch.equal(b0["params"], b1["params"])
+    for mode in ("same", "split"):                    # bitwise-equal replicas after every single step
+        for a, b in zip(r0[mode]["per_step"], r1[mode]["per_step"]):
+            assert torch.equal(a, b), mode
     assert not torch.equal(b0["buffers"], b1["buffers"])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the 8-GPU box lights this up)")
+def test_two_rank_data_parallel_engine_over_rccl(tmp_path):
+    """The same two-rank run over the real transport: backend "nccl" (= RCCL over xGMI), one GPU per rank.  Replicas must hold
+    bitwise-equal parameters after EVERY step (same all-reduced gradient, same fused optimiser kernel), whatever their shards."""
+    r0, r1 = _run(tmp_path, backend="nccl")
+    for mode in ("same", "split"):
+        assert len(r0[mode]["per_step"]) == len(r1[mode]["per_step"]) >= 1
+        for a, b in zip(r0[mode]["per_step"], r1[mode]["per_step"]):
+            assert torch.equal(a, b), mode
+    assert torch.equal(r0["same"]["buffers"], r1["same"]["buffers"])
+    assert r0["split"]["losses"] != r1["split"]["losses"] and not torch.equal(r0["split"]["buffers"], r1["split"]["buffers"])

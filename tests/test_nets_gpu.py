@@ -300,7 +300,7 @@ def test_config5_hourglass2_256_j21(amd, dev, golden_dir):
     for i, k in enumerate(g["bn_keys"]):              # running statistics after the COMPOUNDED momentum == two literal updates
         np.testing.assert_allclose(got_sd[str(k)].cpu().numpy(), g["bn_%d" % i], rtol=2e-4, atol=2e-5)
     counters = [v for k, v in got_sd.items() if k.endswith("num_batches_tracked")]
-    assert len(counters) > 100 and all(int(v) == int(g["num_batches_tracked"]) == 2 for v in counters)
+    assert len(counters) > 50 and all(int(v) == int(g["num_batches_tracked"]) == 2 for v in counters)
     p1 = np.array([float(got_sd[k].reshape(-1)[smp_index(got_sd[k].numel(), i)]) for i, k in enumerate(pkeys)], np.float32)
     d1 = np.abs(p1 - g["param_smp1"])
     assert np.quantile(d1, 0.9) <= 1e-4 and d1.max() <= 2.1e-3, (np.quantile(d1, 0.9), d1.max())

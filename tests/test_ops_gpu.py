@@ -371,3 +371,103 @@ def test_split_mode_accuracy_matches_fp32_mfma(ops, L, dev):
     for e1, e6 in zip(errs[1], errs[6]):
         assert e6 <= 2.0 * e1 + 1e-7, (errs[1], errs[6])
         assert e6 < 5e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 48), (3, 128, 128), (1, 16, 16)])
+def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
+    """csrc/awr_stem.hip: conv 5x5 (1 -> 64, pad 2, no bias) -> BatchNorm (batch statistics) -> ReLU -> MaxPool(3,2,1) without
+    ever writing the full-resolution map, and its backward (BN parameter gradients, conv weight gradient) by recomputation --
+    against float64 torch autograd of the four separate operators (resnet_deconv.py:31-36, :118-121)."""
+    from awr_amd import ops
+    g = torch.Generator().manual_seed(5 + H)
+    img = (torch.rand(B, 1, H, W, generator=g) * 2 - 1)
+    img[:, :, : H // 3] = 1.0                                    # constant background like the real crops
+    w = torch.randn(64, 1, 5, 5, generator=g) * 0.2
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    # ---- float64 reference ----
+    wd, gd, bd = w.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = TF.conv2d(img.double(), wd, None, 1, 2)
+    a = TF.relu(TF.batch_norm(y, None, None, gd, bd, True, 0.1, 1e-5))
+    p_ref = TF.max_pool2d(a, 3, 2, 1)
+    gout = rnd(*p_ref.shape, seed=3)
+    gw_ref, gg_ref, gb_ref = torch.autograd.grad(p_ref, (wd, gd, bd), gout.double())
+    mean_ref, var_ref = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    # ---- HIP ----
+    s = L.stream()
+    imgd, wdv = img.to(dev), w.to(dev).contiguous()
+    stats = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
+    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), B, H, W, L.ptr(stats), s)
+    n = B * H * W
+    st = stats.sum(0).cpu()
+    assert rel_err(st[0] / n, mean_ref) < 2e-6 and rel_err(st[1] / n - (st[0] / n) ** 2, var_ref) < 2e-5
+    coef4 = torch.zeros(4, 64, device=dev)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    gam, bet = gamma.to(dev), beta.to(dev)
+    L.call("awr_bn_finalize", L.ptr(stats), 64, n, L.ptr(gam), L.ptr(bet), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, L.ptr(coef4[0]), L.ptr(coef4[1]),
+           L.ptr(coef4[2]), L.ptr(coef4[3]), s)
+    assert float(stats.abs().max()) == 0.0                       # re-armed
+    pooled = torch.empty(B, H // 2, W // 2, 64, device=dev)
+    arg = torch.empty(B, H // 2, W // 2, 64, device=dev, dtype=torch.uint8)
+    L.call("awr_stem_pool", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4[0]), L.ptr(coef4[1]), B, H, W, L.ptr(pooled), L.ptr(arg), s)
+    assert rel_err(ops.nchw(pooled).cpu(), p_ref.detach()) < 5e-6
+    assert int(arg.max()) <= 8
+    # eval-mode use: same kernel, folded coefficients, no argmax
+    pooled2 = torch.empty_like(pooled)
+    L.call("awr_stem_pool", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4[0]), L.ptr(coef4[1]), B, H, W, L.ptr(pooled2), None, s)
+    assert torch.equal(pooled, pooled2)
+    # ---- backward ----
+    dpool = ops.nhwc(gout).to(dev)
+    sums = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
+    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(sums), s)
+    coef = torch.zeros(3, 64, device=dev)
+    dgam, dbet = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    L.call("awr_bn_bwd_finalize", L.ptr(sums), 64, n, L.ptr(gam), L.ptr(coef4[3]), L.ptr(coef), L.ptr(dgam), L.ptr(dbet), 0, s)
+    assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
+    slots = torch.zeros(16 * 64 * 25, device=dev)
+    gw = torch.empty(64, 1, 5, 5, device=dev)
+    for _ in range(2):                                           # second call: the slot accumulator was re-armed by the first
+        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(coef), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(slots), L.ptr(gw), s)
+        assert rel_err(gw.cpu(), gw_ref) < 5e-5
+    assert float(slots.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,B,H", [
+    ("conv", 64, 64, 3, 1, 2, 32), ("conv", 96, 160, 3, 1, 3, 16),        # ragged channel tiles, odd batch
+    ("conv", 64, 128, 3, 2, 2, 32), ("conv", 128, 256, 3, 2, 3, 16),      # strided: D map 16x16 / 8x8
+    ("deconv", 128, 64, 4, 2, 2, 8), ("deconv", 512, 256, 4, 2, 1, 8), ("deconv", 96, 96, 4, 2, 3, 16),
+    ("conv", 256, 256, 3, 1, 1, 8),                                        # 8x8 map: two patches per image
+])
+def test_wgrad_one_wave_per_tap(ops, L, dev, kind, cin, cout, k, stride, B, H):
+    """awr_conv_wgrad algo 2 (a workgroup owns a 64x64 channel tile for all taps, wave t contracts tap t from one staged D patch
+    + halo'd G patch) against float64 autograd and against algo 1, with the fused BatchNorm+ReLU loader and the bias-gradient
+    by-product, and with split-K chunk counts that do not divide the patch count."""
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, 1)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    x = rnd(B, cin, H, H, seed=2)
+    s_, t_ = rnd(cin, seed=5) + 0.3, rnd(cin, seed=6) * 0.5
+    a = TF.relu(x * s_.view(1, -1, 1, 1) + t_.view(1, -1, 1, 1))
+    wd = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
+    y_ref = _torch_fwd(kind, a.double(), wd, None, stride, 1)
+    gy = rnd(*y_ref.shape, seed=4)
+    (gw_ref,) = torch.autograd.grad(y_ref, [wd], gy.double())
+    xg, gyg = ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev)
+    aff = (s_.to(dev), t_.to(dev), True)
+    bg = torch.empty(cout, device=dev) if kind == "conv" else None
+    gw = ops.conv_wgrad(spec, xg, gyg, x_affine=aff, bias_grad=bg, algo=2)
+    assert rel_err(gw.cpu(), gw_ref) < 1e-5
+    if bg is not None:
+        assert rel_err(bg.cpu(), gy.double().sum((0, 2, 3))) < 1e-5
+    old = ops.conv_wgrad(spec, xg, gyg, x_affine=aff, algo=1)
+    assert rel_err(gw.cpu(), old.cpu()) < 2e-6
+    # split-K depths that leave a ragged last chunk / a single chunk
+    import ctypes as C
+    prob = spec.wgrad_problem(H, H)
+    D, G = (gyg, xg) if prob["D"] == "dy" else (xg, gyg)
+    for blocks in (1, 7, 100000):
+        R = torch.zeros(prob["Cd"], len(prob["taps"]), prob["Cg"], device=dev)
+        wa = ops.make_wgrad_args(prob, B, D, G, R, prob["Cg"], algo=2, **{"g_affine" if prob["D"] == "dy" else "d_affine": aff})
+        wa.target_blocks = blocks
+        L.call("awr_conv_wgrad", C.byref(wa), L.stream())
+        out = torch.empty(*wshape, device=dev)
+        L.call("awr_unpack_wgrad", L.ptr(R), prob["d0"], prob["d1"], spec.T, prob["Cg"], L.ptr(out), 0, L.stream())
+        assert rel_err(out.cpu(), gw_ref) < 1e-5, blocks

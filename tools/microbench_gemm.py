@@ -49,7 +49,7 @@ def run_fwd(spec, B, H, tile=None, stats=False):
     return t, 2 * macs / t / 1e12
 
 
-def run_wgrad(spec, B, H, tile=None):
+def run_wgrad(spec, B, H, tile=None, algo=0, blocks=0, affine=False):
     dev = torch.device("cuda:0")
     prob = spec.wgrad_problem(H, H)
     ho, wo = spec.out_hw(H, H)
@@ -57,9 +57,13 @@ def run_wgrad(spec, B, H, tile=None):
     dy = torch.randn(B, ho, wo, spec.cout_pad, device=dev)
     D, G = (dy, x) if prob["D"] == "dy" else (x, dy)
     R = torch.zeros(prob["Cd"], len(prob["taps"]), prob["Cg"], device=dev)
-    a = ops.make_wgrad_args(prob, B, D, G, R, prob["Cg"])
-    if tile:
-        L.call("awr_debug_force_tile", *tile)
+    aff = {}
+    if affine:      # the un-materialised BatchNorm+ReLU loader on the layer-input operand
+        aff = {"g_affine" if prob["D"] == "dy" else "d_affine": (torch.rand(spec.cin_pad, device=dev) + 0.5, torch.randn(spec.cin_pad, device=dev) * 0.1, True)}
+    a = ops.make_wgrad_args(prob, B, D, G, R, prob["Cg"], algo=algo, **aff)
+    a.target_blocks = blocks
+    if tile and isinstance(tile, tuple) and len(tile) == 2 and algo != 2:
+        a.tile_m, a.tile_n = tile
     s = L.stream()
     t = timeit(lambda: L.check(L.lib.awr_conv_wgrad(C.byref(a), s)))
     L.call("awr_debug_force_tile", 0, 0)
@@ -96,7 +100,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -121,6 +125,28 @@ def main():
                     continue
                 res.append("%s %.0fTF" % (tile, run_fwd(spec, B, H, tile)[1]))
             print("%-26s %s" % (name, "  ".join(res)))
+    elif args.mode == "wgrad":       # weight gradient: workgroup-per-tap (algo 1, its tile / split-K candidates) vs wave-per-tap (algo 2)
+        B = args.batch
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8),
+                  ("layer2.0 3x3s2 64->128 @64", ops.ConvSpec("conv", 64, 128, 3, 2, 1), 64), ("layer4.0 3x3s2 256->512 @16", ops.ConvSpec("conv", 256, 512, 3, 2, 1), 16),
+                  ("deconv 512->256 @8", ops.ConvSpec("deconv", 512, 256, 4, 2, 1), 8), ("deconv 256->256 @16", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 16),
+                  ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32),
+                  ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64), ("hg 3x3 128->128 @8", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 8)]
+        for name, spec, H in shapes:
+            old = []
+            for tile, blocks in (((1, 1), 2048), ((1, 1), 3072), ((1, 1), 4096), ((2, 1), 1536), ((2, 1), 2048), ((1, 2), 2048)):
+                if (tile[0] == 2 and spec.wgrad_problem(H, H)["Cd"] <= 64) or (tile[1] == 2 and spec.wgrad_problem(H, H)["Cg"] <= 64):
+                    continue
+                t, tf = run_wgrad(spec, B, H, tile, algo=1, blocks=blocks)
+                old.append((tf, "%s/%d" % (tile, blocks)))
+            new = []
+            for blocks in (256, 512, 768, 1024, 1536, 2048, 3072):
+                t, tf = run_wgrad(spec, B, H, None, algo=2, blocks=blocks)
+                new.append((tf, str(blocks)))
+            ta, tfa = run_wgrad(spec, B, H, None, algo=2, blocks=max(new)[1] and int(max(new)[1]), affine=True)
+            print("%-30s wg-per-tap best %5.1f TF (%s) | wave-per-tap %s | best %5.1f TF (+affine %5.1f)" % (
+                name, max(old)[0], max(old)[1], " ".join("%s:%.0f" % (b, tf) for tf, b in new), max(new)[0], tfa), flush=True)
     elif args.mode == "split":
         B = args.batch
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
