@@ -355,7 +355,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     const int cslices = a.Cin / BK;
     const int ksteps = ph.ntaps * cslices;
     float4 ra[RA], rb[NP ? RB3 : RB];
-    float4 rsc = make_float4(1, 1, 1, 1), rsh = make_float4(0, 0, 0, 0);     // fused input affine of the staged slice's channels
     unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
     int c0_staged = 0;
 
@@ -389,19 +388,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
 #pragma unroll
             for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
         }
-        if (a.in_scale) {      // requested together with the data: in registers by the time the slice is stored (no load -> wait in the store phase)
-            rsc = ld4(a.in_scale + c0 + kc);
-            rsh = ld4(a.in_shift + c0 + kc);
-        }
         okmask = tapmask;
         c0_staged = c0;
     };
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
     auto store_slice = [&]() {
         if (a.in_scale) {
+            // (requesting the coefficients together with the slice's data was measured: no gain, 8 more registers)
+            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], rsc, rsh, a.relu_in);
+                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
         } else if (a.relu_in) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {

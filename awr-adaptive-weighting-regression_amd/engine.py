@@ -454,11 +454,11 @@ class Plan:
         C_ = y.shape[3]
         sums = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
         coef = self.alloc(3, C_)
-        # Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a lazy BN+ReLU output read
-        # by a single conv), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g / sum g*xhat itself --
+        # Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a BN+ReLU output read
+        # by a single conv, materialised or not), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g / sum g*xhat itself --
         # the separate reduction pass over d(a) and y disappears and the apply pass needs no mask.
         writers = self._grad_writers.get(id(a), [])
-        fused = (a.lazy is not None and relu and res is None and len(writers) == 1 and writers[0] is not None)
+        fused = (relu and res is None and len(writers) == 1 and writers[0] is not None)
         if fused:
             ga = writers[0]
             ga.bnr_y, ga.bnr_coef, ga.stats = L.ptr(y.buf), L.ptr(coef4), L.ptr(sums)

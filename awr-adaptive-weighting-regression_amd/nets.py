@@ -18,6 +18,7 @@ from .engine import BNLayer, ConvLayer, HeadLayer, Plan
 from .ops import ConvSpec, round_up
 
 PARAM_KINDS = ("conv_w", "deconv_w", "conv_b", "bn_w", "bn_b")
+_LAZY_ALL = __import__("os").environ.get("AWR_LAZY_ALL") == "1"       # study hook: never materialise a BN+ReLU output that a single GEMM consumes
 
 
 # ---- checkpoint layout ------------------------------------------------------------------------------
@@ -391,10 +392,14 @@ class ResNet18Deconv(AwrBackbone):
                     P.end_fork(r)
                 else:
                     r = c
-                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=True)              # consumed by conv2 only
+                # bn1 + ReLU feeds conv2 only.  Un-materialised (applied by conv2's loaders) while that is cheaper than one write + read
+                # of the tensor: the loader arithmetic costs 8-15 % of a GEMM whose K grows with the channel count (measured per layer,
+                # profiles/r02_summary.md), the tensor pass does not -- beyond 128 channels the activation is written out
+                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=_LAZY_ALL or Lr[p + ".conv1"].spec.cout <= 128)
                 c = self._cbr(P, Lr, o, p + ".conv2", p + ".bn2", True, res=r)
         for i in range(self.ndeconv):
-            c = self._cbr(P, Lr, c, "deconv_layers.%d" % (3 * i), "deconv_layers.%d" % (3 * i + 1), True, lazy=True)   # next deconv / head GEMM
+            # feeds the next transposed conv (K = 4 x 256 per phase: materialised, as above) or the 1x1 head GEMM (K = 256: lazy)
+            c = self._cbr(P, Lr, c, "deconv_layers.%d" % (3 * i), "deconv_layers.%d" % (3 * i + 1), True, lazy=_LAZY_ALL or (i == self.ndeconv - 1))
         pred = P.conv(c, Lr["head"])
         P.head_out(pred, self.J)
 
