@@ -20,6 +20,20 @@ def get_gemm_products():
     return int(L.lib.awr_get_gemm_products())
 
 
+def set_deterministic(on=True):
+    """Process-wide deterministic mode (include/awr_hip.h: awr_set_deterministic): plans built afterwards give every producer
+    workgroup its own accumulator copy and every split-K chunk its own copy of the weight gradient, summed in a fixed order --
+    two runs on the same inputs are bitwise identical (losses, gradients, parameters).  Slower; the default ($AWR_DETERMINISTIC
+    unset) combines partial sums with atomics."""
+    from . import _lib as L
+    L.call("awr_set_deterministic", int(bool(on)))
+
+
+def get_deterministic():
+    from . import _lib as L
+    return bool(L.lib.awr_get_deterministic())
+
+
 def __getattr__(name):
     import importlib
     table = {

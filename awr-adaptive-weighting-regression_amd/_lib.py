@@ -48,7 +48,7 @@ class ConvArgs(C.Structure):
                 ("Hout", C.c_int), ("Wout", C.c_int), ("N", C.c_int),
                 ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
                 ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int), ("tile_m", C.c_int), ("tile_n", C.c_int),
-                ("ph", Phase * 4), ("w_split", C.c_void_p)]
+                ("ph", Phase * 4), ("w_split", C.c_void_p), ("stat_slots", C.c_int), ("stat_slot_base", C.c_int)]
 
 
 class PackJob(C.Structure):
@@ -74,7 +74,7 @@ class WgradArgs(C.Structure):
                 ("B", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("Cd", C.c_int),
                 ("Hg", C.c_int), ("Wg", C.c_int), ("Cg", C.c_int), ("sg", C.c_int), ("T", C.c_int), ("ld", C.c_int),
                 ("tile_m", C.c_int), ("tile_n", C.c_int), ("target_blocks", C.c_int), ("algo", C.c_int),
-                ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16)]
+                ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16), ("split_stride", C.c_int64), ("max_split", C.c_int)]
 
 
 _I, _F, _L, _P, _D = C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_double
@@ -102,17 +102,21 @@ _SIGS = {
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
     "awr_get_gemm_products": ([], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
-    "awr_stem_stats": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
+    "awr_stem_stats": ([_P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_stem_slots": ([_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "awr_set_deterministic": ([_I], C.c_int),
+    "awr_get_deterministic": ([], C.c_int),
+    "awr_conv_wgrad_splits": ([C.POINTER(WgradArgs), C.POINTER(C.c_int)], C.c_int),
     "awr_stem_pool": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
-    "awr_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P], C.c_int),
-    "awr_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
-    "awr_bn_bwd_finalize": ([_P, _I, _L, _P, _P, _P, _P, _P, _I, _P], C.c_int),
-    "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P], C.c_int),
+    "awr_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
+    "awr_bn_bwd_finalize": ([_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
+    "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P], C.c_int),
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),
-    "awr_channel_stats": ([_P, _L, _I, _P, _P], C.c_int),
+    "awr_channel_stats": ([_P, _L, _I, _P, _I, _P], C.c_int),
     "awr_bn_apply": ([_P, _P, _P, _P, _I, _P, _L, _I, _P], C.c_int),
-    "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P], C.c_int),
-    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P], C.c_int),
+    "awr_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P], C.c_int),
+    "awr_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
     "awr_relu_bwd": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_add": ([_P, _P, _P, _L, _P], C.c_int),
     "awr_bias_grad": ([_P, _L, _I, _P, _I, _P], C.c_int),

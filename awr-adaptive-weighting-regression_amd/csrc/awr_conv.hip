@@ -249,7 +249,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         }
         __syncthreads();
         if (wm == 0 && lane < 8) {
-            double* st = a.stats + (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * a.N;
+            // slot copies: AWR_STAT_SLOTS by default; with a.stat_slots >= the launch's workgroup count every workgroup owns its
+            // slot (one add onto zero is exact: the deterministic mode)
+            const unsigned nslots = a.stat_slots > 0 ? (unsigned)a.stat_slots : (unsigned)AWR_STAT_SLOTS;
+            double* st = a.stats + (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
     auto store_slice = [&]() {
         if (a.in_scale) {
-            // (requesting the coefficients together with the slice's data was measured: no gain, 8 more registers)
+            // (requesting the coefficients together with the slice's data, one slice ahead, was measured on the same box: the 8 extra
+            // registers cost a wave of occupancy, the step went from 14.1 to 14.6 ms)
             const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
             for (int i = 0; i < RA; ++i)
@@ -732,7 +736,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + t) * a.ld + cg, acc[i][j][r]);
+                if (cd < a.Cd && cg < a.Cg) {
+                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
+                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];     // deterministic mode: own copy per K-chunk
+                    else atomicAdd(o, acc[i][j][r]);
+                }
             }
     }
     if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
@@ -746,8 +754,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a,
                 const float4 v = red[g * FM + tid];
                 tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
             }
-            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
-            atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            if (a.split_stride) {
+                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + da_c, tsum);
+            } else {
+                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
+                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            }
         }
     }
 }
@@ -889,7 +901,11 @@ __global__ __launch_bounds__(64 * KS * 4) void conv_wgrad_taps_kernel(const awr_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cd = tcd * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + trow * KS + j) * a.ld + cg, acc[j][r]);
+                if (cd < a.Cd && cg < a.Cg) {
+                    float* o = a.R + ((int64_t)cd * a.T + trow * KS + j) * a.ld + cg;
+                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[j][r];
+                    else atomicAdd(o, acc[j][r]);
+                }
             }
     }
     if (do_colsum) {      // fold the staging threads that share a channel chunk through LDS, one atomic per channel
@@ -902,8 +918,12 @@ __global__ __launch_bounds__(64 * KS * 4) void conv_wgrad_taps_kernel(const awr_
                 const float4 v = red[g];
                 tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
             }
-            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * 64 + 4 * tid;
-            atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            if (a.split_stride) {
+                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * 64 + 4 * tid, tsum);
+            } else {
+                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * 64 + 4 * tid;
+                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            }
         }
     }
 }
@@ -1083,7 +1103,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const awr_wgrad_a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) atomicAdd(a.R + ((int64_t)cd * a.T + t) * a.ld + cg, acc[i][j][r]);
+                if (cd < a.Cd && cg < a.Cg) {
+                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
+                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];
+                    else atomicAdd(o, acc[i][j][r]);
+                }
             }
     }
     if (do_colsum && role[0] == 0) {      // the 8 pixel-group lanes of a channel group hold partial sums of the same 4 channels
@@ -1093,8 +1117,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const awr_wgrad_a
             csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
         }
         if (upg[0] == 0 && ucol[0] != OOB) {
-            float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + uch[0];
-            atomicAdd(o + 0, csum.x); atomicAdd(o + 1, csum.y); atomicAdd(o + 2, csum.z); atomicAdd(o + 3, csum.w);
+            if (a.split_stride) {
+                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + uch[0], csum);
+            } else {
+                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + uch[0];
+                atomicAdd(o + 0, csum.x); atomicAdd(o + 1, csum.y); atomicAdd(o + 2, csum.z); atomicAdd(o + 3, csum.w);
+            }
         }
     }
 }
@@ -1140,6 +1168,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         b.out = a->out + out_img * b.B * c;
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
+        if (a->stat_slots > 0) b.stat_slot_base = a->stat_slot_base + c * (a->stat_slots / nchunk);
         if (int e = conv_gemm_one(&b, stream)) return e;
     }
     return AWR_OK;
@@ -1192,24 +1221,6 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     return check_launch("conv_gemm_kernel");
 }
 
-static int conv_wgrad_one(const awr_wgrad_args* a, void* stream);
-
-int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
-    AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
-    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
-    int nchunk = 1;
-    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
-    if (nchunk == 1) return conv_wgrad_one(a, stream);
-    for (int c = 0; c < nchunk; ++c) {       // split-K over batch chunks: partial sums accumulate in R
-        awr_wgrad_args b = *a;
-        b.B = a->B / nchunk;
-        b.D = a->D + d_img * b.B * c;
-        b.G = a->G + g_img * b.B * c;
-        if (int e = conv_wgrad_one(&b, stream)) return e;
-    }
-    return AWR_OK;
-}
-
 // geometry served by the one-wave-per-tap kernel: 3x3 (stride 1 / 2) and 4x4 stride-2 filters whose taps are listed row-major
 // from the top-left one, power-of-two D maps that a PH x 8 patch tiles
 static int wgrad_taps_patch_rows(const awr_wgrad_args* a) {
@@ -1223,12 +1234,22 @@ static int wgrad_taps_patch_rows(const awr_wgrad_args* a) {
     return ph;
 }
 
-static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
+// launch geometry of one weight-gradient problem: algorithm, tile, split-K depth.  Shared by the launch and by
+// awr_conv_wgrad_splits (a deterministic-mode caller sizes its per-chunk copies of R with it)
+struct wgrad_launch {
+    int taps_ph;        // > 0: one-wave-per-tap kernel with this patch height
+    int TM, TN, tiles;
+    int64_t nsplit, chunk;
+    int pc_log, pr_log;
+};
+
+static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
     AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),
                 "conv_wgrad: scale/shift must come in pairs");
     AWR_REQUIRE(a->algo >= 0 && a->algo <= 2, "conv_wgrad: algo must be 0 (automatic), 1 (workgroup per tap) or 2 (wave per tap)");
+    AWR_REQUIRE(a->split_stride >= 0 && (a->split_stride == 0 || a->max_split >= 1), "conv_wgrad: split_stride > 0 (deterministic K-chunk copies) needs max_split >= 1");
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
@@ -1237,23 +1258,22 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     const int ph = g_products == 1 ? wgrad_taps_patch_rows(a) : 0;
     const int algo = a->algo ? a->algo : (env_algo ? env_algo : 1);
     AWR_REQUIRE(a->algo != 2 || ph, "conv_wgrad: algo 2 (wave per tap) does not serve this geometry / product mode");
+    w->taps_ph = 0;
     if (ph && algo == 2) {
         auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
-        const int pc_log = log2i(a->Wd / 8), pr_log = log2i(a->Hd / ph);
-        const int64_t npatch = (int64_t)a->B << (pc_log + pr_log);
-        const int tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64);
+        w->taps_ph = ph;
+        w->pc_log = log2i(a->Wd / 8);
+        w->pr_log = log2i(a->Hd / ph);
+        const int64_t npatch = (int64_t)a->B << (w->pc_log + w->pr_log);
+        w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64);
         const int want = a->target_blocks > 0 ? a->target_blocks : 256;
-        int64_t nsplit = (want + tiles - 1) / tiles;
+        int64_t nsplit = (want + w->tiles - 1) / w->tiles;
         if (nsplit > npatch / 4) nsplit = npatch / 4;            // at least 4 K-slices per workgroup
+        if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
         if (nsplit < 1) nsplit = 1;
-        const int64_t ppw = (npatch + nsplit - 1) / nsplit;
-        nsplit = (npatch + ppw - 1) / ppw;
-        const dim3 grid((unsigned)tiles, (unsigned)nsplit);
-        hipStream_t st = as_stream(stream);
-        if (a->T == 16) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 4, 2>), grid, dim3(1024), 0, st, *a, (int)ppw, pc_log, pr_log);
-        else if (a->sg == 2) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 3, 2>), grid, dim3(768), 0, st, *a, (int)ppw, pc_log, pr_log);
-        else hipLaunchKernelGGL((conv_wgrad_taps_kernel<1, 3, 4>), grid, dim3(768), 0, st, *a, (int)ppw, pc_log, pr_log);
-        return check_launch("conv_wgrad_taps_kernel");
+        w->chunk = (npatch + nsplit - 1) / nsplit;
+        w->nsplit = (npatch + w->chunk - 1) / w->chunk;
+        return AWR_OK;
     }
     // measured (tools/microbench_gemm.py, AWR_WGRAD_BLOCKS sweep): 64x64 tiles with ~3072 workgroups win on the small
     // feature maps; the 128x64 (cd x cg) tile with ~2048 workgroups wins once there are >= 128K pixels to contract.
@@ -1264,18 +1284,49 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
         TN = a->tile_n;
     }
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
-    const int tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
+    w->TM = TM;
+    w->TN = TN;
+    w->tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
     static const int target_blocks = []() { const char* e = getenv("AWR_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning hook
     const int want_blocks = a->target_blocks > 0 ? a->target_blocks : target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
-    int64_t nsplit = (want_blocks + tiles - 1) / tiles;
+    int64_t nsplit = (want_blocks + w->tiles - 1) / w->tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 256 pixels per workgroup
     if (nsplit > max_split) nsplit = max_split;
+    if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
     if (nsplit < 1) nsplit = 1;
     int64_t chunk = (M + nsplit - 1) / nsplit;
     chunk = (chunk + 63) / 64 * 64;
-    nsplit = (M + chunk - 1) / chunk;
-    const dim3 grid((unsigned)tiles, (unsigned)nsplit);
+    w->chunk = chunk;
+    w->nsplit = (M + chunk - 1) / chunk;
+    return AWR_OK;
+}
+
+int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit) {
+    AWR_REQUIRE(a && nsplit, "conv_wgrad_splits: null pointer");
+    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
+    int nchunk = 1;
+    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    awr_wgrad_args b = *a;
+    b.B = a->B / nchunk;
+    wgrad_launch w;
+    if (int e = wgrad_plan(&b, &w)) return e;
+    *nsplit = (int)w.nsplit * nchunk;          // batch chunks (tensors above 4 GB) take consecutive ranges of copies
+    return AWR_OK;
+}
+
+static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
+    wgrad_launch w;
+    if (int e = wgrad_plan(a, &w)) return e;
     hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)w.tiles, (unsigned)w.nsplit);
+    if (w.taps_ph) {
+        if (a->T == 16) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 4, 2>), grid, dim3(1024), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
+        else if (a->sg == 2) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 3, 2>), grid, dim3(768), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
+        else hipLaunchKernelGGL((conv_wgrad_taps_kernel<1, 3, 4>), grid, dim3(768), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
+        return check_launch("conv_wgrad_taps_kernel");
+    }
+    const int TM = w.TM, TN = w.TN;
+    const int64_t chunk = w.chunk;
     auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     int wshift = log2i(a->Wd), hshift = log2i(a->Hd);
     if (wshift < 0 || hshift < 0) wshift = hshift = -1;
@@ -1290,6 +1341,28 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     else AWR_LAUNCH_WGRAD(1, 1);
 #undef AWR_LAUNCH_WGRAD
     return check_launch("conv_wgrad_kernel");
+}
+
+int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
+    AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
+    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
+    int nchunk = 1;
+    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    if (nchunk == 1) return conv_wgrad_one(a, stream);
+    for (int c = 0; c < nchunk; ++c) {       // split-K over batch chunks: partial sums accumulate in R
+        awr_wgrad_args b = *a;
+        b.B = a->B / nchunk;
+        b.D = a->D + d_img * b.B * c;
+        b.G = a->G + g_img * b.B * c;
+        if (a->split_stride) {            // deterministic mode: every batch chunk writes its own range of K-chunk copies
+            wgrad_launch w;
+            if (int e = wgrad_plan(&b, &w)) return e;
+            b.R = a->R + (int64_t)c * w.nsplit * a->split_stride;
+            if (a->d_colsum) b.d_colsum = a->d_colsum + (int64_t)c * w.nsplit * a->Cd;
+        }
+        if (int e = conv_wgrad_one(&b, stream)) return e;
+    }
+    return AWR_OK;
 }
 
 }  // extern "C"

@@ -151,19 +151,23 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, const float* __restrict__ gamma,
+// One wave per channel: lane l sums slot copies l, l + 64, ... in ascending order, then a fixed butterfly -- the order never
+// depends on which workgroup finished first, so with one slot per producer workgroup the statistics are reproducible bit for bit.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(double* __restrict__ stats, int C, int nslots, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
                                    float* __restrict__ invstd_o) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {   // producers spread their atomics over the slots
+    for (int k = threadIdx.x; k < nslots; k += 64) {   // producers spread their atomics over the slots
         s1 += stats[(size_t)k * 2 * C + c];
         s2 += stats[(size_t)k * 2 * C + C + c];
         stats[(size_t)k * 2 * C + c] = 0.0;
         stats[(size_t)k * 2 * C + C + c] = 0.0;
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;  // biased variance normalises the batch
     if (var < 0.0) var = 0.0;
@@ -197,7 +201,7 @@ template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2:
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ msc, const float* __restrict__ msh, int64_t npix,
-                                                         int C, int rows_per_block, double* __restrict__ out64, float* __restrict__ out32) {
+                                                         int C, int rows_per_block, int nslots, double* __restrict__ out64, float* __restrict__ out32) {
     const int C4 = C >> 2;
     const int rpp = 256 / C4;  // row groups per pass
     const int cg = threadIdx.x % C4, rg = threadIdx.x / C4;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             if (MODE == 2) {
                 atomicAdd(out32 + c, (float)a[k]);
             } else {
-                double* o = out64 + (size_t)(blockIdx.x % AWR_STAT_SLOTS) * 2 * C;
+                double* o = out64 + (size_t)(blockIdx.x % nslots) * 2 * C;
                 atomicAdd(o + c, a[k]);
                 atomicAdd(o + C + c, b[k]);
             }
@@ -300,18 +304,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // collapse the slot-spread backward sums into per-channel coefficients, emit dgamma/dbeta, re-arm the accumulator
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, double inv_count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int nslots, double inv_count, const float* __restrict__ gamma,
                                        const float* __restrict__ invstd, float* __restrict__ coef, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {
+    for (int k = threadIdx.x; k < nslots; k += 64) {
         s1 += sums[(size_t)k * 2 * C + c];
         s2 += sums[(size_t)k * 2 * C + C + c];
         sums[(size_t)k * 2 * C + c] = 0.0;
         sums[(size_t)k * 2 * C + C + c] = 0.0;
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     coef[c] = (float)(s1 * inv_count);                        // mean of g
     coef[C + c] = (float)(s2 * inv_count);                    // mean of g * xhat
     coef[2 * C + c] = (gamma ? gamma[c] : 1.f) * invstd[c];   // gamma * invstd
@@ -524,23 +530,28 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// nslots: slot copies of the fp64 accumulator (0 = AWR_STAT_SLOTS).  The launch never has more than AWR_REDUCE_MAX_BLOCKS
+// workgroups: a caller that allocates that many copies gets one workgroup per copy (deterministic mode).
 static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd,
-                             const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, hipStream_t st) {
+                             const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, int nslots, hipStream_t st) {
     AWR_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "channel reduction: C=%d must be a multiple of 4 in [4,1024]", C);
-    AWR_REQUIRE(npix > 0, "channel reduction: empty tensor");
+    AWR_REQUIRE(npix > 0 && nslots >= 0, "channel reduction: empty tensor");
+    if (nslots == 0) nslots = AWR_STAT_SLOTS;
     const int rpp = 256 / (C / 4);
-    int64_t rows = (npix + 1023) / 1024;  // <= 1024 workgroups; their atomics are spread over AWR_STAT_SLOTS copies
+    int64_t rows = (npix + AWR_REDUCE_MAX_BLOCKS - 1) / AWR_REDUCE_MAX_BLOCKS;  // <= 1024 workgroups; their atomics are spread over the slot copies
     if (rows < 64) rows = 64;
     rows = (rows + rpp - 1) / rpp * rpp;
     const unsigned grid = (unsigned)((npix + rows - 1) / rows);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
     else if (mode == 1)
-        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
     return check_launch("col_reduce_kernel");
 }
+
+static int g_deterministic = []() { const char* e = getenv("AWR_DETERMINISTIC"); return e ? atoi(e) != 0 : 0; }();
 
 }  // namespace awr
 
@@ -588,10 +599,17 @@ int awr_stem_im2col(const float* img, int B, int H, int W, float* cols, void* st
     return check_launch("stem_im2col_kernel");
 }
 
+int awr_set_deterministic(int on) {
+    g_deterministic = on != 0;
+    return AWR_OK;
+}
+
+int awr_get_deterministic(void) { return g_deterministic; }
+
 int awr_bn_finalize(double* stats, int C, int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                    float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, void* stream) {
-    AWR_REQUIRE(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, C, (double)count, gamma, beta,
+                    float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int nslots, void* stream) {
+    AWR_REQUIRE(stats && scale && shift && C > 0 && count > 0 && nslots >= 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), stats, C, nslots ? nslots : AWR_STAT_SLOTS, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     return check_launch("bn_finalize_kernel");
 }
@@ -604,9 +622,9 @@ int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* 
     return check_launch("bn_fold_eval_kernel");
 }
 
-int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream) {
+int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, int nslots, void* stream) {
     AWR_REQUIRE(x && stats, "channel_stats: null pointer");
-    return col_reduce_launch(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, stats, nullptr, as_stream(stream));
+    return col_reduce_launch(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, stats, nullptr, nslots, as_stream(stream));
 }
 
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu, float* out, int64_t npix, int C,
@@ -618,18 +636,18 @@ int awr_bn_apply(const float* x, const float* scale, const float* shift, const f
 }
 
 int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* mask_scale,
-                      const float* mask_shift, int64_t npix, int C, double* sums, void* stream) {
+                      const float* mask_shift, int64_t npix, int C, double* sums, int nslots, void* stream) {
     AWR_REQUIRE(dout && y && mean && invstd && sums, "bn_bwd_reduce: null pointer");
     AWR_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(act && mask_scale), "bn_bwd_reduce: give act OR mask_scale+mask_shift");
-    return col_reduce_launch(1, dout, act, y, mean, invstd, mask_scale, mask_shift, npix, C, sums, nullptr, as_stream(stream));
+    return col_reduce_launch(1, dout, act, y, mean, invstd, mask_scale, mask_shift, npix, C, sums, nullptr, nslots, as_stream(stream));
 }
 
 int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* mask_scale, const float* mask_shift, double* sums, float* coef, int64_t npix, int C, float* dy,
-                     const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate, void* stream) {
-    AWR_REQUIRE(dout && y && mean && invstd && sums && coef && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), sums, C, 1.0 / (double)npix, gamma, invstd,
-                       coef, dgamma, dbeta, accumulate);
+                     const float* dy_add, float* g_out, float* dgamma, float* dbeta, int accumulate, int nslots, void* stream) {
+    AWR_REQUIRE(dout && y && mean && invstd && sums && coef && dy && npix > 0 && C % 4 == 0 && nslots >= 0, "bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), sums, C, nslots ? nslots : AWR_STAT_SLOTS, 1.0 / (double)npix, gamma,
+                       invstd, coef, dgamma, dbeta, accumulate);
     if (int e = check_launch("bn_bwd_finalize_kernel")) return e;
     const int64_t n4 = npix * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
@@ -638,10 +656,10 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
 }
 
 int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
-                        int accumulate, void* stream) {
-    AWR_REQUIRE(sums && invstd && coef && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), sums, C, 1.0 / (double)count, gamma, invstd,
-                       coef, dgamma, dbeta, accumulate);
+                        int accumulate, int nslots, void* stream) {
+    AWR_REQUIRE(sums && invstd && coef && C > 0 && count > 0 && nslots >= 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), sums, C, nslots ? nslots : AWR_STAT_SLOTS, 1.0 / (double)count, gamma,
+                       invstd, coef, dgamma, dbeta, accumulate);
     return check_launch("bn_bwd_finalize_kernel");
 }
 
@@ -663,7 +681,7 @@ int awr_bias_grad(const float* dy, int64_t npix, int C, float* db, int accumulat
         set_error("bias_grad: hipMemsetAsync failed");
         return AWR_ERR_HIP;
     }
-    return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, as_stream(stream));
+    return col_reduce_launch(2, dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, nullptr, db, 0, as_stream(stream));
 }
 
 int awr_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, int in_relu, int B, int H, int W, int C, int k, int s, int p,

@@ -227,19 +227,29 @@ __device__ __forceinline__ float huber_val(float z, float delta) {
 }
 __device__ __forceinline__ float huber_grad(float z, float delta) { return fminf(fmaxf(z, -delta), delta); }
 
-__device__ __forceinline__ void block_accumulate(double local, double scale, double* acc) {
+// Loss accumulators.  Default: fp64 atomic adds of the block partials.  Deterministic mode (awr_set_deterministic): the SAME 8 bytes
+// hold a signed 2^-50 fixed-point number and the partials are added with INTEGER atomics -- associative, so the sum does not depend
+// on the order in which the workgroups finish.  Range +-8192 (losses are O(1) and below), resolution 9e-16 per partial: far below
+// the fp32 loss that is reported.  awr_loss_finalize converts back.
+constexpr double LOSS_FIX = 1125899906842624.0;      // 2^50
+
+__device__ __forceinline__ void block_accumulate(double local, double scale, double* acc, int fixed_point) {
     __shared__ double part[4];
     local = wave_sum(local);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, (part[0] + part[1] + part[2] + part[3]) * scale);
+    if (threadIdx.x == 0) {
+        const double v = (part[0] + part[1] + part[2] + part[3]) * scale;
+        if (fixed_point) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(v * LOSS_FIX));
+        else atomicAdd(acc, v);
+    }
 }
 
 // fused GT map + dense Huber forward/backward: reads pred + depth once, writes the gradient once.
 __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ pred, const float* __restrict__ jt_gt,
                                                          const float* __restrict__ img, int J, int F, int H, float ks, float delta,
                                                          float gscale, double lscale, double* __restrict__ acc,
-                                                         float* __restrict__ g_offset, int accumulate) {
+                                                         float* __restrict__ g_offset, int accumulate, int fixed_point) {
     const int bj = blockIdx.y, b = bj / J, j = bj - b * J;
     const int P = F * F;
     const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -272,12 +282,12 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
         }
         local = (double)lsum;
     }
-    block_accumulate(local, lscale, acc);
+    block_accumulate(local, lscale, acc, fixed_point);
 }
 
 __global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n, float delta,
                                                     float gscale, double lscale, double* __restrict__ acc, float* __restrict__ gx,
-                                                    int accumulate) {
+                                                    int accumulate, int fixed_point) {
     double local = 0.0;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -288,19 +298,20 @@ __global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x,
             gx[i] = accumulate ? gx[i] + g : g;
         }
     }
-    block_accumulate(local, lscale, acc);
+    block_accumulate(local, lscale, acc, fixed_point);
 }
 
 __global__ void zero_f64_kernel(double* p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
-__global__ void loss_finalize_kernel(const double* acc, int n, float* out) {
+__global__ void loss_finalize_kernel(const double* acc, int n, float* out, int fixed_point) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < n; ++i) {
-            out[i] = (float)acc[i];
-            t += acc[i];
+            const double v = fixed_point ? (double)reinterpret_cast<const long long*>(acc)[i] / LOSS_FIX : acc[i];
+            out[i] = (float)v;
+            t += v;
         }
         out[n] = (float)t;
     }
@@ -417,7 +428,7 @@ int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* im
     const int P = F * F;
     const double n = (double)B * 4.0 * J * P;
     hipLaunchKernelGGL(dense_loss_kernel, dim3((P / 4 + 255) / 256, B * J), dim3(256), 0, as_stream(stream), offset_pred, jt_gt, img,
-                       J, F, H, ks, delta, (float)((double)weight / n), (double)weight / n, acc, g_offset, accumulate);
+                       J, F, H, ks, delta, (float)((double)weight / n), (double)weight / n, acc, g_offset, accumulate, awr_get_deterministic());
     return check_launch("dense_loss_kernel");
 }
 
@@ -427,7 +438,7 @@ int awr_huber(const float* x, const float* y, int64_t n, float delta, float weig
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(huber_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, y, n, delta,
-                       (float)((double)weight / (double)n), (double)weight / (double)n, acc, gx, accumulate);
+                       (float)((double)weight / (double)n), (double)weight / (double)n, acc, gx, accumulate, awr_get_deterministic());
     return check_launch("huber_kernel");
 }
 
@@ -439,7 +450,7 @@ int awr_zero_f64(double* p, int64_t n, void* stream) {
 
 int awr_loss_finalize(const double* acc, int n, float* out, void* stream) {
     AWR_REQUIRE(acc && out && n > 0 && n <= 16, "loss_finalize: bad arguments");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), acc, n, out);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), acc, n, out, awr_get_deterministic());
     return check_launch("loss_finalize_kernel");
 }
 

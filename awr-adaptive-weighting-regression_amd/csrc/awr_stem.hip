@@ -70,7 +70,7 @@ __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __r
 // BatchNorm batch statistics of the (never stored) conv output
 // ------------------------------------------------------------------------------------------
 // grid (tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32 channels
-__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, int H, int W,
+__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, int H, int W, int nslots,
                                                          double* __restrict__ stats) {
     __shared__ float patch[ST_PH * ST_PW];
     __shared__ float red[4][2][32];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     if (tid < 64) {
         const int st = tid >> 5, c = tid & 31;
         const double v = (double)red[0][st][c] + (double)red[1][st][c] + (double)red[2][st][c] + (double)red[3][st][c];
-        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
         atomicAdd(stats + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
     }
 }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
 template <int WGRAD>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ coef4,
                                                        const float* __restrict__ bcoef, const float* __restrict__ dpool,
-                                                       const uint8_t* __restrict__ argmax, int H, int W, int tiles_per_wg,
+                                                       const uint8_t* __restrict__ argmax, int H, int W, int tiles_per_wg, int nslots,
                                                        double* __restrict__ sums, float* __restrict__ dw) {
     __shared__ float patch[ST_PH * ST_PW];
     __shared__ __attribute__((aligned(16))) float gt[256 * 32];       // pooled gradient routed to the tile's pixels [pixel][channel]
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = wacc[r];
         __syncthreads();
-        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+        const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
         for (int e = tid; e < 1024; e += 256) {
             const int r = e >> 6, l = e & 63, t = l & 31;
             if (t < ST_T) {
@@ -295,18 +295,18 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
             const int st = tid >> 5, c = tid & 31;
             const double v = (double)red[(0 * 2 + st) * 32 + c] + (double)red[(1 * 2 + st) * 32 + c] + (double)red[(2 * 2 + st) * 32 + c] +
                              (double)red[(3 * 2 + st) * 32 + c];
-            const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % AWR_STAT_SLOTS;
+            const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
             atomicAdd(sums + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
         }
     }
 }
 
 // grad[c][tap] = sum over the slot copies; re-arms the accumulator for the next step
-__global__ void stem_dw_finalize_kernel(float* __restrict__ dw_slots, float* __restrict__ grad) {
+__global__ void stem_dw_finalize_kernel(float* __restrict__ dw_slots, int nslots, float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 64 * ST_T) return;
     float s = 0.f;
-    for (int k = 0; k < AWR_STAT_SLOTS; ++k) {
+    for (int k = 0; k < nslots; ++k) {
         s += dw_slots[k * 64 * ST_T + i];
         dw_slots[k * 64 * ST_T + i] = 0.f;
     }
@@ -323,10 +323,24 @@ extern "C" {
     AWR_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, name ": H=%d, W=%d must be positive multiples of 16", H, W); \
     AWR_REQUIRE((int64_t)B * H * W < (1LL << 31), name ": batch too large")
 
-int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, void* stream) {
-    AWR_REQUIRE(img && w && stats, "stem_stats: null pointer");
+// nslots (0 = AWR_STAT_SLOTS): slot copies of the accumulator the kernel may spread over; awr_stem_slots() of them give every
+// workgroup its own copy (deterministic mode)
+int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots) {
+    AWR_REQUIRE(stats_slots && wgrad_slots, "stem_slots: null pointer");
+    AWR_STEM_GEOMETRY("stem_slots");
+    const int tiles = (H / 16) * (W / 16);
+    int tpw = 8;
+    while (tiles % tpw) tpw >>= 1;
+    *stats_slots = tiles * B;
+    *wgrad_slots = tiles / tpw * B;
+    return AWR_OK;
+}
+
+int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, int nslots, void* stream) {
+    AWR_REQUIRE(img && w && stats && nslots >= 0, "stem_stats: null pointer");
     AWR_STEM_GEOMETRY("stem_stats");
-    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, H, W, stats);
+    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, H, W, nslots ? nslots : AWR_STAT_SLOTS,
+                       stats);
     return check_launch("stem_stats_kernel");
 }
 
@@ -340,25 +354,26 @@ int awr_stem_pool(const float* img, const float* w, const float* scale, const fl
 }
 
 int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool, const uint8_t* argmax, int B, int H, int W,
-                        double* sums, void* stream) {
-    AWR_REQUIRE(img && w && coef4 && dpool && argmax && sums, "stem_bwd_reduce: null pointer");
+                        double* sums, int nslots, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && dpool && argmax && sums && nslots >= 0, "stem_bwd_reduce: null pointer");
     AWR_STEM_GEOMETRY("stem_bwd_reduce");
     hipLaunchKernelGGL(stem_bwd_kernel<0>, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, (const float*)nullptr,
-                       dpool, argmax, H, W, 1, sums, (float*)nullptr);
+                       dpool, argmax, H, W, 1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
     return check_launch("stem_bwd_kernel<0>");
 }
 
 int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef, const float* dpool, const uint8_t* argmax,
-                       int B, int H, int W, float* dw_slots, float* grad, void* stream) {
-    AWR_REQUIRE(img && w && coef4 && bwd_coef && dpool && argmax && dw_slots && grad, "stem_bwd_wgrad: null pointer");
+                       int B, int H, int W, float* dw_slots, float* grad, int nslots, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && bwd_coef && dpool && argmax && dw_slots && grad && nslots >= 0, "stem_bwd_wgrad: null pointer");
+    if (nslots == 0) nslots = AWR_STAT_SLOTS;
     AWR_STEM_GEOMETRY("stem_bwd_wgrad");
     const int tiles = (H / 16) * (W / 16);
     int tpw = 8;                                   // tiles per workgroup: fewer, longer workgroups = fewer atomics on the 64x25 result
     while (tiles % tpw) tpw >>= 1;
     hipLaunchKernelGGL(stem_bwd_kernel<1>, dim3(tiles / tpw, 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, bwd_coef, dpool, argmax, H, W, tpw,
-                       (double*)nullptr, dw_slots);
+                       nslots, (double*)nullptr, dw_slots);
     if (int e = check_launch("stem_bwd_kernel<1>")) return e;
-    hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3((64 * ST_T + 255) / 256), dim3(256), 0, as_stream(stream), dw_slots, grad);
+    hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3((64 * ST_T + 255) / 256), dim3(256), 0, as_stream(stream), dw_slots, nslots, grad);
     return check_launch("stem_dw_finalize_kernel");
 }
 

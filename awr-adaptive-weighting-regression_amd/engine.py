@@ -21,6 +21,7 @@ from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, alloc_pack
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 STAT_SLOTS = 16     # AWR_STAT_SLOTS in include/awr_hip.h
+REDUCE_MAX_BLOCKS = 1024      # AWR_REDUCE_MAX_BLOCKS
 # backward ops that neither read the weight-gradient scratch arena nor hand gradients out: the side streams need not be joined for them
 _NO_JOIN = ("awr_bn_bwd_reduce", "awr_bn_bwd_apply", "awr_bn_bwd_finalize", "awr_maxpool_bwd", "awr_upsample2_bwd", "awr_add", "__zero__")
 
@@ -102,14 +103,14 @@ class ConvLayer:
     def bias_ptr(self):
         return self.bias
 
-    def wgrad_unpack_jobs(self, R, ld, bsum, cd):
+    def wgrad_unpack_jobs(self, R, ld, bsum, rslots, bslots):
         """(packed pointer, gradient view, d0, d1, T, ld, slots, slot stride) scatter jobs: packed split-K result -> checkpoint
-        layout; the bias column sums come as STAT_SLOTS copies of `cd` floats."""
+        layout.  rslots / bslots = (copies, stride in floats) of the packed gradient / of the bias column sums."""
         prob_d0, prob_d1 = (self.spec.cout, self.spec.cin) if self.spec.kind == "conv" else (self.spec.cin, self.spec.cout)
-        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld, 1, 0)]
+        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld) + tuple(rslots)]
         if bsum is not None:
             n = self.gbias.numel()
-            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n, STAT_SLOTS, cd))
+            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n) + tuple(bslots))
         return jobs
 
     def bias_grad_target(self):
@@ -147,11 +148,11 @@ class HeadLayer(ConvLayer):
     def bias_ptr(self):
         return self.bias_cat
 
-    def wgrad_unpack_jobs(self, R, ld, bsum, cd):
+    def wgrad_unpack_jobs(self, R, ld, bsum, rslots, bslots):
         J, cin = self.J, self.cin
-        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld, 1, 0), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld, 1, 0)]
-        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels, STAT_SLOTS copies
-            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J, STAT_SLOTS, cd), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J, STAT_SLOTS, cd)]
+        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld) + tuple(rslots), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld) + tuple(rslots)]
+        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels
+            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J) + tuple(bslots), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J) + tuple(bslots)]
         return jobs
 
 
@@ -164,6 +165,9 @@ class BNLayer:
 class Plan:
     def __init__(self, B, device, training, need_input_grad=False, bn_repeat=1):
         self.B, self.dev, self.training = B, device, training
+        # deterministic mode (include/awr_hip.h): one accumulator copy per producer workgroup, K-chunk copies of every weight
+        # gradient summed in order, no autotuning (a timing-dependent tile choice would change summation orders between runs)
+        self.det = bool(L.lib.awr_get_deterministic())
         self.fwd_ops, self.bwd_ops, self.pack_ops = [], [], []
         self.nodes = []             # backward emitters, in forward order
         self.layers = []            # ConvLayers whose packed copies this plan refreshes
@@ -209,6 +213,23 @@ class Plan:
 
     def new(self, B, H, W, C_, needs_grad=True, name=""):
         return T(self.alloc(B, H, W, C_), needs_grad, name)
+
+    def _stat_buf(self, nslots, C_):
+        """Zeroed statistic accumulator [nslots][2][C] (fp64); `.nslots` travels with it to the finalize call."""
+        t = self.alloc(nslots, 2, C_, dtype=torch.float64, zero=True)
+        t.nslots = nslots
+        return t
+
+    def _gemm_slots(self, B, Hq, Wq, N, nphase):
+        """Slot copies for statistics accumulated by a GEMM epilogue: the default, or (deterministic) one per workgroup of the
+        finest tiling the launch can choose."""
+        if not self.det:
+            return STAT_SLOTS
+        return ((B * Hq * Wq + 63) // 64) * ((N + 63) // 64) * nphase
+
+    @property
+    def _reduce_slots(self):
+        return REDUCE_MAX_BLOCKS if self.det else STAT_SLOTS
 
     def _scratch(self, n):
         """Slice of the split-K scratch arena (sized on first use at build_backward; zeroed by ONE fill per step)."""
@@ -297,13 +318,17 @@ class Plan:
             self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(sc), L.ptr(sh), B, H, W, L.ptr(y.buf), None, None), "awr_stem_pool" + tag))
             self.macs["awr_stem_pool" + tag] = npix * 64 * 25
             return y
-        stats = self.alloc(STAT_SLOTS, 2, 64, dtype=torch.float64, zero=True)
+        ns_stats, ns_dw = C.c_int(STAT_SLOTS), C.c_int(STAT_SLOTS)
+        if self.det:
+            L.call("awr_stem_slots", B, H, W, C.byref(ns_stats), C.byref(ns_dw))
+        ns_stats, ns_dw = ns_stats.value, ns_dw.value
+        stats = self._stat_buf(ns_stats, 64)
         coef4 = self.alloc(4, 64)            # [scale | shift | mean | invstd]
         arg = self.alloc(B, H // 2, W // 2, 64, dtype=torch.uint8)
         mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
-        self.fwd_ops.append((L.lib.awr_stem_stats, (L.ptr(img_buf), w, B, H, W, L.ptr(stats), None), "awr_stem_stats" + tag))
+        self.fwd_ops.append((L.lib.awr_stem_stats, (L.ptr(img_buf), w, B, H, W, L.ptr(stats), ns_stats, None), "awr_stem_stats" + tag))
         self._f("awr_bn_finalize", L.ptr(stats), 64, npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom, BN_EPS,
-                L.ptr(coef4[0]), L.ptr(coef4[1]), L.ptr(coef4[2]), L.ptr(coef4[3]))
+                L.ptr(coef4[0]), L.ptr(coef4[1]), L.ptr(coef4[2]), L.ptr(coef4[3]), ns_stats)
         self.bns.append(bn)
         self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(coef4[0]), L.ptr(coef4[1]), B, H, W, L.ptr(y.buf), L.ptr(arg), None),
                              "awr_stem_pool" + tag))
@@ -313,16 +338,16 @@ class Plan:
 
         def bwd():
             assert y.grad is not None, "no gradient reached the stem"
-            sums = self.alloc(STAT_SLOTS, 2, 64, dtype=torch.float64, zero=True)
+            sums = self._stat_buf(ns_stats, 64)
             coef = self.alloc(3, 64)
-            slots = self.alloc(STAT_SLOTS * 64 * 25, zero=True)
-            self.bwd_ops.append((L.lib.awr_stem_bwd_reduce, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(y.grad), L.ptr(arg), B, H, W, L.ptr(sums), None),
+            slots = self.alloc(ns_dw * 64 * 25, zero=True)
+            self.bwd_ops.append((L.lib.awr_stem_bwd_reduce, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(y.grad), L.ptr(arg), B, H, W, L.ptr(sums), ns_stats, None),
                                  "awr_stem_bwd_reduce" + tag))
-            self._b("awr_bn_bwd_finalize", L.ptr(sums), 64, npix, L.ptr(bn.gamma), L.ptr(coef4[3]), L.ptr(coef), L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
+            self._b("awr_bn_bwd_finalize", L.ptr(sums), 64, npix, L.ptr(bn.gamma), L.ptr(coef4[3]), L.ptr(coef), L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0, ns_stats)
             self._note_grad(bn.ggamma)
             self._note_grad(bn.gbeta)
             self.bwd_ops.append((L.lib.awr_stem_bwd_wgrad, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(coef), L.ptr(y.grad), L.ptr(arg), B, H, W,
-                                                            L.ptr(slots), L.ptr(conv.gw), None), "awr_stem_bwd_wgrad" + tag))
+                                                            L.ptr(slots), L.ptr(conv.gw), ns_dw, None), "awr_stem_bwd_wgrad" + tag))
             self._note_grad(conv.gw)
         self.nodes.append(bwd)
         return y
@@ -337,7 +362,7 @@ class Plan:
         assert prob["full"], "forward transposed conv must cover all phases"
         y = self.new(B, prob["Hout"], prob["Wout"], prob["N"], name=layer.name + ".out")
         if want_stats:
-            y.stats = self.alloc(STAT_SLOTS, 2, prob["N"], dtype=torch.float64, zero=True)
+            y.stats = self._stat_buf(self._gemm_slots(B, prob["Hq"], prob["Wq"], prob["N"], len(prob["phases"])), prob["N"])
         bias = layer.bias_ptr() if use_bias else None
         assert res is None or res.lazy is None, "a fused residual must be a materialised tensor"
         self._join_if(res)
@@ -348,6 +373,8 @@ class Plan:
                            in_shift=in_affine[1] if in_affine else None, bias=bias,
                            out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
                            res=res.buf if res is not None else None, stats=y.stats, relu_in=relu_in, relu_out=relu_out, T=spec.T)
+        if y.stats is not None:
+            a.stat_slots = y.stats.nslots
         self.fwd_ops.append((L.lib.awr_conv_gemm, (C.byref(a), None), "awr_conv_gemm:" + layer.name))
         self._gemm_structs.append((L.lib.awr_conv_gemm, a, "awr_conv_gemm:" + layer.name))
         self.macs["awr_conv_gemm:" + layer.name] = self._gemm_macs(prob, B, spec)
@@ -373,14 +400,29 @@ class Plan:
         # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
         wp = spec.wgrad_problem(H, W)
         ld = wp["Cg"]
-        R = self._scratch(wp["Cd"] * len(wp["taps"]) * ld).view(wp["Cd"], len(wp["taps"]), ld)
+        rsize = wp["Cd"] * len(wp["taps"]) * ld
         D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
         xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
-        bsum = None
-        if fused_bias:           # STAT_SLOTS copies (the kernel spreads its atomics), summed by the scatter job
-            bsum = self._scratch(STAT_SLOTS * y.shape[3])
+        nsum, rstride, bstride = 1, 0, 0           # copies the scatter job sums (R / bias column sums) and their strides
+        if self.det:
+            # every K-chunk stores its own copy of the packed gradient (+ bias column sums); the batched scatter sums them in order
+            probe = make_wgrad_args(wp, B, D, G, dy, ld, **xa)
+            probe.split_stride = rsize
+            probe.max_split = max(1, min(256, -(-2048 // (((wp["Cd"] + 63) // 64) * ((wp["Cg"] + 63) // 64) * len(wp["taps"])))))
+            ns = C.c_int(0)
+            L.call("awr_conv_wgrad_splits", C.byref(probe), C.byref(ns))
+            nsum, rstride, bstride = ns.value, rsize, wp["Cd"]
+            R = self.alloc(nsum * rsize)
+            bsum = self.alloc(nsum * wp["Cd"]) if fused_bias else None
+        else:
+            R = self._scratch(rsize)
+            # STAT_SLOTS copies of the bias column sums (the kernel spreads its atomics), summed by the scatter job
+            bsum = self._scratch(STAT_SLOTS * y.shape[3]) if fused_bias else None
+        if bsum is not None:
             xa["d_colsum"] = bsum
         wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
+        if self.det:
+            wa.split_stride, wa.max_split = probe.split_stride, probe.max_split
         self._keep.append(wa)
         self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
         self._gemm_structs.append((L.lib.awr_conv_wgrad, wa, "awr_conv_wgrad:" + layer.name))
@@ -390,7 +432,8 @@ class Plan:
             self._side_ok.add("awr_conv_wgrad:" + layer.name)
         self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
         # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
-        for packed_ptr, grad, d0, d1, T_, ld_, slots, sstride in layer.wgrad_unpack_jobs(R, ld, bsum, y.shape[3]):
+        bias_slots = (nsum, bstride) if self.det else (STAT_SLOTS, y.shape[3])
+        for packed_ptr, grad, d0, d1, T_, ld_, slots, sstride in layer.wgrad_unpack_jobs(R, ld, bsum, (nsum, rstride), bias_slots):
             job = L.UnpackJob(packed_ptr, L.ptr(grad), d0, d1, T_, ld_, 0, slots, sstride)
             self._unpack_jobs.append(job)
             self._note_grad(grad, job)
@@ -425,8 +468,8 @@ class Plan:
         assert not (lazy and res is not None)
         B, H, W, C_ = y.shape
         if y.stats is None:
-            y.stats = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
-            self._f("awr_channel_stats", L.ptr(y.buf), y.npix, C_, L.ptr(y.stats))
+            y.stats = self._stat_buf(self._reduce_slots, C_)
+            self._f("awr_channel_stats", L.ptr(y.buf), y.npix, C_, L.ptr(y.stats), y.stats.nslots)
             own_stats = y.stats
         else:
             own_stats = y.stats
@@ -436,7 +479,7 @@ class Plan:
         sc, sh, mean, invstd = coef4[0], coef4[1], coef4[2], coef4[3]
         mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
         self._f("awr_bn_finalize", L.ptr(own_stats), C_, y.npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom,
-                BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd))
+                BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd), own_stats.nslots)
         self.bns.append(bn)
         if lazy:
             a = T(y.buf, True, bn.name + ".act(lazy)", lazy=(sc, sh, bool(relu)))
@@ -452,7 +495,6 @@ class Plan:
         da = a.grad
         assert da is not None, "no gradient reached %s" % a.name
         C_ = y.shape[3]
-        sums = self.alloc(STAT_SLOTS, 2, C_, dtype=torch.float64, zero=True)
         coef = self.alloc(3, C_)
         # Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a BN+ReLU output read
         # by a single conv, materialised or not), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g / sum g*xhat itself --
@@ -461,12 +503,15 @@ class Plan:
         fused = (relu and res is None and len(writers) == 1 and writers[0] is not None)
         if fused:
             ga = writers[0]
-            ga.bnr_y, ga.bnr_coef, ga.stats = L.ptr(y.buf), L.ptr(coef4), L.ptr(sums)
+            sums = self._stat_buf(self._gemm_slots(ga.B, ga.Hq, ga.Wq, ga.N, ga.nphase), C_)
+            ga.bnr_y, ga.bnr_coef, ga.stats, ga.stat_slots = L.ptr(y.buf), L.ptr(coef4), L.ptr(sums), sums.nslots
+        else:
+            sums = self._stat_buf(self._reduce_slots, C_)
         # ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
         act = L.ptr(a.buf) if (relu and res is not None) else None
         msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None and not fused) else (None, None)
         if not fused:
-            self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums))
+            self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums), sums.nslots)
         gy, acc = self._gtarget(y) if y.needs_grad else (self.alloc(*y.shape), False)
         g_out, post_add = None, None
         if res is not None and res.needs_grad:
@@ -480,7 +525,7 @@ class Plan:
             else:
                 pass  # handled below: identity of da
         self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), L.ptr(coef), y.npix, C_,
-                L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0)
+                L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0, sums.nslots)
         self._note_grad(bn.ggamma)
         self._note_grad(bn.gbeta)
         if post_add is not None:
@@ -595,6 +640,8 @@ class Plan:
         the choices are stored / reloaded so that a later process (e.g. a profiler run of the same command) skips the timing."""
         import json
         import os
+        if self.det:          # a timing-dependent tile / split-K choice would change summation orders from run to run
+            return
         s = L.stream()
         cache_file = os.environ.get("AWR_TUNE_CACHE")
         if cache_key:

@@ -17,9 +17,11 @@ class _Huber(torch.autograd.Function):
         need_grad = x.requires_grad
         gx = torch.empty_like(xx) if need_grad else None
         L.call("awr_huber", L.ptr(xx), L.ptr(yy), n, DELTA, 1.0, L.ptr(acc), L.ptr(gx), 0, L.stream())
+        out = torch.empty(2, device=xx.device, dtype=torch.float32)
+        L.call("awr_loss_finalize", L.ptr(acc), 1, L.ptr(out), L.stream())        # the only reader of `acc` (its encoding depends on the mode)
         ctx.save_for_backward(gx) if need_grad else None
         ctx.shape = x.shape
-        return acc[0].float()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):

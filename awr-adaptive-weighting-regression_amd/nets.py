@@ -19,6 +19,7 @@ from .ops import ConvSpec, round_up
 
 PARAM_KINDS = ("conv_w", "deconv_w", "conv_b", "bn_w", "bn_b")
 _LAZY_ALL = __import__("os").environ.get("AWR_LAZY_ALL") == "1"       # study hook: never materialise a BN+ReLU output that a single GEMM consumes
+_LAZY_MAXC = int(__import__("os").environ.get("AWR_LAZY_MAXC", "128"))  # study hook: widest conv1 output that stays un-materialised
 
 
 # ---- checkpoint layout ------------------------------------------------------------------------------
@@ -395,7 +396,7 @@ class ResNet18Deconv(AwrBackbone):
                 # bn1 + ReLU feeds conv2 only.  Un-materialised (applied by conv2's loaders) while that is cheaper than one write + read
                 # of the tensor: the loader arithmetic costs 8-15 % of a GEMM whose K grows with the channel count (measured per layer,
                 # profiles/r02_summary.md), the tensor pass does not -- beyond 128 channels the activation is written out
-                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=_LAZY_ALL or Lr[p + ".conv1"].spec.cout <= 128)
+                o = self._cbr(P, Lr, c, p + ".conv1", p + ".bn1", True, lazy=_LAZY_ALL or Lr[p + ".conv1"].spec.cout <= _LAZY_MAXC)
                 c = self._cbr(P, Lr, o, p + ".conv2", p + ".bn2", True, res=r)
         for i in range(self.ndeconv):
             # feeds the next transposed conv (K = 4 x 256 per phase: materialised, as above) or the 1x1 head GEMM (K = 256: lazy)
@@ -466,10 +467,13 @@ class HourglassNet(AwrBackbone):
             a = P.bn_act(P.conv(a, Lr[p + ".conv2"], want_stats=True), Lr[p + ".bn3"], True, lazy=True)
             r = P.conv(x, skip) if skip is not None else x
             return P.conv(a, Lr[p + ".conv3"], res=r, want_stats=True)
-        y = P.conv(x, Lr[p + ".conv1"], in_affine=P.fold_bn(Lr[p + ".bn1"]), relu_in=True)
-        y = P.conv(y, Lr[p + ".conv2"], in_affine=P.fold_bn(Lr[p + ".bn2"]), relu_in=True)
+        # inference: bn1 stays a loader affine (x also feeds the skip path un-normalised); bn2 / bn3 + ReLU normalise tensors that
+        # only conv2 / conv3 read, so they fold into the EPILOGUE of the conv that produces them -- applied once per element
+        # instead of once per (element, tap, column tile) in the 3x3 conv's loader, which cost 8-15 % of that GEMM
+        y = P.conv(x, Lr[p + ".conv1"], in_affine=P.fold_bn(Lr[p + ".bn1"]), relu_in=True, out_affine=P.fold_bn(Lr[p + ".bn2"]), relu_out=True)
+        y = P.conv(y, Lr[p + ".conv2"], out_affine=P.fold_bn(Lr[p + ".bn3"]), relu_out=True)
         r = P.conv(x, skip) if skip is not None else x
-        return P.conv(y, Lr[p + ".conv3"], in_affine=P.fold_bn(Lr[p + ".bn3"]), relu_in=True, res=r)
+        return P.conv(y, Lr[p + ".conv3"], res=r)
 
     def _hg(self, P, Lr, x, p, depth):
         # the skip branch of a level only meets the low-resolution path again at the up-sampling add: issued on its own side

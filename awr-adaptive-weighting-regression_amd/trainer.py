@@ -204,12 +204,13 @@ class TrainEngine:
             self.plan.img.copy_(img, non_blocking=True)
             self.jt_gt.copy_(jt_uvd_gt, non_blocking=True)
         self._compiled = True
-        if not (self.use_graph or (self._autotune and not self.plan.tuned)):
+        tune = self._autotune and not self.plan.tuned and not self.plan.det
+        if not (self.use_graph or tune):
             return
         hook, self.plan.bucket_hook = self.plan.bucket_hook, None          # no collectives during set-up
         keep = self.net._barena.clone()
         self._core()
-        if self._autotune and not self.plan.tuned:
+        if tune:
             self.plan.autotune(cache_key="train/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
         if self.use_graph:
             torch.cuda.synchronize()
@@ -297,9 +298,10 @@ class InferEngine:
         self.plan.img.copy_(img, non_blocking=True)
         if not self._compiled:           # one-off: eager warm-up run, GEMM tile autotune, hipGraph capture
             self._compiled = True
-            if self.use_graph or (self._autotune and not self.plan.tuned):
+            tune = self._autotune and not self.plan.tuned and not self.plan.det
+            if self.use_graph or tune:
                 self._core()
-                if self._autotune and not self.plan.tuned:
+                if tune:
                     self.plan.autotune(cache_key="infer/%s/J%d/B%d/H%d" % (type(self.net).__name__ + str(self.net.nstage), self.J, self.B, self.H))
                 if self.use_graph:
                     torch.cuda.synchronize()

@@ -199,6 +199,8 @@ def main():
                     help="1 = FP32 MFMA (default, the headline); 6 = split-operand mode (fp32 operands as 3 exact bf16 pieces, 6 bf16 MFMA products)")
     ap.add_argument("--no-split-mode", action="store_true", help="skip the extra split-operand measurement reported under 'split_mode'")
     ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
+    ap.add_argument("--deterministic", action="store_true", help="awr_amd.set_deterministic(True): bitwise-reproducible steps (no atomics on shared "
+                                                                  "accumulators, no autotuning); reports what that costs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +226,7 @@ def main():
 
     ks = 1.0 if args.net.startswith("resnet") else 0.4          # config.py:42
     awr_amd.set_gemm_products(args.gemm_products)
+    awr_amd.set_deterministic(args.deterministic)
     nprod = args.gemm_products
     dtype = "f32" if nprod == 1 else "f32 (operands as 3 exact bf16 pieces, 6 bf16 MFMA products per f32 product, f32 accumulate)"
     # MFMA roofline of the mode: FP32 MFMA peak, or the bf16 dense peak against 6 MFMA flops per algorithmic flop
@@ -341,7 +344,7 @@ def main():
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
                        "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams,
-                       "gemm_products": nprod, "device_cus": n_cu.value, "final_loss": loss},
+                       "gemm_products": nprod, "deterministic": bool(args.deterministic), "device_cus": n_cu.value, "final_loss": loss},
             "roofline": roofline,
         }
         if world == 1 and not args.no_parity:

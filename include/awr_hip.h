@@ -31,8 +31,23 @@ extern "C" {
 #define AWR_ERR_UNSUPPORTED (-3)
 
 /* BatchNorm statistic accumulators are [AWR_STAT_SLOTS][2][C] doubles: producers spread their atomics over
- * the slots (less L2 serialisation), awr_bn_finalize sums the slots and zeroes them. */
+ * the slots (less L2 serialisation), awr_bn_finalize sums the slots and zeroes them.  Every entry point that touches
+ * such an accumulator takes `nslots` (0 = AWR_STAT_SLOTS): the number of copies the caller allocated. */
 #define AWR_STAT_SLOTS 16
+/* upper bound of the workgroup count of awr_channel_stats / awr_bn_bwd_reduce launches */
+#define AWR_REDUCE_MAX_BLOCKS 1024
+
+/* Deterministic mode (process-wide flag, default 0 or $AWR_DETERMINISTIC): the library itself only stores it; callers
+ * that see it set give every producer workgroup its OWN accumulator copy, which makes all results independent of the
+ * order in which workgroups finish:
+ *   - statistic accumulators ([nslots][2][C] doubles): pass nslots >= the producer's workgroup count (a single add onto a
+ *     zeroed copy is exact); the finalize kernels sum the copies in a fixed order;
+ *   - weight gradients: awr_wgrad_args.split_stride > 0 makes K-chunk y STORE its partial tile at R + y*split_stride
+ *     (and its bias column sums at d_colsum + y*Cd) instead of atomically adding into R; awr_conv_wgrad_splits tells how
+ *     many copies a launch writes and awr_unpack_job.slots sums them in order.
+ * Cost: see DESIGN.md / profiles. */
+int awr_set_deterministic(int on);
+int awr_get_deterministic(void);
 
 int awr_version(void);
 const char* awr_last_error(void);
@@ -63,7 +78,9 @@ int awr_joint2offset(const float* jt_gt, const float* img, int B, int J, int F, 
 /* ------------------------------------------------------------------------------------------
  * Losses.  My_SmoothL1Loss (model/loss.py:8-25) == Huber(delta) averaged over all elements.
  * Partial sums are accumulated in a device double (`acc`); the caller zeroes it (awr_zero_f64)
- * and reads it through awr_loss_finalize.
+ * and reads it through awr_loss_finalize.  (In deterministic mode the 8 bytes hold a 2^-50 fixed-point
+ * integer and the partials are added with integer atomics: order-independent.  Only
+ * awr_loss_finalize may interpret `acc`.)
  * -----------------------------------------------------------------------------------------*/
 
 /* acc[0] += weight * mean(huber(x-y)); gx (optional) = weight * clamp(x-y,+-delta)/n
@@ -155,7 +172,7 @@ typedef struct awr_conv_args {
     const float* out_scale; /* optional per-output-channel affine after bias (folded eval BN)    */
     const float* out_shift;
     const float* res;       /* optional tensor added element-wise, same shape as out            */
-    double* stats;          /* optional [AWR_STAT_SLOTS][2][N]: += sum and sum of squares of the stored
+    double* stats;          /* optional [stat_slots][2][N]: += sum and sum of squares of the stored
                                value (taken after bias/affine/res, before relu_out)              */
     const float* bnr_y;     /* optional fused BatchNorm-backward reduction (data-gradient launches): the result v   */
     const float* bnr_coef;  /* is d(loss)/d(relu(bn(y)));  with coef = [scale|shift|mean|invstd][N] the kernel stores */
@@ -170,6 +187,9 @@ typedef struct awr_conv_args {
                                Static plans autotune this per launch (engine.Plan.autotune). */
     awr_phase ph[4];
     const void* w_split;    /* split image of w (awr_split_weight); required when awr_get_gemm_products() != 1 */
+    int stat_slots;         /* slot copies in `stats` (0 = AWR_STAT_SLOTS); workgroup i adds into copy (stat_slot_base + i) % stat_slots.
+                               ceil(M/64)*ceil(N/64)*nphase copies (the 64x64 tile's workgroup count) = one per workgroup */
+    int stat_slot_base;
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
@@ -212,8 +232,13 @@ typedef struct awr_wgrad_args {
                                workgroup owns a 64x64 channel tile for all taps and stages D / halo'd G patches once
                                (3x3 stride 1/2 and 4x4 stride-2 filters on power-of-two maps) */
     int8_t dy[16], dx[16];
+    int64_t split_stride;   /* 0: split-K partial sums are combined with atomics in R.  > 0 (deterministic mode): K-chunk y stores its
+                               tile at R + y*split_stride floats and its column sums at d_colsum + y*Cd; nothing needs zeroing */
+    int max_split;          /* with split_stride: number of copies the caller allocated (caps the split-K depth) */
 } awr_wgrad_args;
 int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
+/* number of K-chunk copies the launch described by `a` writes (split_stride mode) */
+int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit);
 
 /* Fused ResNet18-deconv stem: conv 5x5 pad 2 (1 -> 64 channels, no bias) -> BatchNorm -> ReLU -> MaxPool(3,2,1)
  * (model/resnet_deconv.py:31-36, :118-121, their autograd and `pre.1`'s running-stat update).  The full-resolution
@@ -228,14 +253,17 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
  *   awr_stem_bwd_wgrad   grad[64][25] = sum_pixels dY * image taps, dY = BatchNorm backward of g with
  *                        bwd_coef = [mean g | mean g*xhat | gamma*invstd][64]; dw_slots: AWR_STAT_SLOTS*64*25 floats
  *                        of scratch, zero before the first call (the call re-arms it) */
-int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, void* stream);
+int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, int nslots, void* stream);
 int awr_stem_pool(const float* img, const float* w, const float* scale, const float* shift, int B, int H, int W,
                   float* pooled, uint8_t* argmax, void* stream);
 int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool,
-                        const uint8_t* argmax, int B, int H, int W, double* sums, void* stream);
+                        const uint8_t* argmax, int B, int H, int W, double* sums, int nslots, void* stream);
 int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef,
                        const float* dpool, const uint8_t* argmax, int B, int H, int W, float* dw_slots,
-                       float* grad, void* stream);
+                       float* grad, int nslots, void* stream);
+/* workgroup counts of awr_stem_stats / awr_stem_bwd_reduce (stats_slots) and of awr_stem_bwd_wgrad (wgrad_slots, also the
+ * number of 64*25-float copies in dw_slots): that many slot copies = one per workgroup.  nslots = 0 means AWR_STAT_SLOTS. */
+int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots);
 
 /* 5x5 stem (Cin=1): im2col of the depth image into (B,H,W,32) rows (25 taps + 7 zeros) so the
  * stem conv and its wgrad run on the same MFMA GEMMs (resnet_deconv.py:32, hourglass.py:112). */
@@ -245,13 +273,13 @@ int awr_stem_im2col(const float* img, int B, int H, int W, float* cols, void* st
  * (momentum, unbiased running var); zeroes `stats` afterwards.  nn.BatchNorm2d forward, train. */
 int awr_bn_finalize(double* stats, int C, int64_t count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
-                    float* scale, float* shift, float* mean, float* invstd, void* stream);
+                    float* scale, float* shift, float* mean, float* invstd, int nslots, void* stream);
 /* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, float* scale, float* shift, void* stream);
 /* per-channel sum / sum of squares of an NHWC tensor (for BNs whose input is not a conv output);
  * stats is [AWR_STAT_SLOTS][2][C] like the conv epilogue's */
-int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, void* stream);
+int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, int nslots, void* stream);
 /* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,
                  float* out, int64_t npix, int C, void* stream);
@@ -261,7 +289,7 @@ int awr_bn_apply(const float* x, const float* scale, const float* shift, const f
  * activation is re-derived from y with the forward's scale/shift: no read of the activation tensor); else 1. */
 int awr_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* mean,
                       const float* invstd, const float* mask_scale, const float* mask_shift, int64_t npix,
-                      int C, double* sums, void* stream);
+                      int C, double* sums, int nslots, void* stream);
 /* backward pass 2: dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) [+ dy_add]; optional g_out = g
  * (residual branch); dgamma/dbeta (+)= sums (accumulate); zeroes sums afterwards.  dy may alias
  * dy_add or dout.  coef: 3*C floats of scratch (per-channel coefficients collapsed from the slots). */
@@ -269,11 +297,11 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
                      const float* invstd, const float* gamma, const float* mask_scale,
                      const float* mask_shift, double* sums, float* coef, int64_t npix, int C,
                      float* dy, const float* dy_add, float* g_out, float* dgamma, float* dbeta,
-                     int accumulate, void* stream);
+                     int accumulate, int nslots, void* stream);
 /* first half of awr_bn_bwd_apply on its own: collapse the slot-spread sums into coef = [mean g | mean g*xhat |
  * gamma*invstd][C], emit dgamma / dbeta, zero the sums (for fused consumers such as awr_stem_bwd_wgrad) */
 int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, const float* invstd, float* coef,
-                        float* dgamma, float* dbeta, int accumulate, void* stream);
+                        float* dgamma, float* dbeta, int accumulate, int nslots, void* stream);
 /* plain ReLU backward / mask: g = dout * (act > 0) */
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream);
 /* out = a + b (n elements); out may alias a */

@@ -644,3 +644,44 @@ def test_train_and_test_entry_points(dev, tmp_path):
     assert "loading model from" in r.stdout and "[test mpe" in r.stdout, r.stdout[-2000:]
     res = os.listdir(os.path.join(str(tmp_path), "nyu", "checkpoint_entry"))
     assert any(f.startswith("test_") and f.endswith(".txt") for f in res), res
+
+
+@pytest.mark.parametrize("net,B", [("resnet_18", 3), ("hourglass_1", 2)])
+def test_deterministic_mode_is_bitwise_reproducible(amd, dev, golden_dir, net, B):
+    """awr_amd.set_deterministic(): one accumulator copy per producer workgroup (BatchNorm statistics, BN-backward sums, stem),
+    one copy of every weight gradient per split-K chunk summed in order by the scatter, fixed-point integer loss sums.  Three
+    train steps issued (a) eagerly on one stream, (b) as a hipGraph with the weight gradients on two side streams must agree BIT FOR
+    BIT in losses, predictions, gradients, parameters and BN buffers -- and still meet the golden bars."""
+    from awr_amd.trainer import TrainEngine
+    J = 14
+    ks = 1.0 if net.startswith("resnet") else 0.4
+    img, jt_gt = O.synth_batch(B, 128, J, seed=83)
+    man = O.manifest_for(net, J)
+    amd.set_deterministic(True)
+    try:
+        assert amd.get_deterministic()
+        runs = []
+        for use_graph, streams in ((False, 0), (True, 2), (False, 2)):
+            m = make_net(amd, net, J, O.procedural_state(man, seed=8))
+            eng = TrainEngine(m, B, 128, ks, coord_weight=1.0, use_graph=use_graph, wgrad_streams=streams)
+            assert eng.plan.det and not eng.plan.tuned
+            ls, js = [], []
+            for it in range(3):
+                losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+                ls.append(losses.clone())
+                js.append(jt.clone())
+            torch.cuda.synchronize()
+            runs.append((torch.stack(ls), torch.stack(js), m.flat_grads()[:m.n_active].clone(), m.flat_params().clone(), m._barena.clone()))
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                assert torch.equal(a, b)
+        if net == "resnet_18":
+            test_fused_train_step_golden(amd, dev, golden_dir, net, "c1", 1.0)
+    finally:
+        amd.set_deterministic(False)
+    # and the default mode really is order-dependent somewhere (otherwise this test proves nothing): not asserted, only reported
+    m = make_net(amd, net, J, O.procedural_state(man, seed=8))
+    eng = TrainEngine(m, B, 128, ks, coord_weight=1.0, use_graph=False, wgrad_streams=0, autotune=False)
+    for it in range(3):
+        eng.step(img.to(dev), jt_gt.to(dev))
+    report("%s/deterministic/default_mode_param_max_abs_diff" % net, float((m.flat_params() - runs[0][3]).abs().max()))

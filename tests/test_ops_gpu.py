@@ -171,11 +171,11 @@ def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     npix = B * H * H
     xg = ops.nhwc(x).to(dev)
     stats = torch.zeros(16, 2, C, device=dev, dtype=torch.float64)
-    L.call("awr_channel_stats", L.ptr(xg), npix, C, L.ptr(stats), L.stream())
+    L.call("awr_channel_stats", L.ptr(xg), npix, C, L.ptr(stats), 0, L.stream())
     scale, shift, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
     rmg, rvg = rm.to(dev), rv.to(dev)
     L.call("awr_bn_finalize", L.ptr(stats), C, npix, DP(L, gamma, dev), DP(L, beta, dev), L.ptr(rmg), L.ptr(rvg), 0.1, 1e-5,
-           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.stream())
+           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), 0, L.stream())
     assert float(stats.abs().max()) == 0.0          # finalize re-arms the accumulator
     out = torch.empty_like(xg)
     resg = ops.nhwc(res).to(dev)
@@ -186,11 +186,11 @@ def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     sums = torch.zeros(16, 2, C, device=dev, dtype=torch.float64)
     coef = torch.empty(3, C, device=dev)
     goutg = ops.nhwc(gout).to(dev)
-    L.call("awr_bn_bwd_reduce", L.ptr(goutg), L.ptr(out), L.ptr(xg), L.ptr(mean), L.ptr(invstd), None, None, npix, C, L.ptr(sums), L.stream())
+    L.call("awr_bn_bwd_reduce", L.ptr(goutg), L.ptr(out), L.ptr(xg), L.ptr(mean), L.ptr(invstd), None, None, npix, C, L.ptr(sums), 0, L.stream())
     dy, g = torch.empty_like(xg), torch.empty_like(xg)
     dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
     L.call("awr_bn_bwd_apply", L.ptr(goutg), L.ptr(out), L.ptr(xg), L.ptr(mean), L.ptr(invstd), DP(L, gamma, dev), None, None, L.ptr(sums), L.ptr(coef), npix, C,
-           L.ptr(dy), None, L.ptr(g), L.ptr(dgam), L.ptr(dbet), 0, L.stream())
+           L.ptr(dy), None, L.ptr(g), L.ptr(dgam), L.ptr(dbet), 0, 0, L.stream())
     assert rel_err(ops.nchw(dy).cpu(), gx_ref) < 2e-5
     assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
     assert rel_err(ops.nchw(g).cpu(), gout.double() * (y_ref.detach() > 0)) < 1e-6
@@ -199,15 +199,15 @@ def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     out2 = torch.empty_like(xg)
     L.call("awr_bn_apply", L.ptr(xg), L.ptr(scale), L.ptr(shift), None, 1, L.ptr(out2), npix, C, L.stream())
     sa, sb = torch.zeros(16, 2, C, device=dev, dtype=torch.float64), torch.zeros(16, 2, C, device=dev, dtype=torch.float64)
-    L.call("awr_bn_bwd_reduce", L.ptr(goutg), L.ptr(out2), L.ptr(xg), L.ptr(mean), L.ptr(invstd), None, None, npix, C, L.ptr(sa), L.stream())
-    L.call("awr_bn_bwd_reduce", L.ptr(goutg), None, L.ptr(xg), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift), npix, C, L.ptr(sb), L.stream())
+    L.call("awr_bn_bwd_reduce", L.ptr(goutg), L.ptr(out2), L.ptr(xg), L.ptr(mean), L.ptr(invstd), None, None, npix, C, L.ptr(sa), 0, L.stream())
+    L.call("awr_bn_bwd_reduce", L.ptr(goutg), None, L.ptr(xg), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift), npix, C, L.ptr(sb), 0, L.stream())
     assert rel_err(sb.sum(0).cpu(), sa.sum(0).cpu()) < 1e-9
     dya, dyb = torch.empty_like(xg), torch.empty_like(xg)
     gam = DP(L, gamma, dev)
     L.call("awr_bn_bwd_apply", L.ptr(goutg), L.ptr(out2), L.ptr(xg), L.ptr(mean), L.ptr(invstd), gam, None, None, L.ptr(sa), L.ptr(coef), npix, C,
-           L.ptr(dya), None, None, L.ptr(dgam), L.ptr(dbet), 0, L.stream())
+           L.ptr(dya), None, None, L.ptr(dgam), L.ptr(dbet), 0, 0, L.stream())
     L.call("awr_bn_bwd_apply", L.ptr(goutg), None, L.ptr(xg), L.ptr(mean), L.ptr(invstd), gam, L.ptr(scale), L.ptr(shift), L.ptr(sb), L.ptr(coef), npix, C,
-           L.ptr(dyb), None, None, L.ptr(dgam), L.ptr(dbet), 0, L.stream())
+           L.ptr(dyb), None, None, L.ptr(dgam), L.ptr(dbet), 0, 0, L.stream())
     assert torch.equal(dya, dyb)
 
 
@@ -396,7 +396,7 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     s = L.stream()
     imgd, wdv = img.to(dev), w.to(dev).contiguous()
     stats = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
-    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), B, H, W, L.ptr(stats), s)
+    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), B, H, W, L.ptr(stats), 0, s)
     n = B * H * W
     st = stats.sum(0).cpu()
     assert rel_err(st[0] / n, mean_ref) < 2e-6 and rel_err(st[1] / n - (st[0] / n) ** 2, var_ref) < 2e-5
@@ -404,7 +404,7 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
     gam, bet = gamma.to(dev), beta.to(dev)
     L.call("awr_bn_finalize", L.ptr(stats), 64, n, L.ptr(gam), L.ptr(bet), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, L.ptr(coef4[0]), L.ptr(coef4[1]),
-           L.ptr(coef4[2]), L.ptr(coef4[3]), s)
+           L.ptr(coef4[2]), L.ptr(coef4[3]), 0, s)
     assert float(stats.abs().max()) == 0.0                       # re-armed
     pooled = torch.empty(B, H // 2, W // 2, 64, device=dev)
     arg = torch.empty(B, H // 2, W // 2, 64, device=dev, dtype=torch.uint8)
@@ -418,15 +418,15 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     # ---- backward ----
     dpool = ops.nhwc(gout).to(dev)
     sums = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
-    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(sums), s)
+    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(sums), 0, s)
     coef = torch.zeros(3, 64, device=dev)
     dgam, dbet = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
-    L.call("awr_bn_bwd_finalize", L.ptr(sums), 64, n, L.ptr(gam), L.ptr(coef4[3]), L.ptr(coef), L.ptr(dgam), L.ptr(dbet), 0, s)
+    L.call("awr_bn_bwd_finalize", L.ptr(sums), 64, n, L.ptr(gam), L.ptr(coef4[3]), L.ptr(coef), L.ptr(dgam), L.ptr(dbet), 0, 0, s)
     assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
     slots = torch.zeros(16 * 64 * 25, device=dev)
     gw = torch.empty(64, 1, 5, 5, device=dev)
     for _ in range(2):                                           # second call: the slot accumulator was re-armed by the first
-        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(coef), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(slots), L.ptr(gw), s)
+        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(coef), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(slots), L.ptr(gw), 0, s)
         assert rel_err(gw.cpu(), gw_ref) < 5e-5
     assert float(slots.abs().max()) == 0.0
 
