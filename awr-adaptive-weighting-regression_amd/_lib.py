@@ -78,6 +78,8 @@ class WgradArgs(C.Structure):
 
 
 _I, _F, _L, _P, _D = C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_double
+_PP = C.POINTER(C.c_void_p)
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)      # awr_bucket_cb
 _SIGS = {
     "awr_version": ([], C.c_int),
     "awr_last_error": ([], C.c_char_p),
@@ -126,6 +128,26 @@ _SIGS = {
     "awr_upsample2_bwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "awr_nhwc_to_nchw": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "awr_nchw_to_nhwc": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    # network-level API (csrc/awr_net.hip)
+    "awr_net_create": ([_I, _I, _I, _I, _PP], C.c_int),
+    "awr_net_destroy": ([_P], C.c_int),
+    "awr_net_sizes": ([_P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I), C.POINTER(_I)], C.c_int),
+    "awr_net_tensor_info": ([_P, _L, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)], C.c_int),
+    "awr_net_bind": ([_P, _P, _P, _P], C.c_int),
+    "awr_plan_create": ([_P, _I, _I, _I, C.c_uint, _I, _I, _P, _PP, _PP, _PP], C.c_int),
+    "awr_plan_destroy": ([_P], C.c_int),
+    "awr_plan_info": ([_P, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], C.c_int),
+    "awr_plan_bucket": ([_P, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)], C.c_int),
+    "awr_plan_op": ([_P, _I, _I, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(_I)], C.c_int),
+    "awr_plan_set_streams": ([_P, _I, _I], C.c_int),
+    "awr_plan_set_bucket_callback": ([_P, _P, _P], C.c_int),        # (plan, awr_bucket_cb or NULL, user)
+    "awr_plan_refresh_weights": ([_P, _P], C.c_int),
+    "awr_plan_forward": ([_P, _P], C.c_int),
+    "awr_plan_backward": ([_P, _P], C.c_int),
+    "awr_plan_run_timed": ([_P, _I, _P, C.POINTER(_F)], C.c_int),
+    "awr_plan_autotune": ([_P, _I, _P], C.c_int),
+    "awr_plan_gemm": ([_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), C.POINTER(_I)], C.c_int),
+    "awr_plan_set_gemm": ([_P, _I, _I, _I, _I, _F], C.c_int),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -22,6 +22,7 @@ SOURCES = {
     "awr_elem.hip": [],
     "awr_conv.hip": [],
     "awr_stem.hip": [],
+    "awr_net.hip": [],        # host-only: network-level plan builder / runner
 }
 
 

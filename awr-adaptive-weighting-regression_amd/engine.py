@@ -1,38 +1,30 @@
-"""Static execution plans for the AWR backbones on libawr_hip.so.
+"""Binding of the network-level engine of libawr_hip.so (csrc/awr_net.hip; include/awr_hip.h "Network-level API").
 
-A `Plan` is built once per (network, batch, image size, mode).  Building it walks the network
-description (resnet_deconv.py / hourglass.py), allocates every activation / gradient buffer in HBM
-up front and records two flat lists of pre-bound C-ABI calls: `fwd_ops` and `bwd_ops`.  Running a
-plan is just replaying a list of ctypes calls on the current HIP stream -- no allocation, no Python
-graph walking, no host synchronisation -- so a whole train step can be captured in one hipGraph.
-
-The backward list is derived at build time by walking the recorded nodes in reverse (a tiny static
-autograd): every node knows how to emit the kernels of its own gradient, and `Plan._gtarget`
-decides whether a contribution writes a fresh gradient buffer or accumulates into an existing one.
-Identity skip connections alias the upstream gradient buffer instead of copying it.
+The static execution plans of the AWR backbones -- buffer allocation, the forward launch list, the backward list derived by
+a static autograd, gradient buckets, weight repacking, side-stream scheduling, GEMM tile autotuning -- are built and replayed
+natively.  This module only wraps the handles: `NetHandle` (checkpoint layout + arenas bound to torch tensors) and `Plan`
+(one (batch, size, mode) instance whose boundary tensors -- depth batch, NCHW dense maps, their gradients -- are torch tensors
+so that the head / loss kernels and autograd can reach them).
 """
 import ctypes as C
+import json
+import os
 
 import torch
 
 from . import _lib as L
-from .ops import ConvSpec, make_conv_args, make_wgrad_args, round_up, alloc_packed
 
-BN_EPS = 1e-5
-BN_MOMENTUM = 0.1
-STAT_SLOTS = 16     # AWR_STAT_SLOTS in include/awr_hip.h
-REDUCE_MAX_BLOCKS = 1024      # AWR_REDUCE_MAX_BLOCKS
-# backward ops that neither read the weight-gradient scratch arena nor hand gradients out: the side streams need not be joined for them
-_NO_JOIN = ("awr_bn_bwd_reduce", "awr_bn_bwd_apply", "awr_bn_bwd_finalize", "awr_maxpool_bwd", "awr_upsample2_bwd", "awr_add", "__zero__")
+PARAM_KINDS = ("conv_w", "deconv_w", "conv_b", "bn_w", "bn_b")
+_KIND_NAMES = ("conv_w", "deconv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var", "counter")
 
 
 def plan_buckets(writes, n_active, n_buckets):
-    """Group gradient tensors into contiguous arena ranges that become final in backward order.
+    """Reference statement of the native bucket planner (csrc/awr_net.hip: plan_buckets), kept for the CPU unit test.
 
-    writes: list of (arena_lo, arena_hi, ready_op) -- the gradient occupying [lo,hi) floats is final once
-    backward op number `ready_op` has been enqueued.  Returns [(lo, hi, ready_op)] with the ranges tiling
-    [0, n_active) from the arena END downwards (the backward pass finishes the last layers first), ready_op
-    non-decreasing, so bucket k can be all-reduced while the backward of the earlier layers still runs."""
+    writes: list of (arena_lo, arena_hi, ready_op) -- the gradient occupying [lo,hi) floats is final once backward op number
+    `ready_op` has been enqueued.  Returns [(lo, hi, ready_op)] with the ranges tiling [0, n_active) from the arena END downwards
+    (the backward pass finishes the last layers first), ready_op non-decreasing, so bucket k can be all-reduced while the backward
+    of the earlier layers still runs."""
     if not writes:
         return []
     ws = sorted(writes, key=lambda w: -w[0])
@@ -52,652 +44,167 @@ def plan_buckets(writes, n_active, n_buckets):
     return [tuple(b) for b in out]
 
 
-class T:
-    """Plan-time tensor handle: an NHWC fp32 buffer plus (later) its gradient buffer."""
-    __slots__ = ("buf", "grad", "needs_grad", "stats", "name", "lazy")
+class NetHandle:
+    """awr_net: the checkpoint layout of one backbone.  `layout` = [(key, shape, kind, offset, unused)] in state_dict order."""
 
-    def __init__(self, buf, needs_grad=True, name="", lazy=None):
-        self.buf, self.grad, self.needs_grad, self.stats, self.name = buf, None, needs_grad, None, name
-        # lazy = (scale, shift, relu): the tensor this handle stands for is relu(buf*scale+shift) -- a BatchNorm(+ReLU)
-        # output that is never written to HBM; its consumers (conv / wgrad / maxpool loaders) apply the affine on the fly
-        self.lazy = lazy
+    def __init__(self, kind, nstack, J, downsample):
+        self.h = C.c_void_p()
+        L.call("awr_net_create", kind, nstack, J, downsample, C.byref(self.h))
+        nt, npar, nact, nbuf = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        ncnt, nst = C.c_int(), C.c_int()
+        L.call("awr_net_sizes", self.h, C.byref(nt), C.byref(npar), C.byref(nact), C.byref(nbuf), C.byref(ncnt), C.byref(nst))
+        self.n_params, self.n_active, self.n_buffers, self.n_counters, self.nstage = npar.value, nact.value, nbuf.value, ncnt.value, nst.value
+        self.layout = []
+        key, kind_, ndim, off, unused = C.c_char_p(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        for i in range(nt.value):
+            L.call("awr_net_tensor_info", self.h, i, C.byref(key), C.byref(kind_), C.byref(ndim), shape, C.byref(off), C.byref(unused))
+            self.layout.append((key.value.decode(), tuple(shape[:ndim.value]), _KIND_NAMES[kind_.value], off.value, bool(unused.value)))
 
-    @property
-    def shape(self):
-        return tuple(self.buf.shape)
+    def bind(self, params, grads, buffers):
+        L.call("awr_net_bind", self.h, L.ptr(params), L.ptr(grads), L.ptr(buffers))
 
-    @property
-    def npix(self):
-        s = self.buf.shape
-        return s[0] * s[1] * s[2]
-
-
-class ConvLayer:
-    """One nn.Conv2d / nn.ConvTranspose2d of the checkpoint: weight (+bias) views in the parameter
-    arena, gradient views in the gradient arena, packed GEMM copies of the weight."""
-
-    def __init__(self, spec, w, gw, bias=None, gbias=None, name=""):
-        self.spec, self.w, self.gw, self.bias, self.gbias, self.name = spec, w, gw, bias, gbias, name
-        self.p_fwd = self.p_dgrad = None
-
-    def alloc_packed(self, need_dgrad):
-        dev = self.w.device
-        if self.p_fwd is None:
-            _, _, T_, _, rows, ld = self.spec.fwd_pack()
-            self.p_fwd = alloc_packed(rows, T_, ld, dev)
-        if need_dgrad and self.p_dgrad is None:
-            _, _, T_, _, rows, ld = self.spec.dgrad_pack()
-            self.p_dgrad = alloc_packed(rows, T_, ld, dev)
-
-    def pack_calls(self):
-        """(fn, args) tuples that refresh the packed copies from the arena."""
-        calls = []
-        for recipe, dst in ((self.spec.fwd_pack(), self.p_fwd), (self.spec.dgrad_pack(), self.p_dgrad)):
-            if dst is not None:
-                d0, d1, T_, tr, rows, ld = recipe
-                calls.append(("awr_pack_weight", (L.ptr(self.w), d0, d1, T_, tr, rows, ld, L.ptr(dst)), L.ptr(dst.split)))
-        return calls
-
-    batchable = True       # plain layers go through the one-launch batched pack / unpack tables
-
-    def bias_ptr(self):
-        return self.bias
-
-    def wgrad_unpack_jobs(self, R, ld, bsum, rslots, bslots):
-        """(packed pointer, gradient view, d0, d1, T, ld, slots, slot stride) scatter jobs: packed split-K result -> checkpoint
-        layout.  rslots / bslots = (copies, stride in floats) of the packed gradient / of the bias column sums."""
-        prob_d0, prob_d1 = (self.spec.cout, self.spec.cin) if self.spec.kind == "conv" else (self.spec.cin, self.spec.cout)
-        jobs = [(L.ptr(R), self.gw, prob_d0, prob_d1, self.spec.T, ld) + tuple(rslots)]
-        if bsum is not None:
-            n = self.gbias.numel()
-            jobs.append((L.ptr(bsum), self.gbias, 1, n, 1, n) + tuple(bslots))
-        return jobs
-
-    def bias_grad_target(self):
-        return self.gbias
-
-
-class HeadLayer(ConvLayer):
-    """final1 (256->3J) and final2 (256->J) 1x1 convs fused into one 256->Cp GEMM (Cp = 4J rounded up
-    to 32; extra rows are zero).  resnet_deconv.py:52-53,:133-136 / hourglass.py:137-138,:153-157."""
-    batchable = False
-
-    def __init__(self, cin, J, w1, gw1, b1, gb1, w2, gw2, b2, gb2, name=""):
-        self.J, self.cin = J, cin
-        self.cp = round_up(4 * J, 32)
-        spec = ConvSpec("conv", cin, 4 * J, 1, 1, 0, cout_pad=self.cp)
-        super().__init__(spec, w1, gw1, None, None, name)
-        self.w1, self.gw1, self.b1, self.gb1, self.w2, self.gw2, self.b2, self.gb2 = w1, gw1, b1, gb1, w2, gw2, b2, gb2
-        self.bias_cat = torch.zeros(self.cp, device=w1.device, dtype=torch.float32)
-
-    def pack_calls(self):
-        J, cin = self.J, self.cin
-        calls = []
-        rows = self.p_fwd.shape[0]
-        calls.append(("awr_pack_weight", (L.ptr(self.w1), 3 * J, cin, 1, 0, 3 * J, cin, self.p_fwd.data_ptr())))
-        calls.append(("awr_pack_weight", (L.ptr(self.w2), J, cin, 1, 0, rows - 3 * J, cin, self.p_fwd.data_ptr() + 3 * J * cin * 4)))
-        if self.p_dgrad is not None:   # P[cin][1][cp]: columns [0,3J) from w1, [3J,4J) from w2 -> pack into a (cp, cin) staging then transpose
-            calls.append(("awr_pack_weight", (self.p_fwd.data_ptr(), self.cp, cin, 1, 1, self.p_dgrad.shape[0], self.cp, L.ptr(self.p_dgrad))))
-        for p in (self.p_fwd, self.p_dgrad):
-            if p is not None:
-                calls.append(("awr_split_weight", (L.ptr(p), L.ptr(p.split), p.numel())))
-        calls.append(("__copy__", (self.bias_cat[:3 * J], self.b1)))
-        calls.append(("__copy__", (self.bias_cat[3 * J:4 * J], self.b2)))
-        return calls
-
-    def bias_ptr(self):
-        return self.bias_cat
-
-    def wgrad_unpack_jobs(self, R, ld, bsum, rslots, bslots):
-        J, cin = self.J, self.cin
-        jobs = [(R.data_ptr(), self.gw1, 3 * J, cin, 1, ld) + tuple(rslots), (R.data_ptr() + 3 * J * ld * 4, self.gw2, J, cin, 1, ld) + tuple(rslots)]
-        if bsum is not None:           # column sums of dY over the fused (3J | J | padding) channels
-            jobs += [(bsum.data_ptr(), self.gb1, 1, 3 * J, 1, 3 * J) + tuple(bslots), (bsum.data_ptr() + 3 * J * 4, self.gb2, 1, J, 1, J) + tuple(bslots)]
-        return jobs
-
-
-class BNLayer:
-    def __init__(self, C_, gamma, beta, ggamma, gbeta, rmean, rvar, counter, name=""):
-        self.C, self.gamma, self.beta, self.ggamma, self.gbeta = C_, gamma, beta, ggamma, gbeta
-        self.rmean, self.rvar, self.counter, self.name = rmean, rvar, counter, name
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib.awr_net_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class Plan:
-    def __init__(self, B, device, training, need_input_grad=False, bn_repeat=1):
-        self.B, self.dev, self.training = B, device, training
-        # deterministic mode (include/awr_hip.h): one accumulator copy per producer workgroup, K-chunk copies of every weight
-        # gradient summed in order, no autotuning (a timing-dependent tile choice would change summation orders between runs)
-        self.det = bool(L.lib.awr_get_deterministic())
-        self.fwd_ops, self.bwd_ops, self.pack_ops = [], [], []
-        self.nodes = []             # backward emitters, in forward order
-        self.layers = []            # ConvLayers whose packed copies this plan refreshes
-        self.bns = []               # BNLayers updated by a training forward (for the counters)
-        self.bn_repeat = bn_repeat  # hourglass quirk: the reference runs `stacks` forwards per step (train.py:116-117)
-        self.outputs = []           # (nchw_out_buffer, nhwc_T, layer) per stage
-        self.grad_outs = []         # NCHW gradient input buffers per stage
-        self.bytes = 0
-        self._built_bwd = False
-        self._bufs = []
-        self._scratch_buf, self._scratch_used, self._scratch_cap = None, 0, 0
-        self._unpack_jobs, self._unpack_tab, self._pack_tab = [], None, None
-        self.garena = None          # flat gradient arena of the network (set by AwrBackbone.get_plan)
-        self.n_active = 0
-        self.n_buckets = 1          # > 1: gradients leave the backward pass in buckets (data-parallel overlap)
-        self.bucket_hook = None     # callable(lo, hi) fired when arena[lo:hi] holds final gradients
-        self._grad_writes = []      # (arena_lo, arena_hi, ready_op_index, unpack_job|None)
-        self._side_ok = set()       # weight-gradient launches that may run on the side stream(s)
-        self._gemm_structs = []     # (entry point, ctypes args, name) of every GEMM launch: what autotune() iterates over
-        self._zero_init = []        # buffers that must be all-zero before the first real step (atomic accumulators)
+    """awr_plan + its boundary tensors.  Building allocates every buffer; replaying allocates nothing and never synchronises."""
+
+    def __init__(self, net, B, H, F, J, training, supervised, bn_repeat=1, n_buckets=1):
+        dev = net.device
+        self.net, self.B, self.H, self.dev, self.training = net, B, H, dev, bool(training)
+        self.bn_repeat, self.n_buckets = bn_repeat, n_buckets
+        nstage = net.nstage
+        self.img = torch.zeros(B, 1, H, H, device=dev)
+        self.outputs = [torch.zeros(B, 4 * J, F, F, device=dev) for _ in range(nstage)]
+        self.grad_outs = [torch.zeros(B, 4 * J, F, F, device=dev) if training else None for _ in range(nstage)]
+        self.gen = 0
+        mask = 0
+        for s in (range(nstage) if supervised == "all" else supervised):
+            mask |= 1 << s
+        outs = (C.c_void_p * nstage)(*[o.data_ptr() for o in self.outputs])
+        gouts = (C.c_void_p * nstage)(*[g.data_ptr() for g in self.grad_outs]) if training else None
+        self.h = C.c_void_p()
+        L.call("awr_plan_create", net._handle.h, B, H, int(bool(training)), mask, bn_repeat, n_buckets, L.ptr(self.img), outs, gouts, C.byref(self.h))
+        nbytes, det, nf, nb, nbk, ng, nbn = C.c_int64(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.call("awr_plan_info", self.h, C.byref(nbytes), C.byref(det), C.byref(nf), C.byref(nb), C.byref(nbk), C.byref(ng), C.byref(nbn))
+        self.bytes = nbytes.value + sum(t.numel() * 4 for t in [self.img] + self.outputs + [g for g in self.grad_outs if g is not None])
+        self.det, self.n_ops, self.n_gemm, self.n_bn = bool(det.value), (nf.value, nb.value), ng.value, nbn.value
+        self.buckets = []
+        lo, hi, ready = C.c_int64(), C.c_int64(), C.c_int()
+        for i in range(nbk.value):
+            L.call("awr_plan_bucket", self.h, i, C.byref(lo), C.byref(hi), C.byref(ready))
+            self.buckets.append((lo.value, hi.value, ready.value))
+        self.macs, self._ops, self._side_ok = {}, ([], []), set()
+        name, macs, flags = C.c_char_p(), C.c_double(), C.c_int()
+        for lst in (0, 1):
+            for i in range(self.n_ops[lst]):
+                L.call("awr_plan_op", self.h, lst, i, C.byref(name), C.byref(macs), C.byref(flags))
+                nm = name.value.decode()
+                self._ops[lst].append((nm, bool(flags.value & 2)))
+                if flags.value & 2:
+                    self.macs[nm] = macs.value
+                if flags.value & 1:
+                    self._side_ok.add(nm)
         self.tuned = {}
-        self._grad_writers = {}     # id(T) -> [ConvArgs of the dgrad that wrote T.grad | None for any other writer]
-        self.macs = {}              # op name -> algorithmic MACs of that GEMM launch (bench.py roofline)
-        self._keep = []             # ctypes argument structs referenced by the op lists
-        self._head_states = []
+        self.n_side, self._hook, self._cb = 0, None, None
 
-    @staticmethod
-    def _gemm_macs(fwd_prob, B, spec):
-        """ALGORITHMIC multiply-accumulates of one conv-like layer (logical channels, zero padding counted as
-        work, the usual 2*MAC convention): forward, data-gradient and weight-gradient all cost the same."""
-        # conv: every output pixel sees all k*k taps; transposed conv: k*k/so^2 of them
-        taps_per_out = sum(len(t) for _, _, t in fwd_prob["phases"]) / float(fwd_prob["so"] ** 2)
-        return B * fwd_prob["Hout"] * fwd_prob["Wout"] * spec.cout * taps_per_out * spec.cin
+    # ---- introspection ---------------------------------------------------------------------------------------
+    def op_names(self, which):
+        return [n for n, _ in self._ops[0 if which in (0, "fwd", "forward") else 1]]
 
-    # ---- allocation -----------------------------------------------------------------------------------
-    def alloc(self, *shape, dtype=torch.float32, zero=False):
-        t = (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
-        self.bytes += t.numel() * t.element_size()
-        self._bufs.append(t)        # the op lists hold raw device pointers: the plan owns every buffer for its lifetime
-        if zero:
-            self._zero_init.append(t)
-        return t
-
-    def new(self, B, H, W, C_, needs_grad=True, name=""):
-        return T(self.alloc(B, H, W, C_), needs_grad, name)
-
-    def _stat_buf(self, nslots, C_):
-        """Zeroed statistic accumulator [nslots][2][C] (fp64); `.nslots` travels with it to the finalize call."""
-        t = self.alloc(nslots, 2, C_, dtype=torch.float64, zero=True)
-        t.nslots = nslots
-        return t
-
-    def _gemm_slots(self, B, Hq, Wq, N, nphase):
-        """Slot copies for statistics accumulated by a GEMM epilogue: the default, or (deterministic) one per workgroup of the
-        finest tiling the launch can choose."""
-        if not self.det:
-            return STAT_SLOTS
-        return ((B * Hq * Wq + 63) // 64) * ((N + 63) // 64) * nphase
+    # ---- streams / buckets -----------------------------------------------------------------------------------
+    def set_streams(self, n_side, comm=False):
+        """n_side library-owned HIP streams: weight-gradient GEMMs of the backward are issued round-robin on them and run beside
+        the data-gradient chain; forked forward branches (ResNet downsample projections, Hourglass skip residuals) use them too.
+        comm: one more stream that gradient buckets are handed to (data parallel)."""
+        L.call("awr_plan_set_streams", self.h, int(n_side), int(bool(comm)))
+        self.n_side = int(n_side)
 
     @property
-    def _reduce_slots(self):
-        return REDUCE_MAX_BLOCKS if self.det else STAT_SLOTS
+    def bucket_hook(self):
+        return self._hook
 
-    def _scratch(self, n):
-        """Slice of the split-K scratch arena (sized on first use at build_backward; zeroed by ONE fill per step)."""
-        n = round_up(n, 4)
-        off = self._scratch_used
-        self._scratch_used += n
-        if self._scratch_buf is None:
-            self._scratch_buf = self.alloc(self._scratch_cap)
-        assert self._scratch_used <= self._scratch_cap, "wgrad scratch arena too small"
-        return self._scratch_buf[off:off + n]
-
-    def _f(self, name, *args):
-        self.fwd_ops.append((getattr(L.lib, name), args + (None,), name))
-
-    def _b(self, name, *args):
-        self.bwd_ops.append((getattr(L.lib, name), args + (None,), name))
-
-    def _note_grad(self, tensor, job=None):
-        """The gradient view `tensor` (a slice of the flat gradient arena) is final after the op just appended
-        (or, with `job`, once that unpack job has run)."""
-        if self.garena is None or tensor is None:
+    @bucket_hook.setter
+    def bucket_hook(self, fn):
+        """fn(lo, hi): gradient arena [lo, hi) is final in the order of the CURRENT torch stream (the engine switches torch to the
+        stream the native runner names, so `torch.distributed.all_reduce(..., async_op=True)` orders itself correctly)."""
+        self._hook = fn
+        if fn is None:
+            self._cb = None
+            L.call("awr_plan_set_bucket_callback", self.h, None, None)
             return
-        lo = (tensor.data_ptr() - self.garena.data_ptr()) // 4
-        self._grad_writes.append((lo, lo + tensor.numel(), len(self.bwd_ops) - 1, job))
 
-    def _gtarget(self, t, writer=None):
-        """-> (gradient buffer, accumulate?)  and marks the gradient as live."""
-        if writer != "dgrad":
-            self._grad_writers.setdefault(id(t), []).append(None)
-        if t.grad is None:
-            t.grad = self.alloc(*t.shape)
-            return t.grad, False
-        return t.grad, True
+        def trampoline(user, lo, hi, stream):
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=self.dev)):
+                fn(lo, hi)
+        self._cb = L.BUCKET_CB(trampoline)          # keep the ctypes thunk alive as long as the plan may call it
+        L.call("awr_plan_set_bucket_callback", self.h, C.cast(self._cb, C.c_void_p), None)
 
-    def _contribute_identity(self, t, src_grad):
-        """grad(t) += src_grad where src_grad is a finished gradient buffer: alias when first."""
-        if not t.needs_grad:
-            return
-        self._grad_writers.setdefault(id(t), []).append(None)
-        if t.grad is None:
-            t.grad = src_grad
-        else:
-            self._b("awr_add", L.ptr(t.grad), L.ptr(src_grad), L.ptr(t.grad), t.grad.numel())
+    # ---- replay ----------------------------------------------------------------------------------------------
+    def refresh_weights(self):
+        L.call("awr_plan_refresh_weights", self.h, L.stream())
 
-    def use_layer(self, layer):
-        if layer not in self.layers:
-            layer.alloc_packed(need_dgrad=self.training)
-            self.layers.append(layer)
+    def run_forward(self):
+        L.call("awr_plan_forward", self.h, L.stream())
 
-    # ---- ops -------------------------------------------------------------------------------------------
-    def im2col5(self, img_buf, H, W):
-        """Stem im2col of the (B,1,H,W) depth image (== (B,H,W,1)); no gradient flows to the image."""
-        cols = self.new(self.B, H, W, 32, needs_grad=False, name="stem_cols")
-        self._f("awr_stem_im2col", L.ptr(img_buf), self.B, H, W, L.ptr(cols.buf))
-        return cols
+    def run_backward(self):
+        L.call("awr_plan_backward", self.h, L.stream())
 
-    # ---- forward branches that may run beside the main chain (ResNet downsample 1x1 + its BatchNorm) --------------------------
-    def fork(self, sid=0):
-        """Ops emitted until end_fork() only depend on tensors that are final now: `_run` issues them on side stream `sid`
-        (modulo the number of side streams the engine created; without side streams everything stays in order)."""
-        self._fork_sid = sid
-        self.fwd_ops.append((None, (sid,), "__fork__"))
-
-    def end_fork(self, result):
-        """`result` (a T) is what the branch produced; the first op that consumes it joins its side stream."""
-        self.fwd_ops.append((None, (self._fork_sid,), "__endfork__"))
-        if not hasattr(self, "_fork_results"):
-            self._fork_results = {}
-        self._fork_results[id(result)] = self._fork_sid
-
-    def _join_if(self, t):
-        sid = getattr(self, "_fork_results", {}).pop(id(t), None) if t is not None else None
-        if sid is not None:
-            self.fwd_ops.append((None, (sid,), "__join__"))
-
-    def stem_pool(self, img_buf, conv, bn, H, W):
-        """ResNet stem (resnet_deconv.py:31-36, :118-121): conv 5x5 (1 -> 64) -> BatchNorm -> ReLU -> MaxPool(3,2,1) as the fused
-        kernels of csrc/awr_stem.hip -- the full-resolution map is never written, forward or backward."""
-        B = self.B
-        assert conv.spec.cout == 64 and conv.bias is None, "the fused stem is the ResNet one: 64 channels, no conv bias"
-        y = self.new(B, H // 2, W // 2, 64, name=conv.name + ".pool")
-        w, tag = L.ptr(conv.w), ":" + conv.name
-        npix = B * H * W
-        if not self.training:
-            sc, sh = self.fold_bn(bn)
-            self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(sc), L.ptr(sh), B, H, W, L.ptr(y.buf), None, None), "awr_stem_pool" + tag))
-            self.macs["awr_stem_pool" + tag] = npix * 64 * 25
-            return y
-        ns_stats, ns_dw = C.c_int(STAT_SLOTS), C.c_int(STAT_SLOTS)
-        if self.det:
-            L.call("awr_stem_slots", B, H, W, C.byref(ns_stats), C.byref(ns_dw))
-        ns_stats, ns_dw = ns_stats.value, ns_dw.value
-        stats = self._stat_buf(ns_stats, 64)
-        coef4 = self.alloc(4, 64)            # [scale | shift | mean | invstd]
-        arg = self.alloc(B, H // 2, W // 2, 64, dtype=torch.uint8)
-        mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
-        self.fwd_ops.append((L.lib.awr_stem_stats, (L.ptr(img_buf), w, B, H, W, L.ptr(stats), ns_stats, None), "awr_stem_stats" + tag))
-        self._f("awr_bn_finalize", L.ptr(stats), 64, npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom, BN_EPS,
-                L.ptr(coef4[0]), L.ptr(coef4[1]), L.ptr(coef4[2]), L.ptr(coef4[3]), ns_stats)
-        self.bns.append(bn)
-        self.fwd_ops.append((L.lib.awr_stem_pool, (L.ptr(img_buf), w, L.ptr(coef4[0]), L.ptr(coef4[1]), B, H, W, L.ptr(y.buf), L.ptr(arg), None),
-                             "awr_stem_pool" + tag))
-        # algorithmic work: the conv once forward, its weight gradient once backward (the recomputations are not algorithmic)
-        self.macs["awr_stem_pool" + tag] = self.macs["awr_stem_bwd_wgrad" + tag] = npix * 64 * 25
-        self.macs["awr_stem_stats" + tag] = self.macs["awr_stem_bwd_reduce" + tag] = 0
-
-        def bwd():
-            assert y.grad is not None, "no gradient reached the stem"
-            sums = self._stat_buf(ns_stats, 64)
-            coef = self.alloc(3, 64)
-            slots = self.alloc(ns_dw * 64 * 25, zero=True)
-            self.bwd_ops.append((L.lib.awr_stem_bwd_reduce, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(y.grad), L.ptr(arg), B, H, W, L.ptr(sums), ns_stats, None),
-                                 "awr_stem_bwd_reduce" + tag))
-            self._b("awr_bn_bwd_finalize", L.ptr(sums), 64, npix, L.ptr(bn.gamma), L.ptr(coef4[3]), L.ptr(coef), L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0, ns_stats)
-            self._note_grad(bn.ggamma)
-            self._note_grad(bn.gbeta)
-            self.bwd_ops.append((L.lib.awr_stem_bwd_wgrad, (L.ptr(img_buf), w, L.ptr(coef4), L.ptr(coef), L.ptr(y.grad), L.ptr(arg), B, H, W,
-                                                            L.ptr(slots), L.ptr(conv.gw), ns_dw, None), "awr_stem_bwd_wgrad" + tag))
-            self._note_grad(conv.gw)
-        self.nodes.append(bwd)
-        return y
-
-    def conv(self, x, layer, in_affine=None, relu_in=False, out_affine=None, res=None, relu_out=False, want_stats=False,
-             use_bias=True):
-        """y = conv(x) [+bias] [*s+t] [+res] [relu].  in_affine/out_affine: (scale, shift) device vectors."""
-        self.use_layer(layer)
-        spec = layer.spec
-        B, H, W, _ = x.shape
-        prob = spec.fwd_problem(H, W)
-        assert prob["full"], "forward transposed conv must cover all phases"
-        y = self.new(B, prob["Hout"], prob["Wout"], prob["N"], name=layer.name + ".out")
-        if want_stats:
-            y.stats = self._stat_buf(self._gemm_slots(B, prob["Hq"], prob["Wq"], prob["N"], len(prob["phases"])), prob["N"])
-        bias = layer.bias_ptr() if use_bias else None
-        assert res is None or res.lazy is None, "a fused residual must be a materialised tensor"
-        self._join_if(res)
-        if x.lazy is not None:
-            assert in_affine is None
-            in_affine, relu_in = (x.lazy[0], x.lazy[1]), x.lazy[2]
-        a = make_conv_args(prob, B, x.buf, layer.p_fwd, y.buf, in_scale=in_affine[0] if in_affine else None,
-                           in_shift=in_affine[1] if in_affine else None, bias=bias,
-                           out_scale=out_affine[0] if out_affine else None, out_shift=out_affine[1] if out_affine else None,
-                           res=res.buf if res is not None else None, stats=y.stats, relu_in=relu_in, relu_out=relu_out, T=spec.T)
-        if y.stats is not None:
-            a.stat_slots = y.stats.nslots
-        self.fwd_ops.append((L.lib.awr_conv_gemm, (C.byref(a), None), "awr_conv_gemm:" + layer.name))
-        self._gemm_structs.append((L.lib.awr_conv_gemm, a, "awr_conv_gemm:" + layer.name))
-        self.macs["awr_conv_gemm:" + layer.name] = self._gemm_macs(prob, B, spec)
-        self._keep.append(a)
+    def forward(self):
+        self.run_forward()
         if self.training:
-            assert out_affine is None and not relu_out, "fused output affine/ReLU are inference-only"
-            assert x.lazy is not None or (in_affine is None and not relu_in), "training-mode input affine comes from a lazy tensor"
-            self.nodes.append(lambda: self._conv_bwd(x, y, layer, res, bias is not None))
-        return y
+            self.net._counters += self.bn_repeat
 
-    def _conv_bwd(self, x, y, layer, res, has_bias):
-        spec = layer.spec
-        B, H, W, _ = x.shape
-        dy = y.grad
-        assert dy is not None, "no gradient reached %s" % y.name
-        # the bias gradient (column sums of dY) falls out of the slices a conv's wgrad kernel stages anyway; only a biased
-        # TRANSPOSED conv (none in the reference nets) needs the stand-alone reduction
-        fused_bias = has_bias and spec.kind == "conv"
-        if has_bias and not fused_bias:
-            tgt = layer.bias_grad_target()
-            self._b("awr_bias_grad", L.ptr(dy), y.npix, y.shape[3], L.ptr(tgt), 0)
-            self._note_grad(tgt)
-        # weight gradient: split-K atomics into a zeroed packed buffer, then scatter to checkpoint layout
-        wp = spec.wgrad_problem(H, W)
-        ld = wp["Cg"]
-        rsize = wp["Cd"] * len(wp["taps"]) * ld
-        D, G = (dy, x.buf) if wp["D"] == "dy" else (x.buf, dy)
-        xa = {("g_affine" if wp["D"] == "dy" else "d_affine"): x.lazy} if x.lazy is not None else {}
-        nsum, rstride, bstride = 1, 0, 0           # copies the scatter job sums (R / bias column sums) and their strides
-        if self.det:
-            # every K-chunk stores its own copy of the packed gradient (+ bias column sums); the batched scatter sums them in order
-            probe = make_wgrad_args(wp, B, D, G, dy, ld, **xa)
-            probe.split_stride = rsize
-            probe.max_split = max(1, min(256, -(-2048 // (((wp["Cd"] + 63) // 64) * ((wp["Cg"] + 63) // 64) * len(wp["taps"])))))
-            ns = C.c_int(0)
-            L.call("awr_conv_wgrad_splits", C.byref(probe), C.byref(ns))
-            nsum, rstride, bstride = ns.value, rsize, wp["Cd"]
-            R = self.alloc(nsum * rsize)
-            bsum = self.alloc(nsum * wp["Cd"]) if fused_bias else None
-        else:
-            R = self._scratch(rsize)
-            # STAT_SLOTS copies of the bias column sums (the kernel spreads its atomics), summed by the scatter job
-            bsum = self._scratch(STAT_SLOTS * y.shape[3]) if fused_bias else None
-        if bsum is not None:
-            xa["d_colsum"] = bsum
-        wa = make_wgrad_args(wp, B, D, G, R, ld, **xa)
-        if self.det:
-            wa.split_stride, wa.max_split = probe.split_stride, probe.max_split
-        self._keep.append(wa)
-        self.bwd_ops.append((L.lib.awr_conv_wgrad, (C.byref(wa), None), "awr_conv_wgrad:" + layer.name))
-        self._gemm_structs.append((L.lib.awr_conv_wgrad, wa, "awr_conv_wgrad:" + layer.name))
-        if res is None:
-            # safe to run beside the main chain: dY is written once (by the BN backward) before this node and nobody touches it
-            # again.  With a fused residual, d(res) ALIASES dY and later nodes accumulate into it in place -> stays on the main stream.
-            self._side_ok.add("awr_conv_wgrad:" + layer.name)
-        self.macs["awr_conv_wgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
-        # scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
-        bias_slots = (nsum, bstride) if self.det else (STAT_SLOTS, y.shape[3])
-        for packed_ptr, grad, d0, d1, T_, ld_, slots, sstride in layer.wgrad_unpack_jobs(R, ld, bsum, (nsum, rstride), bias_slots):
-            job = L.UnpackJob(packed_ptr, L.ptr(grad), d0, d1, T_, ld_, 0, slots, sstride)
-            self._unpack_jobs.append(job)
-            self._note_grad(grad, job)
-        # data gradient
-        if x.needs_grad:
-            dp = spec.dgrad_problem(H, W)
-            gx, acc = self._gtarget(x, "dgrad")
-            if not dp["full"] and not acc:
-                self.bwd_ops.append((None, (gx,), "__zero__"))
-                acc = True
-            da = make_conv_args(dp, B, dy, layer.p_dgrad, gx, res=gx if acc else None, T=spec.T)
-            self._keep.append(da)
-            # remember who wrote d(x): a single full-coverage, non-accumulating dgrad can host the fused BN-backward reduction
-            self._grad_writers.setdefault(id(x), []).append(da if (dp["full"] and not acc) else None)
-            self.bwd_ops.append((L.lib.awr_conv_gemm, (C.byref(da), None), "awr_conv_dgrad:" + layer.name))
-            self._gemm_structs.append((L.lib.awr_conv_gemm, da, "awr_conv_dgrad:" + layer.name))
-            self.macs["awr_conv_dgrad:" + layer.name] = self._gemm_macs(spec.fwd_problem(H, W), B, spec)
-        if res is not None:
-            self._contribute_identity(res, dy)
+    def backward(self):
+        self.run_backward()
 
-    def fold_bn(self, bn):
-        """Inference: per-channel (scale, shift) of an eval-mode BatchNorm, refreshed with the weights."""
-        sc, sh = self.alloc(bn.C), self.alloc(bn.C)
-        self.pack_ops.append((L.lib.awr_bn_fold_eval, (bn.C, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), BN_EPS,
-                                                        L.ptr(sc), L.ptr(sh), None), "awr_bn_fold_eval"))
-        return sc, sh
+    def timed(self, which):
+        """Serial replay of one launch list with a HIP-event pair around every conv / stem launch -> {name: seconds}."""
+        lst = 0 if which in (0, "fwd", "forward") else 1
+        ms = (C.c_float * self.n_ops[lst])()
+        L.call("awr_plan_run_timed", self.h, lst, L.stream(), ms)
+        return {n: ms[i] * 1e-3 for i, (n, g) in enumerate(self._ops[lst]) if g}
 
-    def bn_act(self, y, bn, relu, res=None, lazy=False):
-        """Training-mode BatchNorm (+residual) (+ReLU): a = [relu](bn(y) [+ res]).  lazy=True (no residual): the
-        normalised tensor is NOT written; the returned handle carries (scale, shift, relu) for its consumers."""
-        assert self.training and y.lazy is None and (res is None or res.lazy is None)
-        assert not (lazy and res is not None)
-        B, H, W, C_ = y.shape
-        if y.stats is None:
-            y.stats = self._stat_buf(self._reduce_slots, C_)
-            self._f("awr_channel_stats", L.ptr(y.buf), y.npix, C_, L.ptr(y.stats), y.stats.nslots)
-            own_stats = y.stats
-        else:
-            own_stats = y.stats
-        # several BNs may normalise the same tensor (hourglass): finalize zeroes the accumulator, so keep a copy
-        y.stats = None
-        coef4 = self.alloc(4, C_)            # [scale | shift | mean | invstd][C]: one buffer so fused consumers take one pointer
-        sc, sh, mean, invstd = coef4[0], coef4[1], coef4[2], coef4[3]
-        mom = 1.0 - (1.0 - BN_MOMENTUM) ** self.bn_repeat
-        self._f("awr_bn_finalize", L.ptr(own_stats), C_, y.npix, L.ptr(bn.gamma), L.ptr(bn.beta), L.ptr(bn.rmean), L.ptr(bn.rvar), mom,
-                BN_EPS, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd), own_stats.nslots)
-        self.bns.append(bn)
-        if lazy:
-            a = T(y.buf, True, bn.name + ".act(lazy)", lazy=(sc, sh, bool(relu)))
-        else:
-            a = self.new(B, H, W, C_, name=bn.name + ".act")
-            self._join_if(res)
-            self._f("awr_bn_apply", L.ptr(y.buf), L.ptr(sc), L.ptr(sh), L.ptr(res.buf) if res is not None else None, int(relu), L.ptr(a.buf),
-                    y.npix, C_)
-        self.nodes.append(lambda: self._bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh, coef4))
-        return a
-
-    def _bn_bwd(self, y, a, bn, relu, res, mean, invstd, sc, sh, coef4):
-        da = a.grad
-        assert da is not None, "no gradient reached %s" % a.name
-        C_ = y.shape[3]
-        coef = self.alloc(3, C_)
-        # Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a BN+ReLU output read
-        # by a single conv, materialised or not), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g / sum g*xhat itself --
-        # the separate reduction pass over d(a) and y disappears and the apply pass needs no mask.
-        writers = self._grad_writers.get(id(a), [])
-        fused = (relu and res is None and len(writers) == 1 and writers[0] is not None)
-        if fused:
-            ga = writers[0]
-            sums = self._stat_buf(self._gemm_slots(ga.B, ga.Hq, ga.Wq, ga.N, ga.nphase), C_)
-            ga.bnr_y, ga.bnr_coef, ga.stats, ga.stat_slots = L.ptr(y.buf), L.ptr(coef4), L.ptr(sums), sums.nslots
-        else:
-            sums = self._stat_buf(self._reduce_slots, C_)
-        # ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
-        act = L.ptr(a.buf) if (relu and res is not None) else None
-        msc, msh = (L.ptr(sc), L.ptr(sh)) if (relu and res is None and not fused) else (None, None)
-        if not fused:
-            self._b("awr_bn_bwd_reduce", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), msc, msh, y.npix, C_, L.ptr(sums), sums.nslots)
-        gy, acc = self._gtarget(y) if y.needs_grad else (self.alloc(*y.shape), False)
-        g_out, post_add = None, None
-        if res is not None and res.needs_grad:
-            if relu:
-                if res.grad is None:
-                    res.grad = self.alloc(*res.shape)
-                    g_out = res.grad
-                else:
-                    g_out = self.alloc(*res.shape)
-                    post_add = g_out
-            else:
-                pass  # handled below: identity of da
-        self._b("awr_bn_bwd_apply", L.ptr(da), act, L.ptr(y.buf), L.ptr(mean), L.ptr(invstd), L.ptr(bn.gamma), msc, msh, L.ptr(sums), L.ptr(coef), y.npix, C_,
-                L.ptr(gy), L.ptr(gy) if acc else None, L.ptr(g_out) if g_out is not None else None, L.ptr(bn.ggamma), L.ptr(bn.gbeta), 0, sums.nslots)
-        self._note_grad(bn.ggamma)
-        self._note_grad(bn.gbeta)
-        if post_add is not None:
-            self._b("awr_add", L.ptr(res.grad), L.ptr(post_add), L.ptr(res.grad), post_add.numel())
-        if res is not None and res.needs_grad and not relu:
-            self._contribute_identity(res, da)
-
-    def maxpool(self, x, k, s, p):
-        B, H, W, C_ = x.shape
-        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        y = self.new(B, Ho, Wo, C_, name=x.name + ".pool")
-        arg = self.alloc(B, Ho, Wo, C_, dtype=torch.uint8) if self.training else None
-        lz = x.lazy
-        self._f("awr_maxpool_fwd", L.ptr(x.buf), L.ptr(lz[0]) if lz else None, L.ptr(lz[1]) if lz else None, int(lz[2]) if lz else 0,
-                B, H, W, C_, k, s, p, L.ptr(y.buf), L.ptr(arg))
-        if self.training:
-            def bwd():
-                if not x.needs_grad:
-                    return
-                gx, acc = self._gtarget(x)
-                self._b("awr_maxpool_bwd", L.ptr(y.grad), L.ptr(arg), B, H, W, C_, k, s, p, L.ptr(gx), int(acc))
-            self.nodes.append(bwd)
-        return y
-
-    def upsample_add(self, up1, low):
-        """out = up1 + nearest_upsample_x2(low)   (hourglass.py:77,:88)"""
-        B, Hl, Wl, C_ = low.shape
-        assert up1.lazy is None and low.lazy is None
-        self._join_if(up1)
-        y = self.new(B, 2 * Hl, 2 * Wl, C_, name=up1.name + ".upadd")
-        self._f("awr_upsample2_add", L.ptr(up1.buf), L.ptr(low.buf), B, Hl, Wl, C_, L.ptr(y.buf))
-        if self.training:
-            def bwd():
-                gl, acc = self._gtarget(low)
-                self._b("awr_upsample2_bwd", L.ptr(y.grad), B, Hl, Wl, C_, L.ptr(gl), int(acc))
-                self._contribute_identity(up1, y.grad)
-            self.nodes.append(bwd)
-        return y
-
-    def head_out(self, pred, J):
-        """NHWC (B,F,F,Cp) dense map -> the reference's NCHW (B,4J,F,F) tensor (+ gradient bridge)."""
-        B, F, _, Cp = pred.shape
-        out = self.alloc(B, 4 * J, F, F)
-        self._f("awr_nhwc_to_nchw", L.ptr(pred.buf), B, F * F, Cp, 4 * J, L.ptr(out))
-        gout = None
-        if self.training:
-            gout = self.alloc(B, 4 * J, F, F, zero=True)
-            state = {"used": False}
-
-            def bwd():
-                if not state["used"]:
-                    return            # no loss on this stage (hourglass: only the last stage is supervised, train.py:116-121)
-                g, acc = self._gtarget(pred)
-                if acc:
-                    tmp = self.alloc(*pred.shape)
-                    self._b("awr_nchw_to_nhwc", L.ptr(gout), B, F * F, Cp, 4 * J, L.ptr(tmp))
-                    self._b("awr_add", L.ptr(g), L.ptr(tmp), L.ptr(g), g.numel())
-                else:
-                    self._b("awr_nchw_to_nhwc", L.ptr(gout), B, F * F, Cp, 4 * J, L.ptr(g))
-            self.nodes.append(bwd)
-            self._head_states.append(state)
-        self.outputs.append(out)
-        self.grad_outs.append(gout)
-        return out
-
-    # ---- finishing ------------------------------------------------------------------------------------------
-    def build_backward(self, supervised_stages):
-        assert self.training and not self._built_bwd
-        for i, st in enumerate(self._head_states):
-            st["used"] = i in supervised_stages
-        # split-K scratch for every weight gradient, as one arena (capacity = all packed gradients of the used layers)
-        self._scratch_cap = sum(round_up(l.p_fwd.numel() if l.spec.kind == "conv" else l.p_dgrad.numel(), 4) + STAT_SLOTS * round_up(l.spec.cout_pad, 4)
-                                for l in self.layers) + 64
-        first = len(self.bwd_ops)
-        self.bwd_ops.append(None)        # placeholder for the scratch fill (kept in place so recorded op indices stay valid)
-        for emit in reversed(self.nodes):
-            emit()
-        if self._scratch_buf is not None:
-            self.bwd_ops[first] = (None, (self._scratch_buf[:self._scratch_used],), "__zero__")
-        else:
-            self.bwd_ops[first] = (None, (self.alloc(4),), "__zero__")
-        def unpack_op(jobs):
-            total = 0
-            for jb in jobs:           # one workgroup per gradient row
-                jb.first = total
-                total += jb.d0
-            tab = L.job_table(jobs, self.dev)
-            self._bufs.append(tab)
-            return (L.lib.awr_unpack_wgrads_batched, (tab.data_ptr(), len(jobs), total, None), "awr_unpack_wgrads_batched")
-        if self.n_buckets <= 1 or not self._grad_writes:
-            if self._unpack_jobs:      # ONE launch scatters every packed weight gradient back to checkpoint layout
-                self.bwd_ops.append(unpack_op(self._unpack_jobs))
-            self.buckets = [(0, self.n_active, len(self.bwd_ops) - 1)]
-        else:
-            # data-parallel overlap: each bucket's weight gradients are scattered into the arena as soon as the backward has
-            # passed its layers, then a marker lets the host start that bucket's all-reduce while the backward continues
-            self.buckets = plan_buckets([(lo, hi, r) for lo, hi, r, _ in self._grad_writes], self.n_active, self.n_buckets)
-            inserts = []
-            for lo, hi, ready in self.buckets:
-                jobs = [j for (wlo, whi, _, j) in self._grad_writes if j is not None and lo <= wlo < hi]
-                ops = ([unpack_op(jobs)] if jobs else []) + [(None, (lo, hi), "__bucket__")]
-                inserts.append((ready + 1, ops))
-            for pos, ops in sorted(inserts, key=lambda t: -t[0]):
-                self.bwd_ops[pos:pos] = ops
-        self._built_bwd = True
+    # ---- autotune --------------------------------------------------------------------------------------------
+    def _gemm(self, i):
+        name, tm, tn, tb, us, tuned = C.c_char_p(), C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_int()
+        L.call("awr_plan_gemm", self.h, i, C.byref(name), C.byref(tm), C.byref(tn), C.byref(tb), C.byref(us), C.byref(tuned))
+        return name.value.decode(), (tm.value, tn.value, tb.value), us.value, bool(tuned.value)
 
     def autotune(self, reps=3, cache_key=None):
-        """Pick the fastest workgroup tile (and split-K depth) for every GEMM launch of this static plan by timing the
-        candidates in place with HIP events.  Runs right after the first real step (buffers hold real data; the next step
-        rebuilds whatever the tuner scribbles on) and re-zeroes every atomic accumulator the launches touched.  Shapes never
-        change, so this is a one-off cost of a few hundred milliseconds per (network, batch) plan; with AWR_TUNE_CACHE=<file>
-        the choices are stored / reloaded so that a later process (e.g. a profiler run of the same command) skips the timing."""
-        import json
-        import os
-        if self.det:          # a timing-dependent tile / split-K choice would change summation orders from run to run
+        """Pick the fastest workgroup tile (and split-K depth) for every GEMM launch of this static plan by timing the candidates
+        in place (natively, HIP events).  Runs right after a first replay (buffers hold real data; the next step rebuilds whatever
+        the tuner scribbles on).  Shapes never change, so this is a one-off cost of a few hundred milliseconds per plan; with
+        AWR_TUNE_CACHE=<file> the choices are stored / reloaded so that a later process (e.g. a profiler run of the same command)
+        skips the timing.  No-op in deterministic mode."""
+        if self.det:
             return
-        s = L.stream()
         cache_file = os.environ.get("AWR_TUNE_CACHE")
         if cache_key:
             cache_key += "/x%d" % L.lib.awr_get_gemm_products()      # tile choices differ between the product modes
+        names = [self._gemm(i)[0] for i in range(self.n_gemm)]
         if cache_file and cache_key and os.path.exists(cache_file):
             try:
                 ent = json.load(open(cache_file)).get(cache_key)
             except (OSError, ValueError):
                 ent = None
-            if ent and all(name in ent for _, _, name in self._gemm_structs):
-                for fn, a, name in self._gemm_structs:
-                    (tm, tn, tb), t = ent[name]
-                    a.tile_m, a.tile_n = tm, tn
-                    if tb:
-                        a.target_blocks = tb
-                    self.tuned[name] = ((tm, tn, tb), t)
+            if ent and all(n in ent for n in names):
+                for i, n in enumerate(names):
+                    (tm, tn, tb), t = ent[n]
+                    L.call("awr_plan_set_gemm", self.h, i, tm, tn, tb, float(t))
+                    self.tuned[n] = ((tm, tn, tb), t)
                 return
-        self.refresh_weights()
-
-        def time_one(fn, a):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            L.check(fn(C.byref(a), s), "autotune warm-up")
-            e0.record()
-            for _ in range(reps):
-                L.check(fn(C.byref(a), s), "autotune")
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / reps
-        for fn, a, name in self._gemm_structs:
-            if fn is L.lib.awr_conv_gemm:
-                cands = [(1, 1, 0), (2, 1, 0)] + ([(1, 2, 0), (2, 2, 0)] if a.N > 64 else [])
-            else:
-                cands = [(1, 1, 2048), (1, 1, 3072), (1, 1, 4096)]
-                if a.Cd > 64:
-                    cands += [(2, 1, 1536), (2, 1, 2048)]
-                if a.Cg > 64:
-                    cands += [(1, 2, 2048)]
-                if a.Cd > 64 and a.Cg > 64 and L.lib.awr_get_gemm_products() != 1:
-                    cands += [(2, 2, 1024), (2, 2, 2048)]     # the split-mode kernel stages less per MFMA on the big tile
-            best, best_t = None, 1e30
-            for tm, tn, tb in cands:
-                a.tile_m, a.tile_n = tm, tn
-                if tb:
-                    a.target_blocks = tb
-                t = time_one(fn, a)
-                if t < best_t:
-                    best, best_t = (tm, tn, tb), t
-            a.tile_m, a.tile_n = best[0], best[1]
-            if best[2]:
-                a.target_blocks = best[2]
-            self.tuned[name] = (best, round(best_t * 1e3, 1))
-        for t in self._zero_init:
-            t.zero_()
-        if self._scratch_buf is not None:
-            self._scratch_buf.zero_()
-        torch.cuda.synchronize()
+        L.call("awr_plan_autotune", self.h, int(reps), L.stream())
+        for i in range(self.n_gemm):
+            n, tile, us, _ = self._gemm(i)
+            self.tuned[n] = (tile, round(us, 1))
         if cache_file and cache_key:
             try:
                 allc = json.load(open(cache_file)) if os.path.exists(cache_file) else {}
@@ -709,126 +216,10 @@ class Plan:
             except OSError:
                 pass
 
-    def refresh_weights(self):
-        """Re-pack every conv weight (and re-fold eval BNs) from the parameter arena: one batched launch for the
-        plain layers, a few extra calls for the fused heads."""
-        s = L.stream()
-        want_split = L.lib.awr_get_gemm_products() != 1      # split images are only written (132 MB per ResNet18 step) for the mode that reads them
-        if self._pack_tab is None:
-            self._pack_tab = {}
-        if want_split not in self._pack_tab:
-            jobs, total = [], 0
-            for layer in self.layers:
-                if layer.batchable:
-                    for name, args, split in layer.pack_calls():
-                        jobs.append(L.PackJob(args[0], args[7], split if want_split else None, args[1], args[2], args[3], args[4], args[5], args[6], total))
-                        total += args[5]                     # one workgroup per packed row
-            self._pack_tab[want_split] = (L.job_table(jobs, self.dev), len(jobs), total) if jobs else (None, 0, 0)
-        tab, njobs, total = self._pack_tab[want_split]
-        if njobs:
-            L.check(L.lib.awr_pack_weights_batched(tab.data_ptr(), njobs, total, s), "awr_pack_weights_batched")
-        for layer in self.layers:
-            if layer.batchable:
-                continue
-            for name, args, *_ in layer.pack_calls():
-                if name == "__copy__":
-                    args[0].copy_(args[1])
-                elif name != "awr_split_weight" or want_split:
-                    L.check(getattr(L.lib, name)(*args, s), name)
-        for fn, args, name in self.pack_ops:
-            L.check(fn(*args[:-1], s), name)
-
-    timer = None     # optional KernelTimer (bench.py): brackets every GEMM-family launch with HIP events
-    # When set (list of streams): weight-gradient GEMMs are issued round-robin on these extra HIP streams and run concurrently
-    # with the data-gradient chain.  Two different kernels co-resident on a CU are never in lock-step, so each one's
-    # prologue/epilogue/barrier bubbles are filled by the other's MFMAs (+4.6 % on the ResNet18 step).
-    side_streams = None
-
-    # Data parallel + side streams: a bucket's scatter (awr_unpack_wgrads_batched) and its all-reduce are issued on THIS stream, which
-    # waits for the main chain and for the weight-gradient streams at the hand-off point -- the main stream itself never waits for
-    # the side streams in the middle of the backward, so the data-gradient chain keeps running under the bucket's collective.
-    comm_stream = None
-
-    def _run(self, ops):
-        s = L.stream()
-        timer = self.timer
-        side = self.side_streams if (ops is self.bwd_ops and timer is None) else None
-        comm = self.comm_stream if (side is not None and self.bucket_hook is not None and self.n_buckets > 1) else None
-        pending, nside, handed = False, 0, False
-        if side is not None:
-            main = torch.cuda.current_stream()
-        fside = self.side_streams if (ops is self.fwd_ops and timer is None and self.side_streams) else None
-        if fside is not None:
-            main = torch.cuda.current_stream()
-
-        def hand_off():                          # everything the bucket needs (main chain so far + weight gradients) -> comm stream
-            comm.wait_stream(main)
-            for st in side:
-                comm.wait_stream(st)
-        for fn, args, name in ops:
-            if comm is not None and name == "awr_unpack_wgrads_batched":
-                hand_off()
-                handed = True
-                rc = fn(*args[:-1], comm.cuda_stream)
-                if rc != 0:
-                    raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
-                continue
-            if comm is not None and name == "__bucket__":
-                if not handed:
-                    hand_off()
-                handed = False
-                with torch.cuda.stream(comm):    # torch's RCCL stream orders itself after the CURRENT stream at the call
-                    self.bucket_hook(args[0], args[1])
-                continue
-            if side is not None and pending and not name.startswith("awr_conv_") and name not in _NO_JOIN and not name.startswith("awr_stem_"):
-                for st in side:                  # join before anything that consumes the weight-gradient scratch (unpack, buckets, copies)
-                    main.wait_stream(st)
-                pending = False
-            if fn is None:
-                if name in ("__fork__", "__endfork__", "__join__"):
-                    if fside is not None:
-                        st = fside[args[0] % len(fside)]
-                        if name == "__fork__":
-                            st.wait_stream(main)
-                            s = st.cuda_stream
-                        elif name == "__endfork__":
-                            s = main.cuda_stream
-                        else:
-                            main.wait_stream(st)
-                elif name == "__zero__":
-                    args[0].zero_()
-                elif name == "__bucket__":
-                    if self.bucket_hook is not None:
-                        self.bucket_hook(args[0], args[1])
-                else:
-                    args[0].copy_(args[1])
-                continue
-            if side is not None and name in self._side_ok:
-                st = side[nside % len(side)]
-                nside += 1
-                st.wait_stream(main)             # its operands (dY, x) are final at this point of the main stream
-                rc = fn(*args[:-1], st.cuda_stream)
-                pending = True
-            elif timer is not None and name.startswith(("awr_conv_", "awr_stem_")):
-                timer.begin(name)
-                rc = fn(*args[:-1], s)
-                timer.end()
-            else:
-                rc = fn(*args[:-1], s)
-            if rc != 0:
-                raise L.AwrError("%s failed (%d): %s" % (name, rc, L.last_error()))
-        if side is not None and (pending or comm is not None):
-            for st in side:
-                main.wait_stream(st)
-            if comm is not None:                 # next step's scratch fill / optimiser must see the scatters
-                main.wait_stream(comm)
-
-    def forward(self):
-        self._run(self.fwd_ops)
-        if self.training:
-            for bn in self.bns:
-                bn.counter += self.bn_repeat
-
-    def backward(self):
-        assert self._built_bwd
-        self._run(self.bwd_ops)
+    def __del__(self):
+        try:
+            if self.h and self.net._handle.h:
+                L.lib.awr_plan_destroy(self.h)
+            self.h = None
+        except Exception:
+            pass

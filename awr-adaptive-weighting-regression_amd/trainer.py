@@ -79,9 +79,9 @@ class TrainEngine:
         self.dp = world > 1 or (process_group is not None and os.environ.get("AWR_FORCE_DP") == "1")   # test hook: 1-rank group
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
                                  n_buckets=n_buckets if self.dp else 1)
-        # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off)
-        self.plan.side_streams = [torch.cuda.Stream(device=dev) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
-        self.plan.comm_stream = torch.cuda.Stream(device=dev) if (wgrad_streams > 0 and self.dp) else None
+        # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data
+        # parallel: one more stream that finished gradient buckets (scatter + all-reduce) are handed to
+        self.plan.set_streams(wgrad_streams, comm=(wgrad_streams > 0 and self.dp))
         self._autotune = bool(autotune)
         self._compiled = False
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
@@ -121,7 +121,7 @@ class TrainEngine:
         B, J, F, H = self.B, self.J, self.F, self.H
         s = L.stream()
         plan.refresh_weights()
-        plan._run(plan.fwd_ops)
+        plan.run_forward()
         out = plan.outputs[self.stage]
         gout = plan.grad_outs[self.stage]
         img = plan.img
@@ -136,7 +136,15 @@ class TrainEngine:
             L.call("awr_head_backward", L.ptr(out), L.ptr(img), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), B, J, F, H, self.ks,
                    L.ptr(gout), 1, s)
         L.call("awr_loss_finalize", L.ptr(self.acc), 2, L.ptr(self.losses), s)
-        plan._run(plan.bwd_ops)
+        plan.run_backward()
+
+    def timed_core(self):
+        """The captured part once more, serially, with a HIP-event pair around every conv / stem launch (bench.py's roofline):
+        -> {launch name: seconds}.  Not an optimisation step (no optimiser update)."""
+        self.plan.refresh_weights()
+        per = self.plan.timed("fwd")
+        per.update(self.plan.timed("bwd"))
+        return per
 
     def _optimizer(self):
         net = self.net
@@ -181,8 +189,7 @@ class TrainEngine:
             self.graph.replay()
         else:
             self._core()
-        for bn in plan.bns:
-            bn.counter += plan.bn_repeat
+        self.net._counters += plan.bn_repeat          # num_batches_tracked of every BatchNorm (host side)
         if self.dp:
             for w in self._works:           # compute stream waits for the bucket all-reduces before the optimiser
                 w.wait()
@@ -279,8 +286,8 @@ class InferEngine:
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
-        if self.plan.side_streams is None:          # forward branches (ResNet downsample projections) run beside the main chain
-            self.plan.side_streams = [torch.cuda.Stream(device=net.device) for _ in range(4)]
+        if self.plan.n_side == 0:          # forward branches (ResNet downsample projections, Hourglass skip residuals) run beside the main chain
+            self.plan.set_streams(4)
         self._autotune, self._compiled = bool(autotune), False
         self.J, self.F = net.J, img_size // getattr(net, "downsample", 2)
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)
@@ -289,7 +296,7 @@ class InferEngine:
 
     def _core(self):
         plan = self.plan
-        plan._run(plan.fwd_ops)
+        plan.run_forward()
         L.call("awr_head_forward", L.ptr(plan.outputs[self.stage]), L.ptr(plan.img), self.B, self.J, self.F, self.H, self.ks, L.ptr(self.jt),
                None, L.stream())
 

@@ -28,31 +28,6 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16); the split-operand mode runs on this pipe
 
 
-class KernelTimer:
-    """HIP-event pairs around individual kernel launches on the current stream."""
-
-    def __init__(self):
-        self.pairs, self._cur = [], None
-
-    def begin(self, name):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self._cur = (name, e0)
-
-    def end(self):
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        self.pairs.append((self._cur[0], self._cur[1], e1))
-
-    def collect(self):
-        out = {}
-        for name, e0, e1 in self.pairs:
-            d = out.setdefault(name, [0.0, 0])
-            d[0] += e0.elapsed_time(e1) * 1e-3
-            d[1] += 1
-        return out
-
-
 def _host_cpu():
     """(physical cores, model string) of the box bench.py runs on."""
     model, cores = "unknown", None
@@ -162,17 +137,16 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
     el = time.perf_counter() - t0
     macs = sum(v for k, v in inf.plan.macs.items())
     if per_layer:
-        tm = KernelTimer()
-        inf.plan.timer = tm
-        inf.use_graph, inf.graph = False, None
+        per = {}
         for _ in range(5):
-            inf(imgs)
-        torch.cuda.synchronize()
-        inf.plan.timer = None
+            for n, sec in inf.plan.timed("fwd").items():
+                d = per.setdefault(n, [0.0, 0])
+                d[0] += sec
+                d[1] += 1
         with open(per_layer, "w") as f:
             f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
-            for n, (sec, c) in sorted(tm.collect().items(), key=lambda kv: -kv[1][0]):
-                f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / sec))
+            for n, (sec, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * inf.plan.macs[n], 2e-12 * inf.plan.macs[n] * c / max(sec, 1e-12)))
     return {"workload": "%s eval forward + head (img -> joints), batch %d" % (net_name, batch), "value": round(batch * steps / el, 2), "unit": "images/s",
             "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "hipgraph": bool(graph),
             "algorithmic_gflop_per_image": round(2e-9 * macs / batch, 3),
@@ -256,36 +230,27 @@ def main():
     warm = args.warmup
     for _ in range(warm):
         eng.step(img, jt)
-    # per-kernel HIP events only make sense when kernels do not share the GPU: with stream overlap (the default) or graph
-    # replay the timed region runs untouched and the per-kernel roofline comes from a serialised pass right after it
-    serial = not graph and args.wgrad_streams == 0
-    timer = None
-    if serial:
-        timer = KernelTimer()
-        eng.plan.timer = timer
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step(img, jt)
     sync()
     elapsed = time.perf_counter() - t0
-    eng.plan.timer = None
     if pg is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t[0])
     loss = float(eng.losses[2])
 
-    if not serial:                   # separate serialised eager pass for the per-kernel events
-        eng.plan.side_streams = None
-        timer = KernelTimer()
-        eng.use_graph, eng.graph = False, None
-        eng.plan.timer = timer
-        for _ in range(3):
-            eng.step(img, jt)
-        torch.cuda.synchronize()
-        eng.plan.timer = None
-    per = timer.collect()
+    # per-kernel HIP events only make sense when kernels do not share the GPU: the timed region runs untouched (side streams /
+    # graph replay) and the per-kernel roofline comes from serialised passes of the same plan right after it
+    per = {}
+    for _ in range(3):
+        for n, sec in eng.timed_core().items():
+            d = per.setdefault(n, [0.0, 0])
+            d[0] += sec
+            d[1] += 1
+    torch.cuda.synchronize()
     macs = eng.plan.macs
     fam = {"conv_gemm_kernel(fwd+dgrad)": ("awr_conv_gemm:", "awr_conv_dgrad:"), "conv_wgrad_kernel": ("awr_conv_wgrad:",),
            "stem kernels (fused direct 5x5 conv+BN+ReLU+pool, fwd+bwd incl. recomputation)": ("awr_stem_",)}
@@ -320,7 +285,7 @@ def main():
             traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_x2"] + v["write_MB_per_launch"]) for v in ent) / nl * 1e6)
             traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 per the gfx950 note, bytes per launch)" % os.path.basename(tpath)
     roofline = {
-        "bound": "mfma", "kernel": dom, "event_pass": "timed region" if serial else "serialised eager pass right after the timed region (in the timed region the step is one hipGraph replay / kernels overlap on side streams)",
+        "bound": "mfma", "kernel": dom, "event_pass": "serialised replay of the same plan right after the timed region (awr_plan_run_timed: a HIP-event pair around every launch; in the timed region kernels overlap on side streams)",
         "achieved": round(flop_mult * kern[dom]["tflops"], 2), "peak": peak_tf, "unit": "TFLOP/s", "mfma_flops_per_algorithmic_flop": flop_mult,
         "frac": round(flop_mult * kern[dom]["tflops"] / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flop_per_launch": round(kern[dom]["flops"] / max(kern[dom]["launches"], 1)),

@@ -325,6 +325,69 @@ int awr_upsample2_bwd(const float* dout, int B, int Hl, int Wl, int C, float* dl
 int awr_nhwc_to_nchw(const float* in, int B, int P, int Cp, int C, float* out, void* stream);
 int awr_nchw_to_nhwc(const float* in, int B, int P, int Cp, int C, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Network-level API: the two backbones as natively built and replayed static plans.
+ * Replaces get_deconv_net(18, J, downsample) / PoseNet('hourglass_<n>', J) construction, forward and
+ * autograd backward (model/resnet_deconv.py:8-16,:19-136,:145-174; model/hourglass.py:6-165;
+ * train.py:52-58, :116-130).  The Python host keeps only the nn.Module shell (state_dict views,
+ * autograd hook, optimiser plumbing).
+ *
+ * Ownership: the caller owns the parameter / gradient / BatchNorm-buffer arenas (awr_net_bind) and
+ * the boundary tensors handed to awr_plan_create (depth batch, NCHW dense maps and their gradients);
+ * the library owns packed weights, activations, gradients and scratch (freed by *_destroy).  Calls
+ * on one net / plan come from one host thread.
+ * -----------------------------------------------------------------------------------------*/
+typedef struct awr_net awr_net;
+typedef struct awr_plan awr_plan;
+
+/* kind 0: ResNet18-deconv (nstack ignored); kind 1: stacked hourglass (downsample ignored, feature size H/2).
+ * Creates the checkpoint layout only: no device memory is touched until awr_net_bind. */
+int awr_net_create(int kind, int nstack, int J, int downsample, awr_net** out);
+int awr_net_destroy(awr_net* net);
+/* state_dict entries (parameters, running stats, counters) in the reference's order; arena sizes in floats.
+ * [0, n_active) of the parameter arena receives gradients; the tail holds hourglass skip_layers that never run */
+int awr_net_sizes(const awr_net* net, int64_t* n_tensors, int64_t* n_params, int64_t* n_active,
+                  int64_t* n_buffers, int* n_counters, int* nstage);
+/* entry i: torch key, kind (0 conv weight OIHW, 1 transposed-conv weight IOHW, 2 conv bias, 3 BN weight, 4 BN bias,
+ * 5 running_mean, 6 running_var, 7 num_batches_tracked), shape, offset in floats into the parameter arena (kinds 0-4)
+ * or the buffer arena (5, 6), counter index (7); unused = never receives a gradient */
+int awr_net_tensor_info(const awr_net* net, int64_t i, const char** key, int* kind, int* ndim,
+                        int64_t shape[4], int64_t* offset, int* unused);
+/* attach 16-byte aligned device arenas (n_params, n_params, n_buffers floats); destroys the net's plans */
+int awr_net_bind(awr_net* net, float* params, float* grads, float* buffers);
+
+/* One static plan for (B, H, mode).  img (B,1,H,H); outs[stage] (B,4J,F,F) NCHW dense maps; grad_outs[stage] their
+ * gradients (training plans; zero the stages you do not supervise).  supervised_mask: bit s = stage s receives a
+ * gradient (hourglass training supervises the last stage only, train.py:116-121); bn_repeat: BatchNorm momentum is
+ * applied that many times per forward (the reference runs `stacks` forwards per iteration); n_buckets > 1: the backward
+ * hands out gradient-arena ranges through the bucket callback as soon as they are final. */
+int awr_plan_create(awr_net* net, int B, int H, int training, unsigned supervised_mask, int bn_repeat,
+                    int n_buckets, float* img, float* const* outs, float* const* grad_outs, awr_plan** out);
+int awr_plan_destroy(awr_plan* plan);
+int awr_plan_info(const awr_plan* plan, int64_t* bytes, int* deterministic, int* n_fwd, int* n_bwd,
+                  int* n_buckets, int* n_gemm, int* n_bn);
+int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* ready_op);
+/* op i of the forward (list 0) / backward (list 1) launch list: name, algorithmic MACs (GEMM-family launches),
+ * flags bit 0 = weight gradient that may run on a side stream, bit 1 = conv / stem family (timed by awr_plan_run_timed) */
+int awr_plan_op(const awr_plan* plan, int list, int i, const char** name, double* macs, int* flags);
+/* n_side extra HIP streams (weight gradients in the backward, forked branches in the forward); comm != 0 adds the
+ * stream buckets are handed to */
+int awr_plan_set_streams(awr_plan* plan, int n_side, int comm);
+typedef void (*awr_bucket_cb)(void* user, int64_t lo, int64_t hi, void* stream);
+/* cb(user, lo, hi, stream): grads[lo, hi) is final in `stream` order -- start its all-reduce there */
+int awr_plan_set_bucket_callback(awr_plan* plan, awr_bucket_cb cb, void* user);
+/* repack every conv weight (and re-fold eval BatchNorms) from the arena; forward; backward */
+int awr_plan_refresh_weights(awr_plan* plan, void* stream);
+int awr_plan_forward(awr_plan* plan, void* stream);
+int awr_plan_backward(awr_plan* plan, void* stream);
+/* serial replay with a HIP-event pair around every conv / stem launch: ms[i] per op (synchronises the stream) */
+int awr_plan_run_timed(awr_plan* plan, int list, void* stream, float* ms);
+/* time the tile / split-K candidates of every GEMM launch in place (no-op in deterministic mode); read / preset choices */
+int awr_plan_autotune(awr_plan* plan, int reps, void* stream);
+int awr_plan_gemm(const awr_plan* plan, int i, const char** name, int* tile_m, int* tile_n, int* target_blocks,
+                  float* us, int* tuned);
+int awr_plan_set_gemm(awr_plan* plan, int i, int tile_m, int tile_n, int target_blocks, float us);
+
 #ifdef __cplusplus
 }
 #endif

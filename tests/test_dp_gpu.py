@@ -20,7 +20,8 @@ def _run(tmp_path, backend="gloo"):
     out = os.path.join(str(tmp_path), "dp")
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AWR_TEST_BACKEND=backend)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AWR_TEST_BACKEND=backend,
+                   AWR_DETERMINISTIC="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -42,6 +43,7 @@ def test_two_rank_data_parallel_engine(tmp_path):
     r0, r1 = _run(tmp_path)
     a0, a1 = r0["same"], r1["same"]
     assert torch.equal(a0["params"], a1["params"]) and torch.equal(a0["buffers"], a1["buffers"])
+    awr_amd.set_deterministic(True)                  # the workers ran with AWR_DETERMINISTIC=1: the reference run must match them bitwise
     torch.manual_seed(1234)
     net = awr_amd.get_deconv_net(18, 14, 2).cuda()
     eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, use_graph=False, autotune=False)
@@ -50,10 +52,10 @@ def test_two_rank_data_parallel_engine(tmp_path):
         img, jt = O.synth_batch(2, 128, 14, seed=70 + s)
         ref_losses.append(float(eng.step(img.cuda(), jt.cuda())[0][2]))
     ref = net.flat_params()[:net.n_active].cpu()
-    assert abs(a0["losses"][0] - ref_losses[0]) <= 1e-6 * abs(ref_losses[0])
-    d = (a0["params"] - ref).abs()
-    # same arithmetic up to the summation order of atomics; two Adam steps move every weight by <= 2 lr
-    assert float(d.quantile(0.99)) <= 2e-4 and float(d.max()) <= 2.1e-3, (float(d.quantile(0.99)), float(d.max()))
+    awr_amd.set_deterministic(False)
+    # both ranks fed the same shard: (g + g) / 2 == g exactly, so two data-parallel steps ARE two single-process steps, bit for bit
+    assert a0["losses"] == ref_losses
+    assert torch.equal(a0["params"], ref)
     b0, b1 = r0["split"], r1["split"]
     assert b0["losses"] != b1["losses"]
     assert torch.equal(b0["params"], b1["params"])

@@ -22,7 +22,7 @@ if os.environ.get("PROFILE"):
     torch.cuda.synchronize()
     st = pstats.Stats(pr).sort_stats("cumulative")
     st.print_stats(28)
-    print("ops: fwd %d bwd %d" % (len(eng.plan.fwd_ops), len(eng.plan.bwd_ops)))
+    print("ops: fwd %d bwd %d" % (len(eng.plan.op_names("fwd")), len(eng.plan.op_names("bwd"))))
 ts = []
 for _ in range(10):
     torch.cuda.synchronize()
