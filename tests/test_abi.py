@@ -69,3 +69,44 @@ def test_product_path_fails_loudly_on_cpu_tensors(lib):
     net = awr_amd.get_deconv_net(18, 14, 2)
     with pytest.raises(lib.AwrError):
         net(torch.zeros(1, 1, 128, 128))
+
+
+def test_network_level_layout_without_a_gpu(lib):
+    """awr_net_create builds the checkpoint layout on the host only: keys, shapes and kinds of the three reference networks
+    must equal the manifest generated from the reference's own modules (tests/golden/statedict_manifest.json), arena offsets
+    must be 16-byte aligned and disjoint, never-trained hourglass skip_layers must sit behind n_active."""
+    import ctypes as C
+    import json
+    man = json.load(open(os.path.join(REPO, "tests", "golden", "statedict_manifest.json")))
+    L = lib
+    for name, (kind, nstack, J) in {"resnet_18_J14": (0, 1, 14), "hourglass_1_J14": (1, 1, 14), "hourglass_2_J21": (1, 2, 21)}.items():
+        h = C.c_void_p()
+        assert L.lib.awr_net_create(kind, nstack, J, 2, C.byref(h)) == 0, L.last_error()
+        nt, npar, nact, nbuf, ncnt, nst = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        assert L.lib.awr_net_sizes(h, C.byref(nt), C.byref(npar), C.byref(nact), C.byref(nbuf), C.byref(ncnt), C.byref(nst)) == 0
+        ref = man[name]
+        assert nt.value == len(ref) and nst.value == nstack
+        key, kd, nd, off, un = C.c_char_p(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        spans, n_float, n_unused = [], 0, 0
+        for i, (rkey, rshape, rdtype) in enumerate(ref):
+            assert L.lib.awr_net_tensor_info(h, i, C.byref(key), C.byref(kd), C.byref(nd), shape, C.byref(off), C.byref(un)) == 0
+            assert key.value.decode() == rkey and list(shape[:nd.value]) == rshape, (rkey, list(shape[:nd.value]), rshape)
+            assert (kd.value == 7) == (rdtype == "int64")
+            if kd.value <= 4:
+                n = 1
+                for d in rshape:
+                    n *= d
+                assert off.value % 4 == 0 and off.value + n <= npar.value
+                assert (off.value >= nact.value) == bool(un.value)
+                spans.append((off.value, off.value + n))
+                n_float += n
+                n_unused += n if un.value else 0
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))          # views never overlap
+        assert (kind == 0) == (n_unused == 0) and nact.value <= npar.value
+        assert L.lib.awr_net_tensor_info(h, nt.value, None, None, None, None, None, None) == -1      # index out of range
+        assert L.lib.awr_plan_create(h, 2, 128, 0, 1, 1, 1, None, None, None, C.byref(C.c_void_p())) == -1      # not bound / null pointers
+        assert L.lib.awr_net_destroy(h) == 0
+    assert L.lib.awr_net_create(2, 1, 14, 2, C.byref(C.c_void_p())) == -1 and "kind" in L.last_error()
+    assert L.lib.awr_net_create(0, 1, 14, 3, C.byref(C.c_void_p())) == -1

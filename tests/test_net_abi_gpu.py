@@ -1,0 +1,100 @@
+"""GPU: one full ResNet18-deconv optimisation step driven through the NETWORK-LEVEL C ABI alone (include/awr_hip.h: awr_net_*,
+awr_plan_*, head / loss / optimiser entry points) -- ctypes on raw device pointers, torch only as the allocator -- the way a
+non-Python host would use libawr_hip.so.  Checked against the oracle and against the golden vectors."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import awr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resnet18_train_step_through_the_c_abi_only(golden_dir):
+    import awr_amd  # noqa: F401
+    from awr_amd import _lib as L
+    lib = L.lib
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "resnet_18_train.npz"))
+    img_h, jt_h = torch.from_numpy(g["img"]), torch.from_numpy(g["jt_gt"])
+    B, J, H, F, ks = img_h.shape[0], int(g["J"]), 128, 64, float(g["ks"])
+
+    def ok(rc):
+        assert rc == 0, L.last_error()
+
+    net = C.c_void_p()
+    ok(lib.awr_net_create(0, 1, J, 2, C.byref(net)))
+    nt, npar, nact, nbuf, ncnt, nst = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+    ok(lib.awr_net_sizes(net, C.byref(nt), C.byref(npar), C.byref(nact), C.byref(nbuf), C.byref(ncnt), C.byref(nst)))
+    # arenas: parameters / gradients / BatchNorm buffers, filled from a state_dict through awr_net_tensor_info (the checkpoint layout)
+    params, grads, bufs = torch.zeros(npar.value, device=dev), torch.zeros(npar.value, device=dev), torch.zeros(nbuf.value, device=dev)
+    sd = O.procedural_state(O.manifest_for("resnet_18", J), seed=1)
+    key, kd, nd, off, un = C.c_char_p(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+    shape = (C.c_int64 * 4)()
+    where = {}
+    for i in range(nt.value):
+        ok(lib.awr_net_tensor_info(net, i, C.byref(key), C.byref(kd), C.byref(nd), shape, C.byref(off), C.byref(un)))
+        k = key.value.decode()
+        if kd.value == 7:
+            continue
+        arena = params if kd.value <= 4 else bufs
+        n = sd[k].numel()
+        arena[off.value:off.value + n].copy_(sd[k].reshape(-1))
+        where[k] = (kd.value, off.value, n)
+    ok(lib.awr_net_bind(net, params.data_ptr(), grads.data_ptr(), bufs.data_ptr()))
+    # one training plan: boundary tensors are the caller's
+    img, out, gout = img_h.to(dev), torch.zeros(B, 4 * J, F, F, device=dev), torch.zeros(B, 4 * J, F, F, device=dev)
+    outs, gouts = (C.c_void_p * 1)(out.data_ptr()), (C.c_void_p * 1)(gout.data_ptr())
+    plan = C.c_void_p()
+    ok(lib.awr_plan_create(net, B, H, 1, 1, 1, 1, img.data_ptr(), outs, gouts, C.byref(plan)))
+    s = torch.cuda.current_stream().cuda_stream
+    jt_gt, jt, stat, g_jt = jt_h.to(dev), torch.zeros(B, J, 3, device=dev), torch.zeros(B, J, 2, device=dev), torch.zeros(B, J, 3, device=dev)
+    acc, losses = torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(3, device=dev)
+    m, v = torch.zeros(nact.value, device=dev), torch.zeros(nact.value, device=dev)
+    ok(lib.awr_plan_set_streams(plan, 2, 0))
+    for step in (1, 2):
+        # train.py:107-131 as ABI calls: repack, forward, head, losses (coord + dense), their gradients, backward, Adam
+        ok(lib.awr_plan_refresh_weights(plan, s))
+        ok(lib.awr_plan_forward(plan, s))
+        ok(lib.awr_head_forward(out.data_ptr(), img.data_ptr(), B, J, F, H, ks, jt.data_ptr(), stat.data_ptr(), s))
+        ok(lib.awr_zero_f64(acc.data_ptr(), 2, s))
+        ok(lib.awr_dense_loss(out.data_ptr(), jt_gt.data_ptr(), img.data_ptr(), B, J, F, H, ks, 0.01, 1.0, acc.data_ptr() + 8, gout.data_ptr(), 0, s))
+        ok(lib.awr_huber(jt.data_ptr(), jt_gt.data_ptr(), B * J * 3, 0.01, 1.0, acc.data_ptr(), g_jt.data_ptr(), 0, s))
+        ok(lib.awr_head_backward(out.data_ptr(), img.data_ptr(), jt.data_ptr(), stat.data_ptr(), g_jt.data_ptr(), B, J, F, H, ks, gout.data_ptr(), 1, s))
+        ok(lib.awr_loss_finalize(acc.data_ptr(), 2, losses.data_ptr(), s))
+        ok(lib.awr_plan_backward(plan, s))
+        if step == 1:
+            torch.cuda.synchronize()
+            loss0, jt0, grads0 = float(losses[2]), jt.cpu().numpy().copy(), grads.clone()
+        ok(lib.awr_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), nact.value, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, 1.0, s))
+    torch.cuda.synchronize()
+    # golden (reference autograd, tag c1 = coord_weight 1)
+    assert abs(loss0 - float(g["c1_loss0"])) <= 2e-4 * abs(float(g["c1_loss0"]))
+    assert float(np.abs(jt0 - g["c1_jt0"]).max()) * 150 <= 5e-3
+    pkeys = [str(k) for k in g["pkeys"]]
+    gmax = float(np.max(g["c1_grad_l2"]))
+    for i, k in enumerate(pkeys):
+        kd_, o_, n_ = where[k]
+        got = float(grads0[o_:o_ + n_].double().norm())
+        assert abs(got - float(g["c1_grad_l2"][i])) <= 5e-3 * (float(g["c1_grad_l2"][i]) + 1e-3 * gmax), k
+    assert abs(float(losses[2]) - float(g["c1_loss1"])) <= 2e-2 * abs(float(g["c1_loss1"]))
+    # BatchNorm running statistics moved (momentum 0.1, twice) and match the oracle after two steps
+    sdo, ost = O.procedural_state(O.manifest_for("resnet_18", J), seed=1), {"step": 0, "m": {}, "v": {}}
+    for _ in range(2):
+        O.train_step("resnet_18", sdo, ost, img_h, jt_h, ks, 1.0, 1.0)
+    for k in ("pre.1.running_mean", "layer4.1.bn2.running_var", "deconv_layers.7.running_mean"):
+        kd_, o_, n_ = where[k]
+        np.testing.assert_allclose(bufs[o_:o_ + n_].cpu().numpy(), sdo[k].numpy(), rtol=3e-3, atol=3e-4)
+    # timed replay + autotune entry points
+    nbytes, det, nf, nb, nbk, ng, nbn = C.c_int64(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ok(lib.awr_plan_info(plan, C.byref(nbytes), C.byref(det), C.byref(nf), C.byref(nb), C.byref(nbk), C.byref(ng), C.byref(nbn)))
+    assert nbytes.value > 1 << 20 and nbn.value == 23 and nbk.value == 1 and ng.value > 60
+    ms = (C.c_float * nf.value)()
+    ok(lib.awr_plan_run_timed(plan, 0, s, ms))
+    assert sum(ms) > 0
+    ok(lib.awr_plan_autotune(plan, 1, s))
+    ok(lib.awr_plan_destroy(plan))
+    ok(lib.awr_net_destroy(net))
