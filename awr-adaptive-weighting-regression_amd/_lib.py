@@ -48,12 +48,12 @@ class ConvArgs(C.Structure):
                 ("Hout", C.c_int), ("Wout", C.c_int), ("N", C.c_int),
                 ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
                 ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int), ("tile_m", C.c_int), ("tile_n", C.c_int),
-                ("ph", Phase * 4), ("w_split", C.c_void_p), ("stat_slots", C.c_int), ("stat_slot_base", C.c_int)]
+                ("ph", Phase * 4), ("w_split", C.c_void_p), ("stat_slots", C.c_int), ("stat_slot_base", C.c_int), ("in2", C.c_void_p), ("Cin1", C.c_int)]
 
 
 class PackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("split", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("T", C.c_int), ("transpose", C.c_int),
-                ("rows", C.c_int), ("ld", C.c_int), ("first", C.c_int64)]
+                ("rows", C.c_int), ("ld", C.c_int), ("first", C.c_int64), ("cols", C.c_int), ("reserved", C.c_int)]
 
 
 class UnpackJob(C.Structure):

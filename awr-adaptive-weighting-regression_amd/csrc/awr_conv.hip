@@ -274,7 +274,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // NP = 0: operands stay fp32 in LDS, v_mfma_f32_32x32x2_f32.  NP = 6 / 9: split-operand mode (above).
 // AFF (split mode only): the fused input affine / ReLU is compiled in (two instantiations instead of a run-time branch around the
 // MFMA block: a branch there makes the register allocator keep both arms' accumulator copies alive).
-template <int TM, int TN, int NP, bool AFF>
+// DUAL (fp32 mode, single tap): the K extent is the concatenation of TWO input tensors at the same pixel -- channels [0, Cin1) come
+// from `in` (with the fused input affine, if any), [Cin1, Cin) from `in2` (plain) -- i.e. out = W_a . a + W_x . x in one launch:
+// the hourglass residual's conv3 + skip_layer (hourglass.py:44-59) without writing and re-reading the skip branch's output.
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
@@ -317,7 +320,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             a_img[i] = 0;
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
+    const int cin1 = DUAL ? a.Cin1 : a.Cin;         // channels (= pixel pitch) of `in`; DUAL: `in2` holds the other a.Cin - cin1
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u);
+    const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(DUAL ? a.in2 : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, OOB);
     unsigned w_off[RB];
 #pragma unroll
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     // Per tap (every Cin/32 K-slices): bounds test + base byte offset of each staged row.  Per K-slice: one add
     // per row.  Keeping the per-slice VALU work tiny matters: the two waves that share a SIMD's MFMA pipe drift
     // into lock-step, so every VALU cycle spent between MFMA bursts is a cycle the matrix pipe idles.
-    unsigned a_off[RA], tapmask = 0, wtap = 0;
+    unsigned a_off[RA], a_off2[DUAL ? RA : 1], tapmask = 0, wtap = 0;
     auto set_tap = [&](int tap) {
         const int tp = ph.tap[tap];
         const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         for (int i = 0; i < RA; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
+            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * cin1 + kc) * 4u;
+            if constexpr (DUAL) a_off2[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * (a.Cin - cin1) + kc) * 4u;
             tapmask |= ok ? (1u << i) : 0u;
         }
         wtap = NP ? (unsigned)wt * (a.Cin / BK) * (6u * BK) : (unsigned)wt * a.Cin * 4u;
@@ -381,8 +387,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     // issue the global loads of one K-slice; nothing here waits for memory
     auto load_slice = [&](int c0) {
         const unsigned cb = (unsigned)c0 * 4u;
+        if (DUAL && c0 >= cin1) {            // wave-uniform: this K-slice comes from the second tensor
+            const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in2, (tapmask & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+        }
         if constexpr (NP == 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + (wtap + cb));
@@ -396,14 +408,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     };
     // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
     auto store_slice = [&]() {
-        if (a.in_scale) {
+        if (a.in_scale && (!DUAL || c0_staged < cin1)) {
             // (requesting the coefficients together with the slice's data, one slice ahead, was measured on the same box: the 8 extra
             // registers cost a wave of occupancy, the step went from 14.1 to 14.6 ms)
             const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
-        } else if (a.relu_in) {
+        } else if (a.relu_in && (!DUAL || c0_staged < cin1)) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f); ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
@@ -1168,6 +1180,10 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         b.out = a->out + out_img * b.B * c;
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
+        if (a->in2) {
+            b.in = a->in + (int64_t)a->Hin * a->Win * a->Cin1 * b.B * c;
+            b.in2 = a->in2 + (int64_t)a->Hin * a->Win * (a->Cin - a->Cin1) * b.B * c;
+        }
         if (a->stat_slots > 0) b.stat_slot_base = a->stat_slot_base + c * (a->stat_slots / nchunk);
         if (int e = conv_gemm_one(&b, stream)) return e;
     }
@@ -1183,6 +1199,8 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && !a->res), "conv_gemm: fused BN-backward reduction needs coef + stats and no accumulate");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
+    AWR_REQUIRE(!a->in2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),
+                "conv_gemm: a second input tensor needs the FP32-MFMA mode, one tap and 0 < Cin1 < Cin, Cin1 %% 32 == 0");
     for (int p = 0; p < a->nphase; ++p) {
         AWR_REQUIRE(a->ph[p].ntaps >= 1 && a->ph[p].ntaps <= 16, "conv_gemm: phase %d has %d taps", p, a->ph[p].ntaps);
         for (int t = 0; t < a->ph[p].ntaps; ++t) AWR_REQUIRE((a->ph[p].tap[t] >> 16) >= 0 && (a->ph[p].tap[t] >> 16) < a->T, "conv_gemm: tap index out of range");
@@ -1209,7 +1227,8 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     const bool aff = a->in_scale != nullptr || a->relu_in;
 #define AWR_LAUNCH_GEMM(tm, tn)                                                                          \
     do {                                                                                                 \
-        if (g_products == 6 && aff) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, true>), grid, dim3(256), 0, st, *a);   \
+        if (a->in2) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false, true>), grid, dim3(256), 0, st, *a);             \
+        else if (g_products == 6 && aff) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, true>), grid, dim3(256), 0, st, *a);   \
         else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
         else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)

@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const awr_pack_job* _
     const int inner = jb.transpose ? jb.d0 : jb.d1, valid_rows = jb.transpose ? jb.d1 : jb.d0;
     const bool rok = r < valid_rows;
     const int cch = (PACK_TILE / TS) & ~31;
-    for (int c0 = 0; c0 < ld; c0 += cch) {
-        const int cc = ld - c0 < cch ? ld - c0 : cch;
+    const int cols = jb.cols > 0 ? jb.cols : ld;        // columns written per line (the pitch stays ld)
+    for (int c0 = 0; c0 < cols; c0 += cch) {
+        const int cc = cols - c0 < cch ? cols - c0 : cch;
         for (int i = threadIdx.x; i < cc * T; i += 256) {
             const int c = i / T, t = i - c * T;
             float v = 0.f;

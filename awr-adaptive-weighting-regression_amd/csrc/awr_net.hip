@@ -389,6 +389,15 @@ struct ConvLayer {
     const float* bias_ptr() const { return head ? bias_cat : bias; }
 };
 
+// conv3 + skip_layer of a hourglass residual whose skip path is a 1x1 conv (hourglass.py:38-47, :44-59), forward-fused: one GEMM
+// over K = [conv3's input channels | the block input's channels], packed weight rows [W3 row | Wskip row], bias b3 + bskip
+struct DualLayer {
+    ConvLayer *c3 = nullptr, *sk = nullptr;
+    Packed p;
+    float* bias_sum = nullptr;
+    std::string name;
+};
+
 struct BNLayer {
     int C = 0;
     float *gamma = nullptr, *beta = nullptr, *ggamma = nullptr, *gbeta = nullptr, *rmean = nullptr, *rvar = nullptr;
@@ -408,6 +417,7 @@ struct awr_net {
     float *params = nullptr, *grads = nullptr, *buffers = nullptr;
     std::map<std::string, ConvLayer> convs;
     std::map<std::string, BNLayer> bns;
+    std::map<std::string, DualLayer> duals;
     std::vector<void*> owned;            // packed weights (device), freed with the net
     std::vector<awr_plan*> plans;
     std::vector<std::string> key_storage;
@@ -486,6 +496,7 @@ static int head_layer(awr_net* n, ConvLayer& h, int cin, const std::string& a, c
 static int make_layers(awr_net* n) {
     n->convs.clear();
     n->bns.clear();
+    n->duals.clear();
     if (n->kind == 0) {
         n->convs["pre.0"] = conv_layer(n, "pre.0.weight", make_spec(false, 25, 64, 1, 1, 0, 32));
         n->bns["pre.1"] = bn_layer(n, "pre.1");
@@ -602,6 +613,7 @@ struct awr_plan {
     std::vector<Op> fwd, bwd, pack_ops;
     std::vector<std::function<int()>> nodes;       // backward emitters, in forward order
     std::vector<ConvLayer*> layers;                // layers whose packed copies this plan refreshes
+    std::vector<DualLayer*> dual_layers;
     std::deque<Tn> tensors;
     std::deque<awr_conv_args> cargs;
     std::deque<awr_wgrad_args> wargs;
@@ -825,6 +837,53 @@ struct Builder {
         return y;
     }
 
+    // y = conv3(a) + skip(x) (+ both biases) as ONE launch (FP32-MFMA mode): the skip branch's output is never written or re-read.
+    // Backward: the two layers' own weight / data gradients, both reading d(y).
+    Tn* conv_dual(Tn* a, Tn* x, DualLayer* d, bool want_stats) {
+        use_layer(d->c3);
+        use_layer(d->sk);
+        bool seen = false;
+        for (auto* q : P.dual_layers) seen = seen || q == d;
+        const int cin1 = d->c3->spec.cin_pad, cin2 = d->sk->spec.cin_pad, cout = d->c3->spec.cout;
+        if (!seen) {
+            if (!d->p.p) {
+                PackRecipe r{cout, cin1 + cin2, 1, 0, (int)round_up(cout, N_ALIGN), cin1 + cin2};
+                if (int e = alloc_packed(&N, d->p, r)) err = e;
+                void* bs = nullptr;
+                if (int e = dev_alloc(N.owned, (size_t)cout * 4, true, &bs)) err = e;
+                d->bias_sum = (float*)bs;
+            }
+            P.dual_layers.push_back(d);
+        }
+        const int B = a->B;
+        Spec spec = make_spec(false, cin1 + cin2, cout, 1, 1, 0);
+        const Prob prob = fwd_problem(spec, a->H, a->W);
+        Tn* y = new_t(B, prob.Hout, prob.Wout, prob.N, true, d->name + ".out");
+        if (want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, 1), prob.N);
+        P.cargs.emplace_back();
+        awr_conv_args* ca = &P.cargs.back();
+        fill_conv_args(*ca, prob, B, a->buf, d->p.p, nullptr, y->buf, 1);
+        ca->in2 = x->buf;
+        ca->Cin1 = cin1;
+        if (a->lazy) { ca->in_scale = a->lz_scale; ca->in_shift = a->lz_shift; ca->relu_in = a->lz_relu; }
+        ca->bias = d->bias_sum;
+        ca->stats = y->stats.p;
+        ca->stat_slots = y->stats.p ? y->stats.nslots : 0;
+        const std::string name = "awr_conv_gemm:" + d->name;
+        Op& op = f(name, [ca](void* s) { return awr_conv_gemm(ca, s); });
+        op.gemm = true;
+        op.macs = gemm_macs(fwd_problem(d->c3->spec, a->H, a->W), B, d->c3->spec) + gemm_macs(fwd_problem(d->sk->spec, x->H, x->W), B, d->sk->spec);
+        P.gemms.push_back({ca, nullptr, name});
+        if (P.training) {
+            ConvLayer *c3 = d->c3, *sk = d->sk;
+            P.nodes.push_back([=]() {
+                NET_CHECK(conv_bwd(a, y, c3, nullptr, true));
+                return conv_bwd(x, y, sk, nullptr, true);
+            });
+        }
+        return y;
+    }
+
     int conv_bwd(Tn* x, Tn* y, ConvLayer* layer, Tn* res, bool has_bias) {
         const Spec& spec = layer->spec;
         const int B = x->B, H = x->H, W = x->W;
@@ -878,9 +937,10 @@ struct Builder {
         wa->R = R;
         wa->d_colsum = bsum;
         const std::string wname = "awr_conv_wgrad:" + layer->name;
-        Op& wop = b(wname, [wa](void* s) { return awr_conv_wgrad(wa, s); });
+        const double layer_macs = gemm_macs(fwd_problem(spec, H, W), B, spec);      // forward, data gradient and weight gradient cost the same
+        Op& wop = b(wname, [wa](void* s) { return awr_conv_wgrad(wa, s); });      // (reference into the op vector: do not use after the next push)
         wop.gemm = true;
-        wop.macs = gemm_macs(fwd_problem(spec, H, W), B, spec);
+        wop.macs = layer_macs;
         // safe to run beside the main chain when dY is written once before this node and nobody touches it again.  With a fused
         // residual, d(res) ALIASES dY and later nodes accumulate into it in place -> stays on the main stream.
         wop.side_ok = (res == nullptr);
@@ -928,7 +988,7 @@ struct Builder {
             const std::string dname = "awr_conv_dgrad:" + layer->name;
             Op& dop = b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
             dop.gemm = true;
-            dop.macs = wop.macs;
+            dop.macs = layer_macs;
             P.gemms.push_back({da, nullptr, dname});
         }
         if (res) contribute_identity(res, dy);
@@ -1371,8 +1431,21 @@ struct NetBuilder {
         b.head_out(pred, N.J, out, gout);
     }
 
+    DualLayer* dual_for(const std::string& p) {
+        // conv3 + skip_layer as one launch: FP32-MFMA mode only (the split-operand kernels take one input tensor)
+        if (awr_get_gemm_products() != 1 || !N.convs.count(p + ".skip_layer")) return nullptr;
+        DualLayer& d = N.duals[p];
+        if (!d.c3) {
+            d.c3 = C(p + ".conv3");
+            d.sk = C(p + ".skip_layer");
+            d.name = p + ".conv3+skip_layer";
+        }
+        return &d;
+    }
+
     Tn* residual(Tn* x, const std::string& p) {
         ConvLayer* skip = N.convs.count(p + ".skip_layer") ? C(p + ".skip_layer") : nullptr;
+        DualLayer* dual = dual_for(p);
         ConvOpt o;
         if (P.training) {
             // the three pre-activations feed exactly one conv each: never written to HBM
@@ -1380,6 +1453,7 @@ struct NetBuilder {
             o.want_stats = true;
             a = b.bn_act(b.conv(a, C(p + ".conv1"), o), BN(p + ".bn2"), true, nullptr, true);
             a = b.bn_act(b.conv(a, C(p + ".conv2"), o), BN(p + ".bn3"), true, nullptr, true);
+            if (dual) return b.conv_dual(a, x, dual, true);
             Tn* r = skip ? b.conv(x, skip) : x;
             o.res = r;
             return b.conv(a, C(p + ".conv3"), o);
@@ -1393,6 +1467,7 @@ struct NetBuilder {
         ConvOpt o2;
         o2.out_scale = s3.first; o2.out_shift = s3.second; o2.relu_out = true;
         y = b.conv(y, C(p + ".conv2"), o2);
+        if (dual) return b.conv_dual(y, x, dual, false);
         Tn* r = skip ? b.conv(x, skip) : x;
         ConvOpt o3;
         o3.res = r;
@@ -1463,6 +1538,20 @@ static int refresh_weights(awr_plan& P, void* stream) {
                 jobs.push_back(j);
             }
         }
+        for (auto* d : P.dual_layers) {       // [W3 row | Wskip row] side by side in one K-contiguous buffer (FP32 mode only: no split image)
+            const int cin1 = d->c3->spec.cin_pad, cin2 = d->sk->spec.cin_pad;
+            const ConvLayer* src[2] = {d->c3, d->sk};
+            const int colsv[2] = {cin1, cin2}, offs[2] = {0, cin1};
+            for (int k = 0; k < 2; ++k) {
+                awr_pack_job j;
+                memset(&j, 0, sizeof j);
+                j.src = src[k]->w; j.dst = d->p.p + offs[k]; j.split = nullptr;
+                j.d0 = src[k]->spec.cout; j.d1 = src[k]->spec.cin; j.T = 1; j.transpose = 0; j.rows = d->p.rows; j.ld = d->p.ld; j.cols = colsv[k];
+                j.first = total;
+                total += d->p.rows;
+                jobs.push_back(j);
+            }
+        }
         if (!jobs.empty()) NET_CHECK(upload_table(P, jobs.data(), jobs.size() * sizeof(awr_pack_job), &P.pack_tab[ws]));
         P.pack_njobs[ws] = (int)jobs.size();
         P.pack_rows[ws] = total;
@@ -1484,6 +1573,7 @@ static int refresh_weights(awr_plan& P, void* stream) {
         HIP_TRY(hipMemcpyAsync(l->bias_cat, l->b1, (size_t)3 * J * 4, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(l->bias_cat + 3 * J, l->b2, (size_t)J * 4, hipMemcpyDeviceToDevice, st));
     }
+    for (auto* d : P.dual_layers) NET_CHECK(awr_add(d->c3->bias, d->sk->bias, d->bias_sum, d->c3->spec.cout, stream));
     for (auto& op : P.pack_ops) NET_CHECK(op.fn(stream));
     return AWR_OK;
 }

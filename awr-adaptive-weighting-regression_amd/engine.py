@@ -142,8 +142,11 @@ class Plan:
             return
 
         def trampoline(user, lo, hi, stream):
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=self.dev)):
+            if (stream or 0) == L.stream():          # the stream the plan is being replayed on: torch is already there
                 fn(lo, hi)
+            else:                                     # the plan's comm stream
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.dev)):
+                    fn(lo, hi)
         self._cb = L.BUCKET_CB(trampoline)          # keep the ctypes thunk alive as long as the plan may call it
         L.call("awr_plan_set_bucket_callback", self.h, C.cast(self._cb, C.c_void_p), None)
 

@@ -134,6 +134,8 @@ typedef struct awr_pack_job {
     void* split;          /* optional: split image of dst (awr_split_weight layout), written in the same pass */
     int d0, d1, T, transpose, rows, ld;
     int64_t first;
+    int cols;             /* 0 = ld.  < ld: only columns [0, cols) of each ld-float line are written (two jobs fill one buffer side by side) */
+    int reserved;
 } awr_pack_job;
 typedef struct awr_unpack_job {
     const float* packed;
@@ -190,6 +192,10 @@ typedef struct awr_conv_args {
     int stat_slots;         /* slot copies in `stats` (0 = AWR_STAT_SLOTS); workgroup i adds into copy (stat_slot_base + i) % stat_slots.
                                ceil(M/64)*ceil(N/64)*nphase copies (the 64x64 tile's workgroup count) = one per workgroup */
     int stat_slot_base;
+    const float* in2;       /* optional second input (B,Hin,Win,Cin-Cin1) of a single-tap launch: K = [Cin1 channels of `in` | the channels of
+                               `in2`], P rows [n][Cin] hold the two weight rows side by side; in_scale / in_shift / relu_in apply to `in` only.
+                               out = W_a.in + W_x.in2: the hourglass residual's conv3 + skip_layer in one launch (FP32-MFMA mode only) */
+    int Cin1;
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
