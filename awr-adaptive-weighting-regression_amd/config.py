@@ -21,7 +21,7 @@ _MODEL = dict(net="hourglass_1",      # or 'resnet_18'
               downsample=2,           # 1, 2 or 4: feature size = img_size / downsample
               kernel_size=0.4)        # 0.4 for hourglass, 1 for resnet
 _OPTIM = dict(loss_type="MyL1Loss", dense_weight=1.0, coord_weight=0, lr=1e-3, optimizer="adam", scheduler="step", weight_decay=0)
-_MI355X = dict(use_hipgraph=True,     # replay each step as one hipGraph
+_MI355X = dict(use_hipgraph=False,    # True: replay each step as one hipGraph (measured slower than eager two-stream issue at every batch size)
                world_size=1,          # data-parallel ranks (one process per GPU, RCCL)
                gemm_products=1)       # 1 = FP32 MFMA, 6 = split-operand mode
 

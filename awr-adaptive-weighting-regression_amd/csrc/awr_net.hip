@@ -944,6 +944,12 @@ struct Builder {
         // safe to run beside the main chain when dY is written once before this node and nobody touches it again.  With a fused
         // residual, d(res) ALIASES dY and later nodes accumulate into it in place -> stays on the main stream.
         wop.side_ok = (res == nullptr);
+        // 128 -> 128 3x3 layers on >= 64x64 maps (the Hourglass residuals at full resolution): the one-wave-per-tap-row kernel stages
+        // D and the halo'd G patch once for all nine taps (measured: 124 vs 114 TF in isolation, Hourglass-1 step 26.44 -> 25.79 ms; writing relu(bn2(.)) out for them on top: 25.87); on
+        // every other shape the workgroup-per-tap kernel is equal or faster (profiles/r02_microbench_wgrad_algos.txt)
+        if (!P.det && awr_get_gemm_products() == 1 && spec.k == 3 && spec.stride == 1 && !spec.deconv && spec.cin == 128 && spec.cout == 128 &&
+            H * W >= 4096 && (int64_t)B * H * W >= (1 << 17))
+            wa->algo = 2;
         P.gemms.push_back({nullptr, wa, wname});
         // scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
         auto add_job = [&](const float* packed, float* grad, int d0, int d1, int T_, int ld_, int slots, int stride, int64_t numel) {
@@ -1723,6 +1729,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
     auto launch = [&](GemmRef& g) { return g.ca ? awr_conv_gemm(g.ca, stream) : awr_conv_wgrad(g.wa, stream); };
     int rc = AWR_OK;
     for (auto& g : P.gemms) {
+        if (g.wa && g.wa->algo == 2) continue;      // the wave-per-tap kernel has one geometry
         struct Cand { int tm, tn, tb; };
         std::vector<Cand> cands;
         if (g.ca) {

@@ -62,7 +62,7 @@ class GradSync:
 
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
-                 optimizer="adam", momentum=0.9, process_group=None, use_graph=True, n_buckets=4, autotune=True, wgrad_streams=2,
+                 optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
                  _share=None):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
@@ -282,7 +282,7 @@ TrainEngine.load_optimizer_state_dict = lambda self, sd: _load_opt_into(self, sd
 class InferEngine:
     """test.py:67-86 without the per-sample host loop: img -> dense map -> joints, eval-mode BN."""
 
-    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=True, autotune=True):
+    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=False, autotune=True):
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False)
@@ -429,7 +429,7 @@ class Trainer:
             set_gemm_products(config.gemm_products)
         self.engine = TrainEngine(self.net, config.batch_size, config.img_size, config.kernel_size, config.coord_weight, config.dense_weight,
                                   config.lr, config.weight_decay, config.optimizer, process_group=process_group,
-                                  use_graph=getattr(config, "use_hipgraph", True))
+                                  use_graph=getattr(config, "use_hipgraph", False))
         if config.load_model and os.path.exists(config.load_model):
             self._msg("loading model from {}".format(config.load_model))
             pth = torch.load(config.load_model, map_location="cpu", weights_only=False)     # trusted project artefact (best_records may hold numpy scalars)
