@@ -104,14 +104,15 @@ _SIGS = {
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
     "awr_get_gemm_products": ([], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
-    "awr_stem_stats": ([_P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_stem_stats": ([_P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_stem_conv": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
     "awr_stem_slots": ([_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "awr_set_deterministic": ([_I], C.c_int),
     "awr_get_deterministic": ([], C.c_int),
     "awr_conv_wgrad_splits": ([C.POINTER(WgradArgs), C.POINTER(C.c_int)], C.c_int),
     "awr_stem_pool": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
-    "awr_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
-    "awr_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
+    "awr_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "awr_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "awr_bn_bwd_finalize": ([_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
     "awr_bn_finalize": ([_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P], C.c_int),
     "awr_bn_fold_eval": ([_I, _P, _P, _P, _P, _F, _P, _P, _P], C.c_int),

@@ -792,14 +792,6 @@ struct Builder {
     }
 
     // ---- ops ----
-    Tn* im2col5(float* img, int H, int W) {     // stem im2col of the (B,1,H,W) depth image; no gradient flows to the image
-        Tn* cols = new_t(P.B, H, W, 32, false, "stem_cols");
-        const int B = P.B;
-        float* out = cols->buf;
-        f("awr_stem_im2col", [=](void* s) { return awr_stem_im2col(img, B, H, W, out, s); });
-        return cols;
-    }
-
     // y = conv(x) [+bias] [*s+t] [+res] [relu]
     Tn* conv(Tn* x, ConvLayer* layer, ConvOpt o = ConvOpt()) {
         use_layer(layer);
@@ -1206,19 +1198,21 @@ struct Builder {
         }
     }
 
-    // ResNet stem (resnet_deconv.py:31-36, :118-121): conv 5x5 (1 -> 64) -> BatchNorm -> ReLU -> MaxPool(3,2,1) as the fused
-    // kernels of awr_stem.hip -- the full-resolution map is never written, forward or backward
-    Tn* stem_pool(float* img, ConvLayer* conv, BNLayer* bn, int H, int W) {
+    // Stems as the fused kernels of awr_stem.hip -- the un-normalised full-resolution conv output is never written, forward or
+    // backward.  pool: ResNet (resnet_deconv.py:31-36, :118-121): conv 5x5 (1 -> 64, no bias) -> BatchNorm -> ReLU -> MaxPool(3,2,1),
+    // the result is the pooled map.  !pool: hourglass (hourglass.py:112): conv 5x5 (bias) -> BatchNorm -> ReLU at full resolution.
+    Tn* stem(float* img, ConvLayer* conv, BNLayer* bn, int H, int W, bool pool) {
         const int B = P.B;
-        Tn* y = new_t(B, H / 2, W / 2, 64, true, conv->name + ".pool");
-        const float* w = conv->w;
+        Tn* y = pool ? new_t(B, H / 2, W / 2, 64, true, conv->name + ".pool") : new_t(B, H, W, 64, true, conv->name + ".act");
+        const float *w = conv->w, *bias = conv->bias;
         const std::string tag = ":" + conv->name;
         const int64_t npix = (int64_t)B * H * W;
         float* yb = y->buf;
         if (!P.training) {
             auto ss = fold_bn(bn);
             const float *sc = ss.first, *sh = ss.second;
-            Op& o = f("awr_stem_pool" + tag, [=](void* s) { return awr_stem_pool(img, w, sc, sh, B, H, W, yb, nullptr, s); });
+            Op& o = pool ? f("awr_stem_pool" + tag, [=](void* s) { return awr_stem_pool(img, w, sc, sh, B, H, W, yb, nullptr, s); })
+                         : f("awr_stem_conv" + tag, [=](void* s) { return awr_stem_conv(img, w, bias, sc, sh, 1, B, H, W, yb, s); });
             o.gemm = true;
             o.macs = (double)npix * 64 * 25;
             return y;
@@ -1227,18 +1221,19 @@ struct Builder {
         if (P.det && awr_stem_slots(B, H, W, &ns_stats, &ns_dw)) err = AWR_ERR_ARG;
         StatBuf stats = stat_buf(ns_stats, 64);
         float* coef4 = alloc<float>(4 * 64);
-        uint8_t* arg = alloc<uint8_t>((int64_t)B * (H / 2) * (W / 2) * 64);
+        uint8_t* arg = pool ? alloc<uint8_t>((int64_t)B * (H / 2) * (W / 2) * 64) : nullptr;
         const float mom = bn_momentum();
         {
             double* sp = stats.p;
-            Op& o = f("awr_stem_stats" + tag, [=](void* s) { return awr_stem_stats(img, w, B, H, W, sp, ns_stats, s); });
+            Op& o = f("awr_stem_stats" + tag, [=](void* s) { return awr_stem_stats(img, w, bias, B, H, W, sp, ns_stats, s); });
             o.gemm = true;
             const float *g = bn->gamma, *bt = bn->beta;
             float *rm = bn->rmean, *rv = bn->rvar;
             f("awr_bn_finalize", [=](void* s) {
                 return awr_bn_finalize(sp, 64, npix, g, bt, rm, rv, mom, BN_EPS, coef4, coef4 + 64, coef4 + 128, coef4 + 192, ns_stats, s);
             });
-            Op& p = f("awr_stem_pool" + tag, [=](void* s) { return awr_stem_pool(img, w, coef4, coef4 + 64, B, H, W, yb, arg, s); });
+            Op& p = pool ? f("awr_stem_pool" + tag, [=](void* s) { return awr_stem_pool(img, w, coef4, coef4 + 64, B, H, W, yb, arg, s); })
+                         : f("awr_stem_conv" + tag, [=](void* s) { return awr_stem_conv(img, w, bias, coef4, coef4 + 64, 1, B, H, W, yb, s); });
             p.gemm = true;
             p.macs = (double)npix * 64 * 25;     // algorithmic work: the conv once forward, its weight gradient once backward
         }
@@ -1249,21 +1244,23 @@ struct Builder {
             }
             StatBuf sums = stat_buf(ns_stats, 64);
             float* coef = alloc<float>(3 * 64);
-            float* slots = alloc<float>((int64_t)ns_dw * 64 * 25, true);
+            float* slots = alloc<float>((int64_t)ns_dw * 64 * 26, true);
             float* dp = y->grad;
             double* sp = sums.p;
-            Op& r = b("awr_stem_bwd_reduce" + tag, [=](void* s) { return awr_stem_bwd_reduce(img, w, coef4, dp, arg, B, H, W, sp, ns_stats, s); });
+            Op& r = b("awr_stem_bwd_reduce" + tag, [=](void* s) { return awr_stem_bwd_reduce(img, w, bias, coef4, dp, arg, B, H, W, sp, ns_stats, s); });
             r.gemm = true;
             const float* gam = bn->gamma;
             float *gg = bn->ggamma, *gb = bn->gbeta;
             b("awr_bn_bwd_finalize", [=](void* s) { return awr_bn_bwd_finalize(sp, 64, npix, gam, coef4 + 192, coef, gg, gb, 0, ns_stats, s); });
             note_grad(bn->ggamma, 64);
             note_grad(bn->gbeta, 64);
-            float* gw = conv->gw;
-            Op& wg = b("awr_stem_bwd_wgrad" + tag, [=](void* s) { return awr_stem_bwd_wgrad(img, w, coef4, coef, dp, arg, B, H, W, slots, gw, ns_dw, s); });
+            float *gw = conv->gw, *gbias = bias ? conv->gbias : nullptr;
+            Op& wg = b("awr_stem_bwd_wgrad" + tag,
+                       [=](void* s) { return awr_stem_bwd_wgrad(img, w, bias, coef4, coef, dp, arg, B, H, W, slots, gw, gbias, ns_dw, s); });
             wg.gemm = true;
             wg.macs = (double)npix * 64 * 25;
             note_grad(conv->gw, 64 * 25);
+            if (gbias) note_grad(gbias, 64);
             return err;
         });
         return y;
@@ -1413,7 +1410,7 @@ struct NetBuilder {
     }
 
     void resnet(float* img, int H, float* out, float* gout) {
-        Tn* c = b.stem_pool(img, C("pre.0"), BN("pre.1"), H, H);      // conv 5x5 -> BN -> ReLU -> MaxPool(3,2,1), one fused kernel family
+        Tn* c = b.stem(img, C("pre.0"), BN("pre.1"), H, H, true);      // conv 5x5 -> BN -> ReLU -> MaxPool(3,2,1), one fused kernel family
         for (int li = 1; li <= 4; ++li)
             for (int bi = 0; bi < 2; ++bi) {
                 const std::string p = fmt("layer%d.%d", li, bi);
@@ -1493,7 +1490,7 @@ struct NetBuilder {
     }
 
     void hourglass(float* img, int H, float* const* outs, float* const* gouts) {
-        Tn* c = cbr(b.im2col5(img, H, H), "pre.0", "pre.0.bn", true);
+        Tn* c = b.stem(img, C("pre.0"), BN("pre.0.bn"), H, H, false);      // conv 5x5 + bias -> BN -> ReLU at full resolution
         c = residual(c, "pre.1");
         c = b.maxpool(c, 2, 2, 0);
         c = residual(c, "pre.3");

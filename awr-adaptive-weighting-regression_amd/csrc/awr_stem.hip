@@ -12,6 +12,11 @@
 //   backward  stem_bwd_kernel<0>   conv again -> ReLU mask, pool-backward gather -> sum g, sum g*xhat (BN backward sums)
 //             stem_bwd_kernel<1>   conv again -> dY = BN backward -> dW[64][25] += dY^T * im2col(image)
 //
+// The Hourglass stem (model/hourglass.py:112: conv 5x5 WITH bias -> BatchNorm -> ReLU, no pooling) uses the same kernels in their
+// "dense" form: stem_conv_kernel writes relu(bn(conv + bias)) at full resolution (the only tensor the next layer needs), the
+// backward kernels take the dense gradient of that tensor instead of scattering pooled gradients, and recompute the conv
+// output for the ReLU mask, xhat and the weight gradient (the un-normalised conv output is never stored either).
+//
 // The conv runs on the FP32 matrix pipe (v_mfma_f32_32x32x2_f32, exact f32): a workgroup stages its image patch in LDS,
 // the A operand of K-step kk is ONE ds_read_b32 per lane (pixel row of the lane + the tap offset of k = 2 kk + lane/32),
 // the B operand (the 64x25 filter bank, 13 K-steps of two taps) lives in 13 registers for the whole kernel.  In the
@@ -24,6 +29,7 @@ namespace awr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ST_T = 25;         // taps
+constexpr int ST_TB = 26;        // columns of the weight-gradient result: 25 taps + the bias gradient (a tap whose image value is 1)
 constexpr int ST_KS = 13;        // MFMA K-steps (2 taps each; tap 25 carries a zero weight)
 constexpr int ST_PW = 48;        // patch pitch of the 16x16-pixel kernels: the two 16-pixel runs of a half-wave sit 16 banks apart
 constexpr int ST_PH = 20;        // patch rows / used columns (16 + 2 * 2)
@@ -48,10 +54,10 @@ __device__ __forceinline__ void stem_lane_init(stem_lane& s, const float* __rest
 }
 
 // y[32 pixels][32 channels] of one tile: pixel row of this lane starts at patch[base]
-__device__ __forceinline__ f32x16 stem_conv_tile(const float* patch, int base, const stem_lane& s) {
+__device__ __forceinline__ f32x16 stem_conv_tile(const float* patch, int base, const stem_lane& s, float bias = 0.f) {
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = bias;
 #pragma unroll
     for (int kk = 0; kk < ST_KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(patch[base + s.koff[kk]], s.w[kk], acc, 0, 0, 0);
     return acc;
@@ -70,8 +76,8 @@ __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __r
 // BatchNorm batch statistics of the (never stored) conv output
 // ------------------------------------------------------------------------------------------
 // grid (tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32 channels
-__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, int H, int W, int nslots,
-                                                         double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int H, int W, int nslots, double* __restrict__ stats) {
     __shared__ float patch[ST_PH * ST_PW];
     __shared__ float red[4][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
@@ -80,12 +86,13 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     stem_load_patch16(patch, img, b, ty * 16, tx * 16, H, W);
     stem_lane sl;
     stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
+    const float bs = bias ? bias[ch0 + m] : 0.f;
     __syncthreads();
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int q = 32 * (wave * 2 + ti) + m;
-        const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl);
+        const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s1 += acc[r];
@@ -104,6 +111,36 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
         const double v = (double)red[0][st][c] + (double)red[1][st][c] + (double)red[2][st][c] + (double)red[3][st][c];
         const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
         atomicAdd(stats + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv (+ bias) -> affine (BatchNorm) -> [ReLU]: writes the full-resolution NHWC map (Hourglass stem)
+// ------------------------------------------------------------------------------------------
+// grid (tiles of 16x16 pixels, channel half, image).  A store instruction covers two pixels x 32 channels = two full 128-byte lines.
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int relu, int H, int W,
+                                                        float* __restrict__ out) {
+    __shared__ float patch[ST_PH * ST_PW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int tiles_x = W >> 4, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z, ch0 = blockIdx.y * 32;
+    stem_load_patch16(patch, img, b, ty * 16, tx * 16, H, W);
+    stem_lane sl;
+    stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
+    const float bs = bias ? bias[ch0 + m] : 0.f, sc = scale[ch0 + m], sh = shift[ch0 + m];
+    const float lo = relu ? 0.f : -INFINITY;
+    __syncthreads();
+    float* const o0 = out + (((size_t)b * H + ty * 16) * W + tx * 16) * 64 + ch0 + m;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int i = wave * 2 + ti, q = 32 * i + m;
+        const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = 32 * i + mfma_row(r, h);
+            o0[((size_t)(p >> 4) * W + (p & 15)) * 64] = fmaxf(acc[r] * sc + sh, lo);
+        }
     }
 }
 
@@ -175,14 +212,16 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
 // instead of testing, for each of the 256 pixels, the up to four windows that contain it.  Windows of equal row / column
 // parity never share a pixel (3 wide, 4 apart), so the four parity classes are added one after the other without atomics:
 // the sum order is fixed (deterministic).
+// DENSE (Hourglass stem, no pooling): dpool is the gradient of the full-resolution activation, (B,H,W,64) NHWC; each lane loads the
+// gradient of its accumulator elements directly (two pixels x 32 channels = two 128-byte lines per load instruction).
 // grid (groups of tiles_per_wg tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels
-template <int WGRAD>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ coef4,
-                                                       const float* __restrict__ bcoef, const float* __restrict__ dpool,
-                                                       const uint8_t* __restrict__ argmax, int H, int W, int tiles_per_wg, int nslots,
-                                                       double* __restrict__ sums, float* __restrict__ dw) {
+template <int WGRAD, bool DENSE>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ coef4, const float* __restrict__ bcoef,
+                                                       const float* __restrict__ dpool, const uint8_t* __restrict__ argmax, int H, int W,
+                                                       int tiles_per_wg, int nslots, double* __restrict__ sums, float* __restrict__ dw) {
     __shared__ float patch[ST_PH * ST_PW];
-    __shared__ __attribute__((aligned(16))) float gt[256 * 32];       // pooled gradient routed to the tile's pixels [pixel][channel]
+    __shared__ __attribute__((aligned(16))) float gt[DENSE ? 4 : 256 * 32];       // pooled gradient routed to the tile's pixels [pixel][channel]
     __shared__ float red[WGRAD ? 4 * 1024 : 4 * 2 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -191,10 +230,12 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     stem_lane sl;
     stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
     const float sc = coef4[ch0 + m], sh = coef4[64 + ch0 + m], mu = coef4[128 + ch0 + m], is = coef4[192 + ch0 + m];
+    const float bs = bias ? bias[ch0 + m] : 0.f;
     float k1 = 0.f, k2 = 0.f, gi = 0.f;
     if (WGRAD) { k1 = bcoef[ch0 + m]; k2 = bcoef[64 + ch0 + m]; gi = bcoef[128 + ch0 + m]; }
     const int tm = m < ST_T ? m : 0;
-    const int toff = (tm / 5) * ST_PW + (tm % 5);          // second GEMM: this lane's column = tap m
+    const int toff = (tm / 5) * ST_PW + (tm % 5);          // second GEMM: this lane's column = tap m; column 25 = the bias gradient
+    const float bcol = m == ST_T ? 1.f : 0.f;              // (its "image" is 1 everywhere), columns 26..31 are zero
     // scatter items of this thread, one per parity class (cy, cx): window (cy + 2 a, cx + 2 b), channels 4 c4 .. 4 c4 + 3
     const int c4 = tid & 7, wi = tid >> 3;
     float s1 = 0.f, s2 = 0.f;
@@ -206,50 +247,65 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const int tile = blockIdx.x * tiles_per_wg + tt;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * 16, x0 = tx * 16;
-        float4 itd[4];
-        uchar4 ita[4];
-        int itp[4];                     // window (wy << 4 | wx) of the item, -1 = none
+        if constexpr (!DENSE) {
+            float4 itd[4];
+            uchar4 ita[4];
+            int itp[4];                     // window (wy << 4 | wx) of the item, -1 = none
 #pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            const int cy = cls >> 1, cx = cls & 1, nx = cx ? 4 : 5, ny = cy ? 4 : 5;
-            const int wy = cy + 2 * (wi / nx), wx = cx + 2 * (wi % nx);
-            const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-            itp[cls] = -1;
-            if (wi < nx * ny && oy < Ho && ox < Wo) {
-                const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * 64 + ch0 + 4 * c4;
-                itd[cls] = ld4(dpool + o);
-                ita[cls] = *reinterpret_cast<const uchar4*>(argmax + o);
-                itp[cls] = (wy << 4) | wx;
-            }
-        }
-        if (tt) __syncthreads();           // the previous tile's readers are done with the LDS arrays
-        stem_load_patch16(patch, img, b, y0, x0, H, W);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st4(&gt[(tid + 256 * i) * 4], make_float4(0, 0, 0, 0));
-        __syncthreads();
-#pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            if (itp[cls] >= 0) {
-                const int ly0 = 2 * (itp[cls] >> 4) - 1, lx0 = 2 * (itp[cls] & 15) - 1;       // the window's top-left pixel (may be -1)
-                const float dv[4] = {itd[cls].x, itd[cls].y, itd[cls].z, itd[cls].w};
-                const int av[4] = {ita[cls].x, ita[cls].y, ita[cls].z, ita[cls].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ky = av[j] >= 6 ? 2 : (av[j] >= 3 ? 1 : 0), kx = av[j] - 3 * ky;
-                    const int ly = ly0 + ky, lx = lx0 + kx;
-                    if ((unsigned)ly < 16u && (unsigned)lx < 16u) gt[(ly * 16 + lx) * 32 + 4 * c4 + j] += dv[j];
+            for (int cls = 0; cls < 4; ++cls) {
+                const int cy = cls >> 1, cx = cls & 1, nx = cx ? 4 : 5, ny = cy ? 4 : 5;
+                const int wy = cy + 2 * (wi / nx), wx = cx + 2 * (wi % nx);
+                const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                itp[cls] = -1;
+                if (wi < nx * ny && oy < Ho && ox < Wo) {
+                    const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * 64 + ch0 + 4 * c4;
+                    itd[cls] = ld4(dpool + o);
+                    ita[cls] = *reinterpret_cast<const uchar4*>(argmax + o);
+                    itp[cls] = (wy << 4) | wx;
                 }
             }
+            if (tt) __syncthreads();           // the previous tile's readers are done with the LDS arrays
+            stem_load_patch16(patch, img, b, y0, x0, H, W);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st4(&gt[(tid + 256 * i) * 4], make_float4(0, 0, 0, 0));
+            __syncthreads();
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                if (itp[cls] >= 0) {
+                    const int ly0 = 2 * (itp[cls] >> 4) - 1, lx0 = 2 * (itp[cls] & 15) - 1;       // the window's top-left pixel (may be -1)
+                    const float dv[4] = {itd[cls].x, itd[cls].y, itd[cls].z, itd[cls].w};
+                    const int av[4] = {ita[cls].x, ita[cls].y, ita[cls].z, ita[cls].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ky = av[j] >= 6 ? 2 : (av[j] >= 3 ? 1 : 0), kx = av[j] - 3 * ky;
+                        const int ly = ly0 + ky, lx = lx0 + kx;
+                        if ((unsigned)ly < 16u && (unsigned)lx < 16u) gt[(ly * 16 + lx) * 32 + 4 * c4 + j] += dv[j];
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            if (tt) __syncthreads();
+            stem_load_patch16(patch, img, b, y0, x0, H, W);
             __syncthreads();
         }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int i = wave * 2 + ti;
             const int q = 32 * i + m;
-            f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl);
+            float gv[16];
+            if constexpr (DENSE) {      // requested before the conv's MFMAs: their latency hides under them
+                const float* g0 = dpool + (((size_t)b * H + y0) * W + x0) * 64 + ch0 + m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * i + mfma_row(r, h);
+                    gv[r] = g0[((size_t)(p >> 4) * W + (p & 15)) * 64];
+                }
+            }
+            f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float g = gt[(32 * i + mfma_row(r, h)) * 32 + m];
+                float g = DENSE ? gv[r] : gt[(32 * i + mfma_row(r, h)) * 32 + m];
                 const float y = acc[r];
                 g = y * sc + sh > 0.f ? g : 0.f;
                 const float xh = (y - mu) * is;
@@ -266,7 +322,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pb = (2 * i + (r >> 3)) * ST_PW + 8 * ((r >> 2) & 1) + (r & 3) + 4 * h;
-                    wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], patch[pb + toff], wacc, 0, 0, 0);
+                    wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], m < ST_T ? patch[pb + toff] : bcol, wacc, 0, 0, 0);
                 }
             }
         }
@@ -278,9 +334,9 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
         for (int e = tid; e < 1024; e += 256) {
             const int r = e >> 6, l = e & 63, t = l & 31;
-            if (t < ST_T) {
+            if (t < ST_TB) {
                 const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
-                atomicAdd(dw + ((size_t)slot * 64 + ch0 + mfma_row(r, l >> 5)) * ST_T + t, v);
+                atomicAdd(dw + ((size_t)slot * 64 + ch0 + mfma_row(r, l >> 5)) * ST_TB + t, v);
             }
         }
     } else {
@@ -301,16 +357,18 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     }
 }
 
-// grad[c][tap] = sum over the slot copies; re-arms the accumulator for the next step
-__global__ void stem_dw_finalize_kernel(float* __restrict__ dw_slots, int nslots, float* __restrict__ grad) {
+// grad[c][tap] (and gbias[c] = column 25) = sum over the slot copies; re-arms the accumulator for the next step
+__global__ void stem_dw_finalize_kernel(float* __restrict__ dw_slots, int nslots, float* __restrict__ grad, float* __restrict__ gbias) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 64 * ST_T) return;
+    if (i >= 64 * ST_TB) return;
     float s = 0.f;
     for (int k = 0; k < nslots; ++k) {
-        s += dw_slots[k * 64 * ST_T + i];
-        dw_slots[k * 64 * ST_T + i] = 0.f;
+        s += dw_slots[k * 64 * ST_TB + i];
+        dw_slots[k * 64 * ST_TB + i] = 0.f;
     }
-    grad[i] = s;
+    const int c = i / ST_TB, t = i - c * ST_TB;
+    if (t < ST_T) grad[c * ST_T + t] = s;
+    else if (gbias) gbias[c] = s;
 }
 
 }  // namespace awr
@@ -336,12 +394,20 @@ int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots) {
     return AWR_OK;
 }
 
-int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, int nslots, void* stream) {
+int awr_stem_stats(const float* img, const float* w, const float* bias, int B, int H, int W, double* stats, int nslots, void* stream) {
     AWR_REQUIRE(img && w && stats && nslots >= 0, "stem_stats: null pointer");
     AWR_STEM_GEOMETRY("stem_stats");
-    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, H, W, nslots ? nslots : AWR_STAT_SLOTS,
-                       stats);
+    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, bias, H, W,
+                       nslots ? nslots : AWR_STAT_SLOTS, stats);
     return check_launch("stem_stats_kernel");
+}
+
+int awr_stem_conv(const float* img, const float* w, const float* bias, const float* scale, const float* shift, int relu, int B, int H, int W,
+                  float* out, void* stream) {
+    AWR_REQUIRE(img && w && scale && shift && out, "stem_conv: null pointer");
+    AWR_STEM_GEOMETRY("stem_conv");
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, bias, scale, shift, relu, H, W, out);
+    return check_launch("stem_conv_kernel");
 }
 
 int awr_stem_pool(const float* img, const float* w, const float* scale, const float* shift, int B, int H, int W, float* pooled,
@@ -353,27 +419,37 @@ int awr_stem_pool(const float* img, const float* w, const float* scale, const fl
     return check_launch("stem_pool_kernel");
 }
 
-int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool, const uint8_t* argmax, int B, int H, int W,
-                        double* sums, int nslots, void* stream) {
-    AWR_REQUIRE(img && w && coef4 && dpool && argmax && sums && nslots >= 0, "stem_bwd_reduce: null pointer");
+int awr_stem_bwd_reduce(const float* img, const float* w, const float* bias, const float* coef4, const float* dg, const uint8_t* argmax, int B,
+                        int H, int W, double* sums, int nslots, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && dg && sums && nslots >= 0, "stem_bwd_reduce: null pointer");
     AWR_STEM_GEOMETRY("stem_bwd_reduce");
-    hipLaunchKernelGGL(stem_bwd_kernel<0>, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, (const float*)nullptr,
-                       dpool, argmax, H, W, 1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
+    const dim3 grid((H / 16) * (W / 16), 2, B);
+    if (argmax)
+        hipLaunchKernelGGL((stem_bwd_kernel<0, false>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, (const float*)nullptr, dg, argmax, H, W,
+                           1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((stem_bwd_kernel<0, true>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, (const float*)nullptr, dg, argmax, H, W,
+                           1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
     return check_launch("stem_bwd_kernel<0>");
 }
 
-int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef, const float* dpool, const uint8_t* argmax,
-                       int B, int H, int W, float* dw_slots, float* grad, int nslots, void* stream) {
-    AWR_REQUIRE(img && w && coef4 && bwd_coef && dpool && argmax && dw_slots && grad && nslots >= 0, "stem_bwd_wgrad: null pointer");
+int awr_stem_bwd_wgrad(const float* img, const float* w, const float* bias, const float* coef4, const float* bwd_coef, const float* dg,
+                       const uint8_t* argmax, int B, int H, int W, float* dw_slots, float* grad, float* gbias, int nslots, void* stream) {
+    AWR_REQUIRE(img && w && coef4 && bwd_coef && dg && dw_slots && grad && nslots >= 0, "stem_bwd_wgrad: null pointer");
     if (nslots == 0) nslots = AWR_STAT_SLOTS;
     AWR_STEM_GEOMETRY("stem_bwd_wgrad");
     const int tiles = (H / 16) * (W / 16);
-    int tpw = 8;                                   // tiles per workgroup: fewer, longer workgroups = fewer atomics on the 64x25 result
+    int tpw = 8;                                   // tiles per workgroup: fewer, longer workgroups = fewer atomics on the 64x26 result
     while (tiles % tpw) tpw >>= 1;
-    hipLaunchKernelGGL(stem_bwd_kernel<1>, dim3(tiles / tpw, 2, B), dim3(256), 0, as_stream(stream), img, w, coef4, bwd_coef, dpool, argmax, H, W, tpw,
-                       nslots, (double*)nullptr, dw_slots);
+    const dim3 grid(tiles / tpw, 2, B);
+    if (argmax)
+        hipLaunchKernelGGL((stem_bwd_kernel<1, false>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, bwd_coef, dg, argmax, H, W, tpw, nslots,
+                           (double*)nullptr, dw_slots);
+    else
+        hipLaunchKernelGGL((stem_bwd_kernel<1, true>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, bwd_coef, dg, argmax, H, W, tpw, nslots,
+                           (double*)nullptr, dw_slots);
     if (int e = check_launch("stem_bwd_kernel<1>")) return e;
-    hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3((64 * ST_T + 255) / 256), dim3(256), 0, as_stream(stream), dw_slots, nslots, grad);
+    hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3((64 * ST_TB + 255) / 256), dim3(256), 0, as_stream(stream), dw_slots, nslots, grad, gbias);
     return check_launch("stem_dw_finalize_kernel");
 }
 

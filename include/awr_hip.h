@@ -246,29 +246,35 @@ int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
 /* number of K-chunk copies the launch described by `a` writes (split_stride mode) */
 int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit);
 
-/* Fused ResNet18-deconv stem: conv 5x5 pad 2 (1 -> 64 channels, no bias) -> BatchNorm -> ReLU -> MaxPool(3,2,1)
- * (model/resnet_deconv.py:31-36, :118-121, their autograd and `pre.1`'s running-stat update).  The full-resolution
- * conv output is NEVER written: every kernel recomputes it from the image on the FP32 matrix pipe.  img (B,1,H,W),
- * H and W multiples of 16; w = `pre.0.weight` in checkpoint layout [64][25]; pooled / argmax NHWC (B,H/2,W/2,64).
- *   awr_stem_stats       stats[AWR_STAT_SLOTS][2][64] += per-channel sum / sum of squares of the conv output
+/* Fused stems: conv 5x5 pad 2 of the one-channel depth image (1 -> 64 channels) -> BatchNorm -> ReLU [-> MaxPool(3,2,1)], their
+ * autograd and the BatchNorm's running-stat update.  ResNet18-deconv (model/resnet_deconv.py:31-36, :118-121): no conv bias, pooled;
+ * stacked hourglass (model/hourglass.py:112, Conv(1, 64, 5, 1, bn=True, relu=True)): conv bias, no pooling.  The un-normalised
+ * full-resolution conv output is NEVER written: every kernel recomputes it from the image on the FP32 matrix pipe.  img (B,1,H,W),
+ * H and W multiples of 16; w = the conv weight in checkpoint layout [64][25]; bias [64] or NULL; all maps NHWC.
+ *   awr_stem_stats       stats[nslots][2][64] += per-channel sum / sum of squares of conv + bias
  *                        (feed awr_bn_finalize with count = B*H*W)
- *   awr_stem_pool        pooled = maxpool(relu(conv * scale + shift)); argmax (optional, training) = window code
+ *   awr_stem_pool        pooled (B,H/2,W/2,64) = maxpool(relu(conv * scale + shift)); argmax (optional, training) = window code
  *                        ky*3+kx of the first maximum, the format awr_maxpool_fwd writes
- *   awr_stem_bwd_reduce  sums[AWR_STAT_SLOTS][2][64] += sum g, sum g*xhat with g = relu' * maxpool_backward(dpool);
- *                        coef4 = [scale|shift|mean|invstd][64] of the forward (feed awr_bn_bwd_finalize)
- *   awr_stem_bwd_wgrad   grad[64][25] = sum_pixels dY * image taps, dY = BatchNorm backward of g with
- *                        bwd_coef = [mean g | mean g*xhat | gamma*invstd][64]; dw_slots: AWR_STAT_SLOTS*64*25 floats
- *                        of scratch, zero before the first call (the call re-arms it) */
-int awr_stem_stats(const float* img, const float* w, int B, int H, int W, double* stats, int nslots, void* stream);
+ *   awr_stem_conv        out (B,H,W,64) = [relu]((conv + bias) * scale + shift)
+ *   awr_stem_bwd_reduce  sums[nslots][2][64] += sum g, sum g*xhat with g = relu' * dg; coef4 = [scale|shift|mean|invstd][64] of the
+ *                        forward (feed awr_bn_bwd_finalize).  argmax != NULL: dg is the gradient of the POOLED map, routed through
+ *                        the max-pool backward; argmax == NULL: dg is the dense gradient of awr_stem_conv's output
+ *   awr_stem_bwd_wgrad   grad[64][25] = sum_pixels dY * image taps, gbias[64] (optional) = sum_pixels dY, dY = BatchNorm backward of
+ *                        g with bwd_coef = [mean g | mean g*xhat | gamma*invstd][64]; dw_slots: nslots*64*26 floats of scratch,
+ *                        zero before the first call (the call re-arms it) */
+int awr_stem_stats(const float* img, const float* w, const float* bias, int B, int H, int W, double* stats, int nslots,
+                   void* stream);
 int awr_stem_pool(const float* img, const float* w, const float* scale, const float* shift, int B, int H, int W,
                   float* pooled, uint8_t* argmax, void* stream);
-int awr_stem_bwd_reduce(const float* img, const float* w, const float* coef4, const float* dpool,
+int awr_stem_conv(const float* img, const float* w, const float* bias, const float* scale, const float* shift, int relu,
+                  int B, int H, int W, float* out, void* stream);
+int awr_stem_bwd_reduce(const float* img, const float* w, const float* bias, const float* coef4, const float* dg,
                         const uint8_t* argmax, int B, int H, int W, double* sums, int nslots, void* stream);
-int awr_stem_bwd_wgrad(const float* img, const float* w, const float* coef4, const float* bwd_coef,
-                       const float* dpool, const uint8_t* argmax, int B, int H, int W, float* dw_slots,
-                       float* grad, int nslots, void* stream);
+int awr_stem_bwd_wgrad(const float* img, const float* w, const float* bias, const float* coef4, const float* bwd_coef,
+                       const float* dg, const uint8_t* argmax, int B, int H, int W, float* dw_slots, float* grad,
+                       float* gbias, int nslots, void* stream);
 /* workgroup counts of awr_stem_stats / awr_stem_bwd_reduce (stats_slots) and of awr_stem_bwd_wgrad (wgrad_slots, also the
- * number of 64*25-float copies in dw_slots): that many slot copies = one per workgroup.  nslots = 0 means AWR_STAT_SLOTS. */
+ * number of 64*26-float copies in dw_slots): that many slot copies = one per workgroup.  nslots = 0 means AWR_STAT_SLOTS. */
 int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots);
 
 /* 5x5 stem (Cin=1): im2col of the depth image into (B,H,W,32) rows (25 taps + 7 zeros) so the

@@ -396,7 +396,7 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     s = L.stream()
     imgd, wdv = img.to(dev), w.to(dev).contiguous()
     stats = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
-    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), B, H, W, L.ptr(stats), 0, s)
+    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), None, B, H, W, L.ptr(stats), 0, s)
     n = B * H * W
     st = stats.sum(0).cpu()
     assert rel_err(st[0] / n, mean_ref) < 2e-6 and rel_err(st[1] / n - (st[0] / n) ** 2, var_ref) < 2e-5
@@ -418,17 +418,80 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     # ---- backward ----
     dpool = ops.nhwc(gout).to(dev)
     sums = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
-    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(sums), 0, s)
+    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), None, L.ptr(coef4), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(sums), 0, s)
     coef = torch.zeros(3, 64, device=dev)
     dgam, dbet = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
     L.call("awr_bn_bwd_finalize", L.ptr(sums), 64, n, L.ptr(gam), L.ptr(coef4[3]), L.ptr(coef), L.ptr(dgam), L.ptr(dbet), 0, 0, s)
     assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
-    slots = torch.zeros(16 * 64 * 25, device=dev)
+    slots = torch.zeros(16 * 64 * 26, device=dev)
     gw = torch.empty(64, 1, 5, 5, device=dev)
     for _ in range(2):                                           # second call: the slot accumulator was re-armed by the first
-        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(coef4), L.ptr(coef), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(slots), L.ptr(gw), 0, s)
+        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), None, L.ptr(coef4), L.ptr(coef), L.ptr(dpool), L.ptr(arg), B, H, W, L.ptr(slots), L.ptr(gw), None, 0, s)
         assert rel_err(gw.cpu(), gw_ref) < 5e-5
     assert float(slots.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 48), (2, 128, 128), (1, 16, 16)])
+def test_fused_stem_dense_matches_conv_bias_bn_relu(L, dev, B, H, W):
+    """Hourglass stem (hourglass.py:112): conv 5x5 (1 -> 64, pad 2, WITH bias) -> BatchNorm (batch statistics) -> ReLU at full
+    resolution, and its backward from the dense gradient of that activation (BN parameter gradients, conv weight and bias
+    gradients) by recomputing the conv -- against float64 torch autograd of the three operators."""
+    from awr_amd import ops
+    g = torch.Generator().manual_seed(11 + H)
+    img = (torch.rand(B, 1, H, W, generator=g) * 2 - 1)
+    img[:, :, : H // 3] = 1.0
+    w = torch.randn(64, 1, 5, 5, generator=g) * 0.2
+    bias = torch.randn(64, generator=g) * 0.5
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    wd, bsd = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = TF.conv2d(img.double(), wd, bsd, 1, 2)
+    a_ref = TF.relu(TF.batch_norm(y, None, None, gd, bd, True, 0.1, 1e-5))
+    gout = rnd(*a_ref.shape, seed=4)
+    gw_ref, gg_ref, gb_ref = torch.autograd.grad(a_ref, (wd, gd, bd), gout.double())
+    mean_ref, var_ref = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    s = L.stream()
+    imgd, wdv, bsv = img.to(dev), w.to(dev).contiguous(), bias.to(dev)
+    stats = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
+    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), B, H, W, L.ptr(stats), 0, s)
+    n = B * H * W
+    st = stats.sum(0).cpu()
+    assert rel_err(st[0] / n, mean_ref) < 2e-6 and rel_err(st[1] / n - (st[0] / n) ** 2, var_ref) < 2e-5
+    coef4 = torch.zeros(4, 64, device=dev)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    gam, bet = gamma.to(dev), beta.to(dev)
+    L.call("awr_bn_finalize", L.ptr(stats), 64, n, L.ptr(gam), L.ptr(bet), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, L.ptr(coef4[0]), L.ptr(coef4[1]),
+           L.ptr(coef4[2]), L.ptr(coef4[3]), 0, s)
+    assert rel_err(rm.cpu(), 0.1 * mean_ref) < 2e-6
+    act = torch.empty(B, H, W, 64, device=dev)
+    L.call("awr_stem_conv", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), L.ptr(coef4[0]), L.ptr(coef4[1]), 1, B, H, W, L.ptr(act), s)
+    assert rel_err(ops.nchw(act).cpu(), a_ref.detach()) < 5e-6
+    pre = torch.empty_like(act)                               # relu = 0: the plain normalised map
+    L.call("awr_stem_conv", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), L.ptr(coef4[0]), L.ptr(coef4[1]), 0, B, H, W, L.ptr(pre), s)
+    assert rel_err(ops.nchw(pre).cpu(), TF.batch_norm(y, None, None, gd, bd, True, 0.1, 1e-5).detach()) < 5e-6
+    # ---- backward from the dense gradient ----
+    dg = ops.nhwc(gout).to(dev)
+    sums = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
+    L.call("awr_stem_bwd_reduce", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), L.ptr(coef4), L.ptr(dg), None, B, H, W, L.ptr(sums), 0, s)
+    coef = torch.zeros(3, 64, device=dev)
+    dgam, dbet = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    L.call("awr_bn_bwd_finalize", L.ptr(sums), 64, n, L.ptr(gam), L.ptr(coef4[3]), L.ptr(coef), L.ptr(dgam), L.ptr(dbet), 0, 0, s)
+    assert rel_err(dgam.cpu(), gg_ref) < 2e-5 and rel_err(dbet.cpu(), gb_ref) < 2e-5
+    slots = torch.zeros(16 * 64 * 26, device=dev)
+    gw, gbias = torch.empty(64, 1, 5, 5, device=dev), torch.full((64,), 7.0, device=dev)
+    for _ in range(2):
+        L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), L.ptr(coef4), L.ptr(coef), L.ptr(dg), None, B, H, W, L.ptr(slots), L.ptr(gw),
+               L.ptr(gbias), 0, s)
+        assert rel_err(gw.cpu(), gw_ref) < 5e-5
+        # a bias in front of a BatchNorm has a zero gradient in exact arithmetic: what is left is rounding noise of a sum of n terms
+        assert float(gbias.abs().max()) < 1e-6 * n * float(gout.abs().mean())
+    assert float(slots.abs().max()) == 0.0
+    # the bias column proper: with the identity as "BatchNorm backward" (k1 = k2 = 0, gamma*invstd = 1) it is sum of relu' * g
+    ident = torch.zeros(3, 64, device=dev)
+    ident[2] = 1.0
+    L.call("awr_stem_bwd_wgrad", L.ptr(imgd), L.ptr(wdv), L.ptr(bsv), L.ptr(coef4), L.ptr(ident), L.ptr(dg), None, B, H, W, L.ptr(slots), L.ptr(gw),
+           L.ptr(gbias), 0, s)
+    assert rel_err(gbias.cpu(), (gout.double() * (a_ref.detach() > 0)).sum((0, 2, 3))) < 2e-5
 
 
 @pytest.mark.parametrize("kind,cin,cout,k,stride,B,H", [
