@@ -201,7 +201,8 @@ class Plan:
             if ent and all(n in ent for n in names):
                 for i, n in enumerate(names):
                     (tm, tn, tb), t = ent[n]
-                    L.call("awr_plan_set_gemm", self.h, i, tm, tn, tb, float(t))
+                    if tm and tn:                     # (0, 0): a launch the tuner leaves alone (one-geometry kernels)
+                        L.call("awr_plan_set_gemm", self.h, i, tm, tn, tb, float(t))
                     self.tuned[n] = ((tm, tn, tb), t)
                 return
         L.call("awr_plan_autotune", self.h, int(reps), L.stream())
