@@ -644,6 +644,7 @@ struct awr_plan {
     bool pack_built[2] = {false, false};
     // streams
     std::vector<hipStream_t> side;
+    std::vector<hipStream_t> branch;      // backward branches (an hourglass level's full-resolution skip residual)
     hipStream_t comm = nullptr;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
@@ -780,6 +781,16 @@ struct Builder {
         o.kind = OP_ENDFORK;
         o.sid = P.fork_sid;
         P.fork_results[result] = P.fork_sid;
+    }
+    // Backward branches.  The emitters run in reverse node order, so a marker node pushed AFTER a group of nodes is emitted
+    // BEFORE that group's backward ops.
+    void bwd_marker_node(int kind, int sid) {
+        P.nodes.push_back([=]() {
+            Op& o = b(kind == OP_FORK ? "__fork__" : kind == OP_ENDFORK ? "__endfork__" : "__join__", nullptr);
+            o.kind = kind;
+            o.sid = sid;
+            return err;
+        });
     }
     void join_if(Tn* t) {
         if (!t) return;
@@ -1480,12 +1491,39 @@ struct NetBuilder {
     Tn* hg(Tn* x, const std::string& p, int depth) {
         // the skip branch of a level only meets the low-resolution path again at the up-sampling add: issued on its own side
         // stream, its full-resolution GEMMs fill the chip while the main stream walks the small (<= 16x16) levels
+        const size_t n0 = P.nodes.size();
         b.fork(depth);
         Tn* up1 = residual(x, p + ".up1");
         b.end_fork(up1);
-        Tn* low = residual(b.maxpool(x, 2, 2, 0), p + ".low1");
+        const size_t n1 = P.nodes.size();
+        Tn* pooled = b.maxpool(x, 2, 2, 0);
+        // backward branches for the two outer levels only (64x64 / 32x32 skip residuals): one stream each, no false dependencies
+        // (measured: branches for the inner levels too change nothing, 25.7 ms either way vs 26.8-27.3 without any)
+        const bool bwd_branch = P.training && depth >= 3;
+        if (bwd_branch) b.bwd_marker_node(OP_JOIN, depth);      // emitted right before maxpool's backward: d(x) += ... waits for the branch
+        Tn* low = residual(pooled, p + ".low1");
         low = depth > 1 ? hg(low, p + ".low2", depth - 1) : residual(low, p + ".low2");
         low = residual(low, p + ".low3");
+        if (bwd_branch) {
+            // Backward of the level: d(out) feeds the up1 residual (large full-resolution GEMMs) and, through the up-sampling, the
+            // whole low-resolution path (hundreds of small launches): independent until both add into d(x).  The up1 emitters are
+            // moved behind the low path's, i.e. emitted FIRST and bracketed by fork / end-fork markers: up1's backward is the
+            // first writer of d(x) on a branch stream, the low path runs beside it on the main stream, and the join above orders
+            // the max-pool backward's accumulation into d(x) after the branch.  (d(out) itself is read by the up-sampling backward
+            // BEFORE the fork and may be accumulated into in place by the branch afterwards: the identity skip aliases it.)
+            std::rotate(P.nodes.begin() + n0, P.nodes.begin() + n1, P.nodes.end());
+            const size_t nlow = P.nodes.size() - (n1 - n0);       // up1's emitters now start here
+            P.nodes.insert(P.nodes.begin() + nlow, nullptr);      // placeholder: end-fork marker (emitted after up1's backward)
+            const int sid = depth;
+            Builder* bp = &b;
+            P.nodes[nlow] = [bp, sid]() {
+                Op& o = bp->b("__endfork__", nullptr);
+                o.kind = OP_ENDFORK;
+                o.sid = sid;
+                return bp->err;
+            };
+            b.bwd_marker_node(OP_FORK, depth);                    // emitted right after the up-sampling add's backward
+        }
         return b.upsample_add(up1, low);
     }
 
@@ -1610,6 +1648,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     auto hand_off = [&]() -> int {       // everything the bucket needs (main chain so far + weight gradients) -> comm stream
         NET_CHECK(stream_wait(P, comm, main));
         for (auto st : P.side) NET_CHECK(stream_wait(P, comm, st));
+        for (auto st : P.branch) NET_CHECK(stream_wait(P, comm, st));
         return AWR_OK;
     };
     for (auto& op : ops) {
@@ -1625,12 +1664,14 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
             P.bucket_cb(P.bucket_user, op.lo, op.hi, (void*)comm);
             continue;
         }
-        if (wside && pending && op.kind != OP_ZERO) {
+        if (wside && pending && (op.kind == OP_CALL || op.kind == OP_BUCKET)) {
             const std::string& n = op.name;
-            const bool no_join = n.compare(0, 9, "awr_conv_") == 0 || n.compare(0, 9, "awr_stem_") == 0 || n == "awr_bn_bwd_reduce" || n == "awr_bn_bwd_apply" ||
-                                 n == "awr_bn_bwd_finalize" || n == "awr_maxpool_bwd" || n == "awr_upsample2_bwd" || n == "awr_add";
+            const bool no_join = op.kind == OP_CALL &&
+                                 (n.compare(0, 9, "awr_conv_") == 0 || n.compare(0, 9, "awr_stem_") == 0 || n == "awr_bn_bwd_reduce" || n == "awr_bn_bwd_apply" ||
+                                  n == "awr_bn_bwd_finalize" || n == "awr_maxpool_bwd" || n == "awr_upsample2_bwd" || n == "awr_add");
             if (!no_join) {      // join before anything that consumes the weight-gradient scratch (scatter, buckets)
                 for (auto st : P.side) NET_CHECK(stream_wait(P, main, st));
+                for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
                 pending = false;
             }
         }
@@ -1645,17 +1686,18 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
                 if (P.bucket_cb) P.bucket_cb(P.bucket_user, op.lo, op.hi, stream);
                 continue;
             case OP_FORK:
-                if (use_side && !is_bwd) {
-                    hipStream_t st = P.side[op.sid % P.side.size()];
+                if (use_side) {
+                    hipStream_t st = is_bwd ? P.branch[op.sid % P.branch.size()] : P.side[op.sid % P.side.size()];
                     NET_CHECK(stream_wait(P, st, main));
                     cur = (void*)st;
+                    if (is_bwd) pending = true;      // the end-of-list join has to cover the branch streams
                 }
                 continue;
             case OP_ENDFORK:
                 cur = stream;
                 continue;
             case OP_JOIN:
-                if (use_side && !is_bwd) NET_CHECK(stream_wait(P, main, P.side[op.sid % P.side.size()]));
+                if (use_side) NET_CHECK(stream_wait(P, main, is_bwd ? P.branch[op.sid % P.branch.size()] : P.side[op.sid % P.side.size()]));
                 continue;
             default:
                 break;
@@ -1663,7 +1705,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         int rc;
         if (wside && op.side_ok) {
             hipStream_t st = P.side[nside++ % P.side.size()];
-            NET_CHECK(stream_wait(P, st, main));      // its operands (dY, x) are final at this point of the main stream
+            NET_CHECK(stream_wait(P, st, awr::as_stream(cur)));      // its operands (dY, x) are final at this point of the issuing chain
             rc = op.fn((void*)st);
             pending = true;
         } else {
@@ -1673,6 +1715,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     }
     if (wside && (pending || comm)) {
         for (auto st : P.side) NET_CHECK(stream_wait(P, main, st));
+        for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
         if (comm) NET_CHECK(stream_wait(P, main, comm));      // next step's scratch fill / optimiser must see the scatters
     }
     return AWR_OK;
@@ -1775,6 +1818,7 @@ static void free_all(std::vector<void*>& v) {
 static void destroy_plan(awr_plan* p) {
     for (auto e : p->events) (void)hipEventDestroy(e);
     for (auto s : p->side) (void)hipStreamDestroy(s);
+    for (auto s : p->branch) (void)hipStreamDestroy(s);
     if (p->comm) (void)hipStreamDestroy(p->comm);
     free_all(p->owned);
     delete p;
@@ -1935,7 +1979,9 @@ int awr_plan_op(const awr_plan* p, int list, int i, const char** name, double* m
 int awr_plan_set_streams(awr_plan* p, int n_side, int comm) {
     AWR_REQUIRE(p && n_side >= 0 && n_side <= 8, "plan_set_streams: 0..8 side streams");
     for (auto s : p->side) (void)hipStreamDestroy(s);
+    for (auto s : p->branch) (void)hipStreamDestroy(s);
     p->side.clear();
+    p->branch.clear();
     if (p->comm) {
         (void)hipStreamDestroy(p->comm);
         p->comm = nullptr;
@@ -1944,6 +1990,11 @@ int awr_plan_set_streams(awr_plan* p, int n_side, int comm) {
         hipStream_t s;
         HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         p->side.push_back(s);
+    }
+    for (int i = 0; i < (n_side > 0 ? 2 : 0); ++i) {
+        hipStream_t s;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        p->branch.push_back(s);
     }
     if (comm) HIP_TRY(hipStreamCreateWithFlags(&p->comm, hipStreamNonBlocking));
     return AWR_OK;
