@@ -277,7 +277,9 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // DUAL (fp32 mode, single tap): the K extent is the concatenation of TWO input tensors at the same pixel -- channels [0, Cin1) come
 // from `in` (with the fused input affine, if any), [Cin1, Cin) from `in2` (plain) -- i.e. out = W_a . a + W_x . x in one launch:
 // the hourglass residual's conv3 + skip_layer (hourglass.py:44-59) without writing and re-reading the skip branch's output.
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false>
+// SPLIT (fp32 mode): blockIdx.z owns a contiguous range of the K slices and stores its raw partial tile to a.partial (copy
+// blockIdx.z); splitk_reduce_kernel finishes the job.
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
@@ -444,6 +446,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
     };
 
+    if constexpr (SPLIT) {
+        const int per = (ksteps + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int ks0 = (int)blockIdx.z * per, ks1 = ks0 + per < ksteps ? ks0 + per : ksteps;
+        if (ks0 < ks1) {       // (uniform per workgroup; an empty range stores a zero tile)
+            tap = ks0 / cslices;
+            c0 = (ks0 - tap * cslices) * BK;
+            set_tap(tap);
+            load_slice(c0);
+            store_slice();
+            __syncthreads();
+            for (int ks = ks0; ks < ks1; ++ks) {
+                const bool more = ks + 1 < ks1;
+                if (more) {
+                    advance();
+                    load_slice(c0);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float4 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_frag + i * 32 * ROWB) + 8 * s);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_frag + j * 32 * ROWB) + 8 * s);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();
+                if (more) {
+                    store_slice();
+                    __syncthreads();
+                }
+            }
+        }
+        awr_conv_args b = a;      // raw partial sums: the epilogue proper runs in splitk_reduce_kernel
+        b.out = a.partial + (size_t)blockIdx.z * ((size_t)a.B * a.Hout * a.Wout * a.N);
+        b.bias = nullptr; b.out_scale = nullptr; b.out_shift = nullptr; b.res = nullptr; b.stats = nullptr; b.bnr_y = nullptr; b.relu_out = 0;
+        gemm_epilogue<TM, TN>(b, ph, acc, smem, M, tile_m, tile_n);
+        return;
+    }
     set_tap(0);
     if constexpr (NP == 0) {
         load_slice(0);
@@ -607,6 +653,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         }
     }
     gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
+}
+
+// out = epilogue(sum over the split-K copies, in order): bias, folded-BN affine, residual, ReLU
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t stride, const float* __restrict__ bias,
+                                                            const float* __restrict__ osc, const float* __restrict__ osh, const float* __restrict__ res,
+                                                            int relu, int64_t n4, int N4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = ld4(partial + i * 4);
+    for (int z = 1; z < nsplit; ++z) {
+        const float4 p = ld4(partial + (int64_t)z * stride + i * 4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int n0 = (int)(i % N4) * 4;
+    if (bias) { const float4 b = ld4(bias + n0); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (osc) {
+        const float4 sc = ld4(osc + n0), sh = ld4(osh + n0);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    }
+    if (res) { const float4 r = ld4(res + i * 4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    st4(out + i * 4, v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1222,8 +1290,37 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         TN = a->tile_n;
     }
     if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
-    const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     hipStream_t st = as_stream(stream);
+    // split-K: few workgroups with a long K loop (low-batch inference: a layer4 conv at batch 4 is 32 workgroups x 144 slices)
+    int S = 1;
+    if (a->partial && a->split_max > 1 && g_products == 1 && !a->in2 && !a->stats && !a->bnr_y) {
+        int minsteps = a->ph[0].ntaps;
+        for (int p = 1; p < a->nphase; ++p) minsteps = a->ph[p].ntaps < minsteps ? a->ph[p].ntaps : minsteps;
+        minsteps *= a->Cin / BK;
+        if (a->split_k > 0) {
+            S = a->split_k;
+        } else {      // heuristic: fill ~2 workgroups per CU, keep >= 8 slices per range
+            const int64_t nb = blocks(TM, TN);
+            while (S * 2 <= a->split_max && nb * S * 2 <= 512 && minsteps / (S * 2) >= 8) S *= 2;
+        }
+        AWR_REQUIRE(S >= 1 && S <= a->split_max, "conv_gemm: split_k=%d exceeds split_max=%d", S, a->split_max);
+    } else {      // (the split-operand mode ignores a split-K request: a plan keeps its scratch and depth across mode switches)
+        AWR_REQUIRE(a->split_k <= 1 || (a->partial && a->split_max > 1 && !a->in2 && !a->stats && !a->bnr_y),
+                    "conv_gemm: split_k needs `partial` scratch and no stats / bnr_y / in2");
+    }
+    if (S > 1) {
+        const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase, S);
+        if (TM == 2 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 0, false, false, true>), grid, dim3(256), 0, st, *a);
+        else if (TM == 2 && TN == 1) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, 0, false, false, true>), grid, dim3(256), 0, st, *a);
+        else if (TM == 1 && TN == 2) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, true>), grid, dim3(256), 0, st, *a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 0, false, false, true>), grid, dim3(256), 0, st, *a);
+        if (int e = check_launch("conv_gemm_kernel<split>")) return e;
+        const int64_t numel = (int64_t)a->B * a->Hout * a->Wout * a->N, n4 = numel / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->partial, S, numel, a->bias, a->out_scale, a->out_shift,
+                           a->res, a->relu_out, n4, a->N / 4, a->out);
+        return check_launch("splitk_reduce_kernel");
+    }
+    const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     const bool aff = a->in_scale != nullptr || a->relu_in;
 #define AWR_LAUNCH_GEMM(tm, tn)                                                                          \
     do {                                                                                                 \

@@ -827,6 +827,19 @@ struct Builder {
         a->stats = y->stats.p;
         a->stat_slots = y->stats.p ? y->stats.nslots : 0;
         a->relu_in = o.relu_in; a->relu_out = o.relu_out;
+        if (!P.training && !a->stats) {
+            // low-batch inference: a launch of a few workgroups, each walking a long K loop, is latency-bound -> split-K scratch
+            // (awr_conv_gemm picks the depth from the workgroup count, the tuner refines it)
+            const int64_t wgs = ((int64_t)B * prob.Hq * prob.Wq + 63) / 64 * ((prob.N + 63) / 64) * (int64_t)prob.phases.size();
+            int minsteps = 1 << 30;
+            for (auto& ph : prob.phases) minsteps = std::min(minsteps, (int)ph.taps.size() * (a->Cin / 32));
+            int smax = 1;
+            while (smax < 16 && wgs * smax < 512 && minsteps / (smax * 2) >= 4) smax *= 2;
+            if (smax > 1) {
+                a->partial = alloc<float>((int64_t)smax * y->numel());
+                a->split_max = smax;
+            }
+        }
         const std::string name = "awr_conv_gemm:" + layer->name;
         Op& op = f(name, [a](void* s) { return awr_conv_gemm(a, s); });
         op.gemm = true;
@@ -1775,6 +1788,12 @@ static int autotune(awr_plan& P, int reps, void* stream) {
         if (g.ca) {
             cands = {{1, 1, 0}, {2, 1, 0}};
             if (g.ca->N > 64) { cands.push_back({1, 2, 0}); cands.push_back({2, 2, 0}); }
+            if (g.ca->partial && g.ca->split_max > 1 && awr_get_gemm_products() == 1) {      // (tile, split-K depth) pairs; tb = depth
+                std::vector<Cand> withk;
+                for (auto& c : cands)
+                    for (int sk = 1; sk <= g.ca->split_max; sk *= 2) withk.push_back({c.tm, c.tn, sk});
+                cands.swap(withk);
+            }
         } else {
             cands = {{1, 1, 2048}, {1, 1, 3072}, {1, 1, 4096}};
             if (g.wa->Cd > 64) { cands.push_back({2, 1, 1536}); cands.push_back({2, 1, 2048}); }
@@ -1784,7 +1803,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
         float best_t = 1e30f;
         Cand best = cands[0];
         for (auto& c : cands) {
-            if (g.ca) { g.ca->tile_m = c.tm; g.ca->tile_n = c.tn; }
+            if (g.ca) { g.ca->tile_m = c.tm; g.ca->tile_n = c.tn; if (c.tb) g.ca->split_k = c.tb; }
             else { g.wa->tile_m = c.tm; g.wa->tile_n = c.tn; if (c.tb) g.wa->target_blocks = c.tb; }
             if ((rc = launch(g))) break;      // warm-up
             (void)hipEventRecord(e0, main);
@@ -1797,7 +1816,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
             if (t < best_t) { best_t = t; best = c; }
         }
         if (rc) break;
-        if (g.ca) { g.ca->tile_m = best.tm; g.ca->tile_n = best.tn; }
+        if (g.ca) { g.ca->tile_m = best.tm; g.ca->tile_n = best.tn; if (best.tb) g.ca->split_k = best.tb; }
         else { g.wa->tile_m = best.tm; g.wa->tile_n = best.tn; if (best.tb) g.wa->target_blocks = best.tb; }
         g.tm = best.tm; g.tn = best.tn; g.tb = best.tb; g.us = best_t * 1e3f; g.tuned = true;
     }
@@ -2048,8 +2067,12 @@ int awr_plan_set_gemm(awr_plan* p, int i, int tile_m, int tile_n, int target_blo
     AWR_REQUIRE(p && i >= 0 && i < (int)p->gemms.size(), "plan_set_gemm: index out of range");
     AWR_REQUIRE((tile_m == 1 || tile_m == 2) && (tile_n == 1 || tile_n == 2) && target_blocks >= 0, "plan_set_gemm: tiles in {1,2}");
     GemmRef& g = p->gemms[i];
-    if (g.ca) { g.ca->tile_m = tile_m; g.ca->tile_n = tile_n; }
-    else { g.wa->tile_m = tile_m; g.wa->tile_n = tile_n; if (target_blocks) g.wa->target_blocks = target_blocks; }
+    if (g.ca) {
+        g.ca->tile_m = tile_m; g.ca->tile_n = tile_n;
+        if (target_blocks && g.ca->partial && target_blocks <= g.ca->split_max) g.ca->split_k = target_blocks;      // conv launches: split-K depth
+    } else {
+        g.wa->tile_m = tile_m; g.wa->tile_n = tile_n; if (target_blocks) g.wa->target_blocks = target_blocks;
+    }
     g.tm = tile_m; g.tn = tile_n; g.tb = target_blocks; g.us = us; g.tuned = true;
     return AWR_OK;
 }

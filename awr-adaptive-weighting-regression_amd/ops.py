@@ -107,8 +107,12 @@ class ConvSpec:
 
 
 def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, out_scale=None, out_shift=None, res=None,
-                   stats=None, relu_in=False, relu_out=False, T=None):
+                   stats=None, relu_in=False, relu_out=False, T=None, partial=None, split_k=0):
+    """partial: (split_max, *out.shape) scratch -> split-K (awr_hip.h: awr_conv_args.partial); split_k = 0 lets the library pick the depth."""
     a = L.ConvArgs()
+    if partial is not None:
+        a.partial, a.split_max, a.split_k = L.ptr(partial), partial.shape[0], split_k
+        a._keep = partial
     a.in_, a.w, a.out = L.ptr(x), L.ptr(w), L.ptr(out)
     a.w_split = L.ptr(getattr(w, "split", None))
     a.in_scale, a.in_shift, a.bias = L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias)

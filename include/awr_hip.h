@@ -196,6 +196,12 @@ typedef struct awr_conv_args {
                                `in2`], P rows [n][Cin] hold the two weight rows side by side; in_scale / in_shift / relu_in apply to `in` only.
                                out = W_a.in + W_x.in2: the hourglass residual's conv3 + skip_layer in one launch (FP32-MFMA mode only) */
     int Cin1;
+    float* partial;         /* optional scratch of split_max * B*Hout*Wout*N floats: enables split-K (small launches whose few workgroups
+                               would each walk a long K loop -- low-batch inference): blockIdx.z takes a contiguous range of the K
+                               slices and stores its raw partial tile, a second kernel sums the copies in order and applies the
+                               epilogue (bias, folded BN, residual, ReLU).  FP32-MFMA mode, no `stats` / `bnr_y` / `in2` */
+    int split_k;            /* K ranges (1 = off, 0 = heuristic from the workgroup count and K depth), <= split_max */
+    int split_max;
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
@@ -394,7 +400,8 @@ int awr_plan_forward(awr_plan* plan, void* stream);
 int awr_plan_backward(awr_plan* plan, void* stream);
 /* serial replay with a HIP-event pair around every conv / stem launch: ms[i] per op (synchronises the stream) */
 int awr_plan_run_timed(awr_plan* plan, int list, void* stream, float* ms);
-/* time the tile / split-K candidates of every GEMM launch in place (no-op in deterministic mode); read / preset choices */
+/* time the tile / split-K candidates of every GEMM launch in place (no-op in deterministic mode); read / preset choices
+ * (target_blocks: weight gradients = workgroup target of the split over pixels; conv launches with `partial` scratch = split-K depth) */
 int awr_plan_autotune(awr_plan* plan, int reps, void* stream);
 int awr_plan_gemm(const awr_plan* plan, int i, const char** name, int* tile_m, int* tile_n, int* target_blocks,
                   float* us, int* tuned);

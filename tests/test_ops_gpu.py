@@ -431,6 +431,37 @@ def test_fused_stem_matches_conv_bn_relu_maxpool(L, dev, B, H, W):
     assert float(slots.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind,cin,cout,k,stride,B,H", [("conv", 512, 512, 3, 1, 2, 8), ("conv", 256, 512, 3, 2, 1, 16), ("deconv", 512, 256, 4, 2, 1, 8),
+                                                       ("conv", 96, 160, 1, 1, 3, 8)])
+def test_conv_split_k(ops, dev, kind, cin, cout, k, stride, B, H):
+    """awr_conv_args.partial / split_k: blockIdx.z walks a range of the K slices, the reduce kernel sums the copies in order and applies
+    bias, folded-BN affine, residual and ReLU -- against float64 and against the single-pass kernel (low-batch inference path)."""
+    pad = 1 if k > 1 else 0
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w = rnd(*wshape, seed=1, scale=(cin * k * k) ** -0.5)
+    x = rnd(B, cin, H, H, seed=2)
+    bias, osc, osh = rnd(cout, seed=3), rnd(cout, seed=4) + 1.5, rnd(cout, seed=5)
+    isc, ish = rnd(cin, seed=6) + 0.5, rnd(cin, seed=7) * 0.3
+    a_in = TF.relu(x.double() * isc.double().view(1, -1, 1, 1) + ish.double().view(1, -1, 1, 1))
+    y0 = _torch_fwd(kind, a_in, w.double(), bias.double(), stride, pad)
+    res = rnd(*y0.shape, seed=8)
+    y_ref = TF.relu(y0 * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1) + res.double())
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    kw = dict(bias=bias.to(dev), out_scale=osc.to(dev), out_shift=osh.to(dev), res=ops.nhwc(res).to(dev), relu_out=True,
+              in_scale=isc.to(dev), in_shift=ish.to(dev), relu_in=True)
+    xg = ops.nhwc(x).to(dev)
+    y1 = ops.conv_forward(spec, xg, wp, **kw)
+    assert rel_err(ops.nchw(y1).cpu(), y_ref) < 5e-6
+    for sk in (0, 2, 4, 8):
+        part = torch.full((8,) + tuple(y1.shape), float("nan"), device=dev)      # every copy the launch reads must have been written
+        y2 = ops.conv_forward(spec, xg, wp, partial=part, split_k=sk, **kw)
+        assert rel_err(ops.nchw(y2).cpu(), y_ref) < 5e-6, sk
+        assert float((y2 - y1).abs().max()) <= 2e-5 * float(y1.abs().max()), sk
+    y3 = ops.conv_forward(spec, xg, wp, partial=part, split_k=4, **kw)
+    assert torch.equal(ops.conv_forward(spec, xg, wp, partial=part, split_k=4, **kw), y3)      # fixed summation order
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 32, 48), (2, 128, 128), (1, 16, 16)])
 def test_fused_stem_dense_matches_conv_bias_bn_relu(L, dev, B, H, W):
     """Hourglass stem (hourglass.py:112): conv 5x5 (1 -> 64, pad 2, WITH bias) -> BatchNorm (batch statistics) -> ReLU at full
