@@ -834,7 +834,7 @@ struct Builder {
             int minsteps = 1 << 30;
             for (auto& ph : prob.phases) minsteps = std::min(minsteps, (int)ph.taps.size() * (a->Cin / 32));
             int smax = 1;
-            while (smax < 16 && wgs * smax < 512 && minsteps / (smax * 2) >= 4) smax *= 2;
+            while (smax < 16 && wgs * smax < 2048 && minsteps / (smax * 2) >= 4) smax *= 2;
             if (smax > 1) {
                 a->partial = alloc<float>((int64_t)smax * y->numel());
                 a->split_max = smax;
