@@ -487,17 +487,22 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     assert abs(tr2.test(1) - tr.test(1)) < 1e-6
 
 
-def test_bucketed_backward_matches_and_is_final_at_the_marker(amd, dev):
+@pytest.mark.parametrize("net,streams", [("resnet_18", 0), ("resnet_18", 2), ("hourglass_1", 2)])
+def test_bucketed_backward_matches_and_is_final_at_the_marker(amd, dev, net, streams):
     """Data-parallel overlap: with n_buckets > 1 the backward hands out arena ranges as soon as they are final.
-    Snapshots taken at each marker must equal the end-of-step gradients, and those must equal the 1-bucket plan's."""
+    Snapshots taken at each marker must equal the end-of-step gradients, and those must equal the 1-bucket plan's.  With side
+    streams the weight gradients run beside the chain, the hourglass backward forks its outer levels onto branch streams and the
+    buckets are handed to the comm stream (the hook runs with torch switched to it)."""
     J = 14
     img, jt_gt = O.synth_batch(2, 128, J, seed=61)
-    man = O.manifest_for("resnet_18", J)
+    man = O.manifest_for(net, J)
     grads = []
     for nb in (1, 4):
-        m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=6))
+        m = make_net(amd, net, J, O.procedural_state(man, seed=6))
         m.train()
         plan = m.get_plan(2, 128, True, supervised=(0,), n_buckets=nb)
+        if streams:
+            plan.set_streams(streams, comm=nb > 1)
         snaps = []
         plan.bucket_hook = lambda lo, hi: snaps.append((lo, hi, m.flat_grads()[lo:hi].clone()))
         m.sync_weights(plan, force=True)
