@@ -1,10 +1,11 @@
 #!/bin/bash
+# One-box sweep of the configurations quoted in profiles/rNN_summary.md (train batch sizes, deterministic / serial modes, Hourglass, low-batch inference, split-operand mode)
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 C="--no-cpu-baseline --no-parity --no-split-mode --no-extras"
-run() { n=$1; shift; python bench.py $C "$@" > $OUT/b_r02u_$n.json 2>$OUT/b_r02u_$n.err; python - <<P
+run() { n=$1; shift; python bench.py $C "$@" > $OUT/b_sweep_$n.json 2>$OUT/b_sweep_$n.err; python - <<P
 import json
 try:
-    d=json.load(open("$OUT/b_r02u_$n.json")); print("$n", d["value"], d["ms_per_step"], d.get("roofline",{}).get("step_mfma_frac"), d.get("roofline",{}).get("frac"))
+    d=json.load(open("$OUT/b_sweep_$n.json")); print("$n", d["value"], d["ms_per_step"], d.get("roofline",{}).get("step_mfma_frac"), d.get("roofline",{}).get("frac"))
 except Exception as e: print("$n failed", e)
 P
 }
