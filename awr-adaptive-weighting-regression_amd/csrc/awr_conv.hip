@@ -202,8 +202,13 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     if (a.bnr_y) {
                         // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
                         const float4 yy = ld4(a.bnr_y + o);
-                        v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
-                        v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
+                        if (a.bnr_act) {      // the activation had a residual added before the ReLU: mask from the stored tensor
+                            const float4 aa = ld4(a.bnr_act + o);
+                            v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
+                        } else {
+                            v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
+                            v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
+                        }
                         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                         s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                         s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
@@ -1248,6 +1253,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         b.out = a->out + out_img * b.B * c;
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
+        if (a->bnr_act) b.bnr_act = a->bnr_act + out_img * b.B * c;
         if (a->in2) {
             b.in = a->in + (int64_t)a->Hin * a->Win * a->Cin1 * b.B * c;
             b.in2 = a->in2 + (int64_t)a->Hin * a->Win * (a->Cin - a->Cin1) * b.B * c;
@@ -1264,7 +1270,9 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(g_products == 1 || a->w_split, "conv_gemm: the %d-product mode needs the split image of the weights (w_split)", g_products);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
     AWR_REQUIRE(a->N % 4 == 0, "conv_gemm: N=%d must be a multiple of 4 (16-byte output rows)", a->N);
-    AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && !a->res), "conv_gemm: fused BN-backward reduction needs coef + stats and no accumulate");
+    AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && (!a->res || (a->bnr_act && a->res == a->out))),
+                "conv_gemm: fused BN-backward reduction needs coef + stats; accumulating (res) only in place and with bnr_act");
+    AWR_REQUIRE(!a->bnr_act || a->bnr_y, "conv_gemm: bnr_act without bnr_y");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
     AWR_REQUIRE(!a->in2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),

@@ -1005,8 +1005,8 @@ struct Builder {
             awr_conv_args* da = &P.cargs.back();
             fill_conv_args(*da, dp, B, dy, layer->p_dgrad.p, layer->p_dgrad.split, gx, spec.T());
             da->res = acc ? gx : nullptr;
-            // remember who wrote d(x): a single full-coverage, non-accumulating dgrad can host the fused BN-backward reduction
-            P.grad_writers[x].push_back((dp.full && !acc) ? da : nullptr);
+            // remember who wrote d(x), in order: a full-coverage dgrad that is the LAST producer can host the fused BN-backward reduction
+            P.grad_writers[x].push_back(dp.full ? da : nullptr);
             const std::string dname = "awr_conv_dgrad:" + layer->name;
             Op& dop = b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
             dop.gemm = true;
@@ -1085,21 +1085,28 @@ struct Builder {
         // Fused reduction: when the ONLY producer of d(a) is one full-coverage data-gradient GEMM (a BN+ReLU output read by a
         // single conv, materialised or not), that GEMM's epilogue masks with the re-derived ReLU and accumulates sum g /
         // sum g*xhat itself -- the separate reduction pass over d(a) and y disappears and the apply pass needs no mask.
+        // With a residual added before the ReLU (ResNet block outputs: d(a) = the next block's skip gradient + its conv1 data gradient)
+        // the LAST producer qualifies: it adds its tile onto the earlier contributions in place, takes the mask from the stored
+        // activation, reduces, and leaves the MASKED gradient behind -- which is also d(res).
         auto& writers = P.grad_writers[a];
-        const bool fused = relu && !res && writers.size() == 1 && writers[0] != nullptr;
+        awr_conv_args* ga = (!writers.empty() && relu) ? writers.back() : nullptr;
+        if (ga && ga->res && (ga->res != ga->out || !res)) ga = nullptr;      // accumulating producers only for the residual form, in place
+        if (ga && !ga->res && writers.size() != 1) ga = nullptr;
+        const bool fused = ga != nullptr;
         StatBuf sums;
         if (fused) {
-            awr_conv_args* ga = writers[0];
             sums = stat_buf(gemm_slots(ga->B, ga->Hq, ga->Wq, ga->N, ga->nphase), C);
             ga->bnr_y = y->buf;
             ga->bnr_coef = coef4;
+            ga->bnr_act = res ? a->buf : nullptr;
             ga->stats = sums.p;
             ga->stat_slots = sums.nslots;
         } else {
             sums = stat_buf(reduce_slots(), C);
         }
-        // ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`
-        const float* act = (relu && res) ? a->buf : nullptr;
+        // ReLU mask: without a residual the activation is re-derived from y (no read of `a`); with one it needs `a`; a fused producer
+        // has applied it already
+        const float* act = (relu && res && !fused) ? a->buf : nullptr;
         const float* msc = (relu && !res && !fused) ? sc : nullptr;
         const float* msh = (relu && !res && !fused) ? sh : nullptr;
         const float* yb = y->buf;
@@ -1116,7 +1123,8 @@ struct Builder {
             gy = alloc<float>(y->numel());
         }
         float *g_out = nullptr, *post_add = nullptr;
-        if (res && res->needs_grad && relu) {
+        if (res && res->needs_grad && relu && !fused) {      // the masked gradient is d(res): written out by the apply kernel
+            P.grad_writers[res].push_back(nullptr);
             if (!res->grad) {
                 res->grad = alloc<float>(res->numel());
                 g_out = res->grad;
@@ -1140,7 +1148,7 @@ struct Builder {
             const int64_t n = res->numel();
             b("awr_add", [=](void* s) { return awr_add(rg, post_add, rg, n, s); });
         }
-        if (res && res->needs_grad && !relu) contribute_identity(res, da);
+        if (res && res->needs_grad && (!relu || fused)) contribute_identity(res, da);      // d(a) itself (already masked when fused) is d(res)
         return err;
     }
 

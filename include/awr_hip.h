@@ -176,7 +176,7 @@ typedef struct awr_conv_args {
     const float* res;       /* optional tensor added element-wise, same shape as out            */
     double* stats;          /* optional [stat_slots][2][N]: += sum and sum of squares of the stored
                                value (taken after bias/affine/res, before relu_out)              */
-    const float* bnr_y;     /* optional fused BatchNorm-backward reduction (data-gradient launches): the result v   */
+    const float* bnr_y;     /* optional fused BatchNorm-backward reduction (data-gradient launches): the result v (after `res`) */
     const float* bnr_coef;  /* is d(loss)/d(relu(bn(y)));  with coef = [scale|shift|mean|invstd][N] the kernel stores */
                             /* g = v * (y*scale+shift > 0) and accumulates sum g, sum g*(y-mean)*invstd into `stats` */
     int B, Hin, Win, Cin;
@@ -202,6 +202,10 @@ typedef struct awr_conv_args {
                                epilogue (bias, folded BN, residual, ReLU).  FP32-MFMA mode, no `stats` / `bnr_y` / `in2` */
     int split_k;            /* K ranges (1 = off, 0 = heuristic from the workgroup count and K depth), <= split_max */
     int split_max;
+    const float* bnr_act;   /* with bnr_y: take the ReLU mask from this stored activation (act > 0) instead of re-deriving it from y -- the
+                               BatchNorm whose output had a residual added before the ReLU (resnet_deconv.py:74-78).  `res` may then be
+                               set as well: the launch is the LAST producer of the gradient, adds its tile onto the earlier
+                               contributions, masks, reduces and stores the masked gradient in place */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).

@@ -417,7 +417,7 @@ def test_inference_engine_and_graph_replay(amd, dev):
         else:
             assert np.allclose(res[0][0][:3], res[1][0][:3], rtol=2e-3) and np.allclose(res[0][0], res[1][0], rtol=3e-2), (res[0][0], res[1][0])
             dpar = (res[0][1] - res[1][1]).abs()
-            assert float(torch.quantile(dpar[:1000000], 0.9)) <= 2e-4 and float(dpar.max()) <= 8.1e-3
+            assert float(torch.quantile(dpar[:1000000], 0.9)) <= 4e-4 and float(dpar.max()) <= 8.1e-3      # (4 Adam steps of 1e-3: noise-level differences)
 
 
 def test_roundtrip_save_load_checkpoint(amd, dev, tmp_path):
