@@ -161,7 +161,14 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     __syncthreads();                    // every wave is done with the staged slices
     float* tbuf = smem + wave * (32 * LDK);
     const int c4 = lane & 7, rbase = lane >> 3;
-    float4 cs1[TN], cs2[TN];
+    // BatchNorm statistics (sum x, sum x^2) are accumulated SHIFTED by the first row of the wave's tile, c: a channel that is
+    // almost constant (std << |mean|: dead or saturated channels, constant image background) would otherwise lose its variance to
+    // the rounding of x^2 -- every term rounds the same way, the error does not average out -- and 1/sqrt(var + eps) amplifies
+    // that into the normalised activations and the gradients.  x - c is exact for nearly equal values; the sums return to the
+    // unshifted form in fp64 once per wave: sum x = s1 + n c, sum x^2 = s2 + 2 c s1 + n c^2.
+    const bool shifted = a.stats && !a.bnr_y;
+    float4 cs1[TN], cs2[TN], csh[TN];
+    int ccnt[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
@@ -175,7 +182,8 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
             ksc = ld4(a.bnr_coef + n0); ksh = ld4(a.bnr_coef + a.N + n0);
             kmu = ld4(a.bnr_coef + 2 * a.N + n0); kis = ld4(a.bnr_coef + 3 * a.N + n0);
         }
-        float4 s1 = z4, s2 = z4;
+        float4 s1 = z4, s2 = z4, cshift = z4;
+        int cnt = 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -186,19 +194,27 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 const int row = rbase + 8 * q;
                 float4 v = ld4(tbuf + row * LDK + 4 * c4);
                 const int m = tile_m * BM + wm * 32 * TM + i * 32 + row;
-                if (m < M && nok) {
+                const bool valid = m < M && nok;
+                size_t o = 0;
+                if (valid) {
                     int opix = m;
                     if (!direct) {
                         const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
                         opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
                     }
-                    const size_t o = (size_t)opix * a.N + n0;
+                    o = (size_t)opix * a.N + n0;
                     v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
                     if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                     if (a.res) {
                         const float4 rr = ld4(a.res + o);
                         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                     }
+                }
+                if (shifted && i == 0 && q == 0) {      // (wave-uniform) the shift: row 0 of the wave's tile, held by lanes 0..7
+                    const float4 t = valid ? v : z4;
+                    cshift.x = __shfl(t.x, c4, 64); cshift.y = __shfl(t.y, c4, 64); cshift.z = __shfl(t.z, c4, 64); cshift.w = __shfl(t.w, c4, 64);
+                }
+                if (valid) {
                     if (a.bnr_y) {
                         // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
                         const float4 yy = ld4(a.bnr_y + o);
@@ -213,8 +229,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                         s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                         s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
                     } else {
-                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                        const float4 d = make_float4(v.x - cshift.x, v.y - cshift.y, v.z - cshift.z, v.w - cshift.w);
+                        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                        s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+                        ++cnt;
                     }
                     if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     st4(a.out + o, v);
@@ -224,33 +242,48 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         }
         cs1[j] = s1;
         cs2[j] = s2;
+        csh[j] = cshift;
+        ccnt[j] = cnt;
     }
     if (a.stats) {
-        // BatchNorm statistics.  Lanes with equal (lane & 7) hold partial sums of the same 4 columns: fold lane bits 3..5,
-        // combine the two M-waves of the workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over
-        // AWR_STAT_SLOTS accumulator copies (thousands of workgroups hit the same C channels; without the slots the
-        // atomics serialise in L2 and cost more than the GEMM epilogue itself).
+        // Lanes with equal (lane & 7) hold partial sums of the same 4 columns: fold lane bits 3..5 (all lanes of a wave share the
+        // shift, so the shifted fp32 sums combine in one basis), leave the shifted form in fp64, combine the two M-waves of the
+        // workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands
+        // of workgroups hit the same C channels; without the slots the atomics serialise in L2 and cost more than the GEMM
+        // epilogue itself).  (The BatchNorm-backward sums -- sum g, sum g*xhat -- have no such cancellation: plain sums.)
+        double d1[TN][4], d2[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float* p1 = &cs1[j].x;
             float* p2 = &cs2[j].x;
+            int cnt = ccnt[j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int o = 8; o <= 32; o <<= 1) {
 #pragma unroll
-                for (int o = 8; o <= 32; o <<= 1) {
+                for (int e = 0; e < 4; ++e) {
                     p1[e] += __shfl_xor(p1[e], o, 64);
                     p2[e] += __shfl_xor(p2[e], o, 64);
                 }
+                cnt += __shfl_xor(cnt, o, 64);
+            }
+            const float* pc = &csh[j].x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double c = shifted ? (double)pc[e] : 0.0, n = (double)cnt;
+                d1[j][e] = (double)p1[e] + n * c;
+                d2[j][e] = (double)p2[e] + 2.0 * c * (double)p1[e] + n * c * c;
             }
         }
         __syncthreads();                 // all transpose tiles are dead: reuse the LDS for the cross-wave combine
-        float4* red = reinterpret_cast<float4*>(smem);
+        double* red = reinterpret_cast<double*>(smem);      // [wn * TN + j][stat][lane 0..7][4]
         if (wm == 1 && lane < 8) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                red[((wn * TN + j) * 2 + 0) * 8 + lane] = cs1[j];
-                red[((wn * TN + j) * 2 + 1) * 8 + lane] = cs2[j];
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e] = d1[j][e];
+                    red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e] = d2[j][e];
+                }
         }
         __syncthreads();
         if (wm == 0 && lane < 8) {
@@ -262,11 +295,11 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
             for (int j = 0; j < TN; ++j) {
                 const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
                 if (n0 < a.N) {
-                    const float4 o1 = red[((wn * TN + j) * 2 + 0) * 8 + lane], o2 = red[((wn * TN + j) * 2 + 1) * 8 + lane];
-                    atomicAdd(st + n0 + 0, (double)(cs1[j].x + o1.x)); atomicAdd(st + n0 + 1, (double)(cs1[j].y + o1.y));
-                    atomicAdd(st + n0 + 2, (double)(cs1[j].z + o1.z)); atomicAdd(st + n0 + 3, (double)(cs1[j].w + o1.w));
-                    atomicAdd(st + a.N + n0 + 0, (double)(cs2[j].x + o2.x)); atomicAdd(st + a.N + n0 + 1, (double)(cs2[j].y + o2.y));
-                    atomicAdd(st + a.N + n0 + 2, (double)(cs2[j].z + o2.z)); atomicAdd(st + a.N + n0 + 3, (double)(cs2[j].w + o2.w));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        atomicAdd(st + n0 + e, d1[j][e] + red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e]);
+                        atomicAdd(st + a.N + n0 + e, d2[j][e] + red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e]);
+                    }
                 }
             }
         }

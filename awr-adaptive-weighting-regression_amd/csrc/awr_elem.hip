@@ -221,11 +221,18 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             kt = ld4(msh + cg * 4);
         }
     }
+    // MODE 0: sums shifted by the thread's first row (nearly constant channels: csrc/awr_conv.hip, gemm_epilogue), converted back
+    // to the plain sums in fp64 before the cross-thread combine
+    float4 c0 = make_float4(0, 0, 0, 0);
+    int nrows = 0;
+    if (MODE == 0 && active && r0 + rg < r1) c0 = ld4(x + (r0 + rg) * C + cg * 4);
     // one row (all operands) -> partial sums
     auto accum = [&](float4 v, float4 aa, float4 yy) {
         if (MODE == 0) {
+            v.x -= c0.x; v.y -= c0.y; v.z -= c0.z; v.w -= c0.w;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
             s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            ++nrows;
         } else if (MODE == 1) {
             if (act) {
                 v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
@@ -262,16 +269,25 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             accum(ld4(x + o), (MODE == 1 && act) ? ld4(act + o) : z4, (MODE == 1) ? ld4(y + o) : z4);
         }
     }
-    __shared__ float4 sh1[256], sh2[256];
-    sh1[threadIdx.x] = s1;
-    sh2[threadIdx.x] = s2;
+    __shared__ double sh1[256][4], sh2[256][4];
+    {
+        const float p[4] = {s1.x, s1.y, s1.z, s1.w}, q[4] = {s2.x, s2.y, s2.z, s2.w}, c[4] = {c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {       // (MODE != 0: c = 0, plain sums)
+            const double cc = (double)c[k], n = (double)nrows;
+            sh1[threadIdx.x][k] = (double)p[k] + n * cc;
+            sh2[threadIdx.x][k] = (double)q[k] + 2.0 * cc * (double)p[k] + n * cc * cc;
+        }
+    }
     __syncthreads();
     if (threadIdx.x < C4) {
         double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
         for (int g = 0; g < rpp; ++g) {
-            const float4 p = sh1[g * C4 + threadIdx.x], q = sh2[g * C4 + threadIdx.x];
-            a[0] += p.x; a[1] += p.y; a[2] += p.z; a[3] += p.w;
-            b[0] += q.x; b[1] += q.y; b[2] += q.z; b[3] += q.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] += sh1[g * C4 + threadIdx.x][k];
+                b[k] += sh2[g * C4 + threadIdx.x][k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -79,7 +79,7 @@ __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __r
 __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                                          int H, int W, int nslots, double* __restrict__ stats) {
     __shared__ float patch[ST_PH * ST_PW];
-    __shared__ float red[4][2][32];
+    __shared__ double red[4][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int tiles_x = W >> 4, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int b = blockIdx.z, ch0 = blockIdx.y * 32;
@@ -88,27 +88,32 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
     const float bs = bias ? bias[ch0 + m] : 0.f;
     __syncthreads();
-    float s1 = 0.f, s2 = 0.f;
+    // sums shifted by the lane's first value (a constant background gives a nearly constant channel: x^2 would round the same way
+    // in every term and the variance would drown; csrc/awr_conv.hip: gemm_epilogue), back to the plain sums in fp64 per lane
+    float s1 = 0.f, s2 = 0.f, c0 = 0.f;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int q = 32 * (wave * 2 + ti) + m;
         const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
+        if (ti == 0) c0 = acc[0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s1 += acc[r];
-            s2 += acc[r] * acc[r];
+            const float d = acc[r] - c0;
+            s1 += d;
+            s2 += d * d;
         }
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    double t1 = (double)s1 + 32.0 * (double)c0, t2 = (double)s2 + 2.0 * (double)c0 * (double)s1 + 32.0 * (double)c0 * (double)c0;
+    t1 += __shfl_xor(t1, 32, 64);
+    t2 += __shfl_xor(t2, 32, 64);
     if (h == 0) {
-        red[wave][0][m] = s1;
-        red[wave][1][m] = s2;
+        red[wave][0][m] = t1;
+        red[wave][1][m] = t2;
     }
     __syncthreads();
     if (tid < 64) {
         const int st = tid >> 5, c = tid & 31;
-        const double v = (double)red[0][st][c] + (double)red[1][st][c] + (double)red[2][st][c] + (double)red[3][st][c];
+        const double v = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
         const int slot = (blockIdx.x + blockIdx.z * gridDim.x) % nslots;
         atomicAdd(stats + ((size_t)slot * 2 + st) * 64 + ch0 + c, v);
     }

@@ -155,6 +155,54 @@ def test_stem_im2col_gemm(ops, L, dev):
     assert rel_err(gw.cpu().view(64, 1, 5, 5), gw_ref) < 5e-6
 
 
+def test_batch_statistics_of_nearly_constant_channels(ops, L, dev):
+    """sum x / sum x^2 of channels whose spread is tiny next to their mean (dead or saturated channels, a constant image
+    background): a plain one-pass fp32 accumulation loses the variance (|mean| = 5, std = 1e-3: x^2 carries the spread in its last
+    two bits).  All three producers -- GEMM epilogue, stand-alone channel statistics, fused stem -- accumulate shifted sums and must
+    give the float64 variance to 1e-4 relative."""
+    B, H, cin, cout = 2, 16, 64, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5
+    w[:16] *= 1e-3                                     # channels 0..15: conv output = bias + 1e-3 * noise
+    bias = torch.randn(cout, generator=g)
+    bias[:16] = torch.linspace(-8, 8, 16)
+    spec = ops.ConvSpec("conv", cin, cout, 1, 1, 0)
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    stats = torch.zeros(16, 2, cout, device=dev, dtype=torch.float64)
+    y = ops.conv_forward(spec, ops.nhwc(x).to(dev), wp, bias=bias.to(dev), stats=stats)
+    n = B * H * H
+
+    def var_of(st):
+        st = st.sum(0).cpu()
+        return st[0] / n, st[1] / n - (st[0] / n) ** 2
+
+    yd = ops.nchw(y).cpu().double()                    # statistics of the values the kernel stored (fp32), evaluated in float64
+    mean_ref, var_ref = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+    assert float(var_ref[:16].max()) < 1e-5 and float(var_ref[16:].min()) > 0.1
+    mean, var = var_of(stats)
+    assert float(((mean - mean_ref).abs() / (mean_ref.abs() + 1e-3)).max()) < 1e-6
+    assert float(((var - var_ref).abs() / var_ref).max()) < 1e-4, ((var - var_ref).abs() / var_ref)[:16]
+    stats2 = torch.zeros(16, 2, cout, device=dev, dtype=torch.float64)
+    L.call("awr_channel_stats", L.ptr(y), n, cout, L.ptr(stats2), 0, L.stream())
+    mean2, var2 = var_of(stats2)
+    assert float(((var2 - var_ref).abs() / var_ref).max()) < 1e-4
+    # fused stem: a constant image -> every interior conv pixel of a channel has the same value (bias + sum of taps)
+    Hs = 64
+    img = torch.full((B, 1, Hs, Hs), 1.0)
+    img[:, :, 20:30, 20:30] += torch.randn(B, 1, 10, 10, generator=g) * 1e-3
+    ws = torch.randn(64, 1, 5, 5, generator=g) * 0.2
+    bs = torch.randn(64, generator=g) * 3
+    ys = TF.conv2d(img.double(), ws.double(), bs.double(), 1, 2)
+    stats3 = torch.zeros(16, 2, 64, device=dev, dtype=torch.float64)
+    imgd, wsd, bsd = img.to(dev), ws.to(dev).contiguous(), bs.to(dev)      # (named: the launch is asynchronous, temporaries would be recycled)
+    L.call("awr_stem_stats", L.ptr(imgd), L.ptr(wsd), L.ptr(bsd), B, Hs, Hs, L.ptr(stats3), 0, L.stream())
+    st = stats3.sum(0).cpu()
+    ns = B * Hs * Hs
+    var3 = st[1] / ns - (st[0] / ns) ** 2
+    assert float(((var3 - ys.var((0, 2, 3), unbiased=False)).abs() / ys.var((0, 2, 3), unbiased=False)).max()) < 1e-4
+
+
 @pytest.mark.parametrize("B,H,C", [(2, 16, 64), (3, 10, 96), (2, 8, 512), (4, 32, 128)])
 def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     x = rnd(B, C, H, H, seed=1) * 2 + 0.3
