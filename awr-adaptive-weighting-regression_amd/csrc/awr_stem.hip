@@ -63,7 +63,27 @@ __device__ __forceinline__ f32x16 stem_conv_tile(const float* patch, int base, c
     return acc;
 }
 
-// 20x20 image patch under a 16x16 tile of conv pixels (zero outside the image = the conv's padding)
+// 20x20 image patch under a 16x16 tile of conv pixels (zero outside the image = the conv's padding), in two halves so that a
+// multi-tile workgroup can request the next tile's patch before it computes the current one (256 threads: two elements each)
+struct patch_regs { float v[2]; };
+__device__ __forceinline__ patch_regs stem_fetch_patch16(const float* __restrict__ img, int b, int y0, int x0, int H, int W) {
+    patch_regs r;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int py = i / ST_PH, px = i - py * ST_PH;
+        const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+        r.v[k] = (i < ST_PH * ST_PH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
+    }
+    return r;
+}
+__device__ __forceinline__ void stem_commit_patch16(float* patch, const patch_regs& r) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < ST_PH * ST_PH) patch[(i / ST_PH) * ST_PW + (i % ST_PH)] = r.v[k];
+    }
+}
 __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __restrict__ img, int b, int y0, int x0, int H, int W) {
     for (int i = threadIdx.x; i < ST_PH * ST_PH; i += blockDim.x) {
         const int py = i / ST_PH, px = i - py * ST_PH;
@@ -75,35 +95,47 @@ __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __r
 // ------------------------------------------------------------------------------------------
 // BatchNorm batch statistics of the (never stored) conv output
 // ------------------------------------------------------------------------------------------
-// grid (tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32 channels
+// grid (groups of tiles_per_wg tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32
+// channels.  A workgroup walks several tiles: the filter bank is loaded once and the next tile's patch is requested before the
+// current tile's MFMAs (a one-tile workgroup spends most of its life waiting for its 13 + 2 loads).
 __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         int H, int W, int nslots, double* __restrict__ stats) {
+                                                         int H, int W, int tiles_per_wg, int nslots, double* __restrict__ stats) {
     __shared__ float patch[ST_PH * ST_PW];
     __shared__ double red[4][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
-    const int tiles_x = W >> 4, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tiles_x = W >> 4;
     const int b = blockIdx.z, ch0 = blockIdx.y * 32;
-    stem_load_patch16(patch, img, b, ty * 16, tx * 16, H, W);
+    const int tile0 = blockIdx.x * tiles_per_wg;
+    patch_regs nxt = stem_fetch_patch16(img, b, (tile0 / tiles_x) * 16, (tile0 % tiles_x) * 16, H, W);
     stem_lane sl;
     stem_lane_init<ST_PW>(sl, w, ch0 + m, h);
     const float bs = bias ? bias[ch0 + m] : 0.f;
-    __syncthreads();
     // sums shifted by the lane's first value (a constant background gives a nearly constant channel: x^2 would round the same way
     // in every term and the variance would drown; csrc/awr_conv.hip: gemm_epilogue), back to the plain sums in fp64 per lane
     float s1 = 0.f, s2 = 0.f, c0 = 0.f;
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        if (tt) __syncthreads();           // the previous tile's readers are done with the patch
+        stem_commit_patch16(patch, nxt);
+        if (tt + 1 < tiles_per_wg) {
+            const int tile = tile0 + tt + 1;
+            nxt = stem_fetch_patch16(img, b, (tile / tiles_x) * 16, (tile % tiles_x) * 16, H, W);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int q = 32 * (wave * 2 + ti) + m;
-        const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
-        if (ti == 0) c0 = acc[0];
+        for (int ti = 0; ti < 2; ++ti) {
+            const int q = 32 * (wave * 2 + ti) + m;
+            const f32x16 acc = stem_conv_tile(patch, (q >> 4) * ST_PW + (q & 15), sl, bs);
+            if (tt == 0 && ti == 0) c0 = acc[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = acc[r] - c0;
-            s1 += d;
-            s2 += d * d;
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[r] - c0;
+                s1 += d;
+                s2 += d * d;
+            }
         }
     }
-    double t1 = (double)s1 + 32.0 * (double)c0, t2 = (double)s2 + 2.0 * (double)c0 * (double)s1 + 32.0 * (double)c0 * (double)c0;
+    const double n = 32.0 * tiles_per_wg;
+    double t1 = (double)s1 + n * (double)c0, t2 = (double)s2 + 2.0 * (double)c0 * (double)s1 + n * (double)c0 * (double)c0;
     t1 += __shfl_xor(t1, 32, 64);
     t2 += __shfl_xor(t2, 32, 64);
     if (h == 0) {
@@ -159,51 +191,63 @@ constexpr int SP_RH = 9, SP_RW = 17, SP_PY = 4, SP_PX = 8;      // conv rows / c
 
 __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
-                                                        float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+                                                        int tiles_per_wg, float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
     __shared__ float patch[(SP_RH + 4) * SP_PW];
     __shared__ __attribute__((aligned(16))) float act[160 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
-    const int tiles_x = Wo / SP_PX, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tiles_x = Wo / SP_PX;
     const int b = blockIdx.z, ch0 = blockIdx.y * 32;
-    const int oy0 = ty * SP_PY, ox0 = tx * SP_PX;
-    for (int i = tid; i < (SP_RH + 4) * (SP_RW + 4); i += 320) {
-        const int py = i / (SP_RW + 4), px = i - py * (SP_RW + 4);
-        const int gy = 2 * oy0 - 3 + py, gx = 2 * ox0 - 3 + px;
-        patch[py * SP_PW + px] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
-    }
+    // this thread's patch element (273 of the 320 threads hold one); the next tile's is requested before the current tile's MFMAs
+    const int ppy = tid / (SP_RW + 4), ppx = tid - ppy * (SP_RW + 4);
+    const bool pact = tid < (SP_RH + 4) * (SP_RW + 4);
+    auto fetch = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int gy = 2 * ty * SP_PY - 3 + ppy, gx = 2 * tx * SP_PX - 3 + ppx;
+        return (pact && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)b * H + gy) * W + gx] : 0.f;
+    };
+    const int tile0 = blockIdx.x * tiles_per_wg;
+    float nxt = fetch(tile0);
     stem_lane sl;
     stem_lane_init<SP_PW>(sl, w, ch0 + m, h);
     const float sc = scale[ch0 + m], sh = shift[ch0 + m];
-    __syncthreads();
-    {
-        int q = 32 * wave + m;
-        q = q < SP_RH * SP_RW ? q : SP_RH * SP_RW - 1;       // rows 153..159 of the last tile: recomputed, never pooled
-        const int qy = q / SP_RW, qx = q - qy * SP_RW;
-        const f32x16 acc = stem_conv_tile(patch, qy * SP_PW + qx, sl);
+    int q = 32 * wave + m;
+    q = q < SP_RH * SP_RW ? q : SP_RH * SP_RW - 1;       // rows 153..159 of the last tile: recomputed, never pooled
+    const int qy = q / SP_RW, qx = q - qy * SP_RW;
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const int tile = tile0 + tt;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int oy0 = ty * SP_PY, ox0 = tx * SP_PX;
+        if (tt) __syncthreads();           // the previous tile's pooling threads are done with act / patch
+        if (pact) patch[ppy * SP_PW + ppx] = nxt;
+        if (tt + 1 < tiles_per_wg) nxt = fetch(tile + 1);
+        __syncthreads();
+        {
+            const f32x16 acc = stem_conv_tile(patch, qy * SP_PW + qx, sl);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[(32 * wave + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
-    }
-    __syncthreads();
-    if (tid < SP_PY * SP_PX * 8) {
-        const int c4 = tid & 7, pp = tid >> 3, py = pp >> 3, px = pp & 7;
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int am[4] = {0, 0, 0, 0};
-        // window row dy <-> conv row 2 oy - 1 + dy: only row / column -1 can fall outside (H, W even), torch pads with -inf
-        for (int dy = (oy0 + py == 0) ? 1 : 0; dy < 3; ++dy)
-            for (int dx = (ox0 + px == 0) ? 1 : 0; dx < 3; ++dx) {
-                const float4 v = ld4(&act[((2 * py + dy) * SP_RW + 2 * px + dx) * 32 + 4 * c4]);
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int r = 0; r < 16; ++r) act[(32 * wave + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
+        }
+        __syncthreads();
+        if (tid < SP_PY * SP_PX * 8) {
+            const int c4 = tid & 7, pp = tid >> 3, py = pp >> 3, px = pp & 7;
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int am[4] = {0, 0, 0, 0};
+            // window row dy <-> conv row 2 oy - 1 + dy: only row / column -1 can fall outside (H, W even), torch pads with -inf
+            for (int dy = (oy0 + py == 0) ? 1 : 0; dy < 3; ++dy)
+                for (int dx = (ox0 + px == 0) ? 1 : 0; dx < 3; ++dx) {
+                    const float4 v = ld4(&act[((2 * py + dy) * SP_RW + 2 * px + dx) * 32 + 4 * c4]);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (vv[c] > mx[c]) {      // first maximum in scan order wins (ATen)
-                        mx[c] = vv[c];
-                        am[c] = dy * 3 + dx;
-                    }
-            }
-        const size_t oidx = (((size_t)b * Ho + oy0 + py) * Wo + ox0 + px) * 64 + ch0 + 4 * c4;
-        st4(pooled + oidx, make_float4(mx[0], mx[1], mx[2], mx[3]));
-        if (argmax) *reinterpret_cast<uchar4*>(argmax + oidx) = make_uchar4((uint8_t)am[0], (uint8_t)am[1], (uint8_t)am[2], (uint8_t)am[3]);
+                    for (int c = 0; c < 4; ++c)
+                        if (vv[c] > mx[c]) {      // first maximum in scan order wins (ATen)
+                            mx[c] = vv[c];
+                            am[c] = dy * 3 + dx;
+                        }
+                }
+            const size_t oidx = (((size_t)b * Ho + oy0 + py) * Wo + ox0 + px) * 64 + ch0 + 4 * c4;
+            st4(pooled + oidx, make_float4(mx[0], mx[1], mx[2], mx[3]));
+            if (argmax) *reinterpret_cast<uchar4*>(argmax + oidx) = make_uchar4((uint8_t)am[0], (uint8_t)am[1], (uint8_t)am[2], (uint8_t)am[3]);
+        }
     }
 }
 
@@ -386,6 +430,13 @@ extern "C" {
     AWR_REQUIRE(B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, name ": H=%d, W=%d must be positive multiples of 16", H, W); \
     AWR_REQUIRE((int64_t)B * H * W < (1LL << 31), name ": batch too large")
 
+// tiles a workgroup walks: the largest divisor of the tile count that is <= want (power of two)
+static int stem_tiles_per_wg(int tiles, int want) {
+    int tpw = want;
+    while (tiles % tpw) tpw >>= 1;
+    return tpw;
+}
+
 // nslots (0 = AWR_STAT_SLOTS): slot copies of the accumulator the kernel may spread over; awr_stem_slots() of them give every
 // workgroup its own copy (deterministic mode)
 int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots) {
@@ -402,7 +453,8 @@ int awr_stem_slots(int B, int H, int W, int* stats_slots, int* wgrad_slots) {
 int awr_stem_stats(const float* img, const float* w, const float* bias, int B, int H, int W, double* stats, int nslots, void* stream) {
     AWR_REQUIRE(img && w && stats && nslots >= 0, "stem_stats: null pointer");
     AWR_STEM_GEOMETRY("stem_stats");
-    hipLaunchKernelGGL(stem_stats_kernel, dim3((H / 16) * (W / 16), 2, B), dim3(256), 0, as_stream(stream), img, w, bias, H, W,
+    const int tiles = (H / 16) * (W / 16), tpw = stem_tiles_per_wg(tiles, 4);
+    hipLaunchKernelGGL(stem_stats_kernel, dim3(tiles / tpw, 2, B), dim3(256), 0, as_stream(stream), img, w, bias, H, W, tpw,
                        nslots ? nslots : AWR_STAT_SLOTS, stats);
     return check_launch("stem_stats_kernel");
 }
@@ -419,8 +471,8 @@ int awr_stem_pool(const float* img, const float* w, const float* scale, const fl
                   uint8_t* argmax, void* stream) {
     AWR_REQUIRE(img && w && scale && shift && pooled, "stem_pool: null pointer");
     AWR_STEM_GEOMETRY("stem_pool");
-    hipLaunchKernelGGL(stem_pool_kernel, dim3((H / 2 / SP_PY) * (W / 2 / SP_PX), 2, B), dim3(320), 0, as_stream(stream), img, w, scale, shift, H, W,
-                       pooled, argmax);
+    const int tiles = (H / 2 / SP_PY) * (W / 2 / SP_PX), tpw = stem_tiles_per_wg(tiles, 4);
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(tiles / tpw, 2, B), dim3(320), 0, as_stream(stream), img, w, scale, shift, H, W, tpw, pooled, argmax);
     return check_launch("stem_pool_kernel");
 }
 
@@ -428,13 +480,14 @@ int awr_stem_bwd_reduce(const float* img, const float* w, const float* bias, con
                         int H, int W, double* sums, int nslots, void* stream) {
     AWR_REQUIRE(img && w && coef4 && dg && sums && nslots >= 0, "stem_bwd_reduce: null pointer");
     AWR_STEM_GEOMETRY("stem_bwd_reduce");
-    const dim3 grid((H / 16) * (W / 16), 2, B);
+    const int tiles = (H / 16) * (W / 16), tpw = stem_tiles_per_wg(tiles, 4);
+    const dim3 grid(tiles / tpw, 2, B);
     if (argmax)
         hipLaunchKernelGGL((stem_bwd_kernel<0, false>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, (const float*)nullptr, dg, argmax, H, W,
-                           1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
+                           tpw, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
     else
         hipLaunchKernelGGL((stem_bwd_kernel<0, true>), grid, dim3(256), 0, as_stream(stream), img, w, bias, coef4, (const float*)nullptr, dg, argmax, H, W,
-                           1, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
+                           tpw, nslots ? nslots : AWR_STAT_SLOTS, sums, (float*)nullptr);
     return check_launch("stem_bwd_kernel<0>");
 }
 
