@@ -1,0 +1,90 @@
+"""GPU: the BASELINE configurations at their FULL batch sizes -- the bench shapes themselves -- against the oracle run on the GPU
+box's host cores (torch-CPU fp32, seconds per case), plus size-independent properties (the images of an eval batch are independent:
+a full batch equals its slices run on their own)."""
+import numpy as np
+import pytest
+import torch
+
+import awr_oracle as O
+
+pytestmark = pytest.mark.gpu
+NORTH_STAR_MEAN_MM = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import awr_amd
+    return awr_amd
+
+
+def _net(amd, name, J, sd):
+    m = amd.get_deconv_net(18, J, 2) if name.startswith("resnet") else amd.PoseNet(name, J)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def test_config2_resnet18_train_step_batch64_vs_oracle(amd, dev):
+    """BASELINE configs[1] (the headline shape): one fused train step at batch 64 -- loss, joints, BatchNorm running statistics and
+    the parameters after Adam -- against the oracle's step on the same 64 images."""
+    from awr_amd.trainer import TrainEngine
+    J, B, ks = 14, 64, 1.0
+    img, jt_gt = O.synth_batch(B, 128, J, seed=301)
+    sd = O.reference_init_state("resnet_18", J, seed=3)
+    m = _net(amd, "resnet_18", J, sd)
+    eng = TrainEngine(m, B, 128, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3)
+    losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+    sdo, ost = {k: v.clone() for k, v in sd.items()}, {"step": 0, "m": {}, "v": {}}
+    ref = O.train_step("resnet_18", sdo, ost, img, jt_gt, ks, 0.0, 1.0)
+    loss_ref, jt_ref = float(ref[0]), ref[-1]
+    assert abs(float(losses[2]) - loss_ref) <= 1e-5 * abs(loss_ref), (float(losses[2]), loss_ref)
+    d = (jt.cpu() - jt_ref).norm(dim=-1) * 150.0
+    assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
+    got = m.state_dict()
+    for k in ("pre.1.running_mean", "layer2.0.bn1.running_var", "layer4.1.bn2.running_var", "deconv_layers.7.running_mean"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), sdo[k].numpy(), rtol=2e-5, atol=2e-6)
+    # one Adam step moves every weight by ~lr whatever the gradient magnitude: elements whose gradient is rounding noise may land anywhere in
+    # +-lr, the bulk must agree tightly
+    diffs = torch.cat([(got[k].cpu() - sdo[k]).abs().reshape(-1) for k in ("layer1.0.conv1.weight", "layer3.1.conv2.weight", "deconv_layers.3.weight", "final2.weight")])
+    assert float(torch.quantile(diffs[:2000000], 0.9)) <= 1e-4 and float(diffs.max()) <= 2.1e-3
+
+
+def test_config3_hourglass1_inference_batch128_vs_oracle_and_slices(amd, dev):
+    """BASELINE configs[2] (NYU test pass shape): Hourglass-1 img -> joints at batch 128 against the oracle on the same images, and the
+    batch against its own slices (eval-mode images are independent; tile and split-K choices differ with the batch size)."""
+    from awr_amd.trainer import InferEngine
+    J, B, ks = 14, 128, 0.4
+    img, _ = O.synth_batch(B, 128, J, seed=302)
+    sd = O.reference_init_state("hourglass_1", J, seed=4)
+    m = _net(amd, "hourglass_1", J, sd).eval()
+    jt = InferEngine(m, B, 128, ks)(img.to(dev)).cpu()
+    with torch.no_grad():
+        ref = O.offset2joint_softmax(O.backbone_forward("hourglass_1", sd, img, training=False)[-1], img, ks)
+    d = (jt - ref).norm(dim=-1) * 150.0
+    assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
+    small = InferEngine(m, 8, 128, ks)
+    for lo in (0, 56, 120):
+        js = small(img[lo:lo + 8].to(dev)).cpu()
+        assert float((js - jt[lo:lo + 8]).norm(dim=-1).max()) * 150.0 <= 1e-3, lo
+
+
+def test_config1_resnet18_eval_batch4_split_k_path_vs_oracle(amd, dev):
+    """BASELINE configs[0] (the reference's CPU-runnable case): ResNet18 eval at batch 4 -- the low-batch plan whose long-K launches run
+    split-K -- against the oracle, and against the same images inside a batch of 64 (single-pass kernels)."""
+    from awr_amd.trainer import InferEngine
+    J, ks = 14, 1.0
+    img, _ = O.synth_batch(64, 128, J, seed=303)
+    sd = O.reference_init_state("resnet_18", J, seed=5)
+    m = _net(amd, "resnet_18", J, sd).eval()
+    j4 = InferEngine(m, 4, 128, ks)(img[:4].to(dev)).cpu()
+    with torch.no_grad():
+        ref = O.offset2joint_softmax(O.resnet18_forward(sd, img[:4]), img[:4], ks)
+    d = (j4 - ref).norm(dim=-1) * 150.0
+    assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
+    j64 = InferEngine(m, 64, 128, ks)(img.to(dev)).cpu()
+    assert float((j64[:4] - j4).norm(dim=-1).max()) * 150.0 <= 1e-3
