@@ -54,6 +54,25 @@ def test_config2_resnet18_train_step_batch64_vs_oracle(amd, dev):
     assert float(torch.quantile(diffs[:2000000], 0.9)) <= 1e-4 and float(diffs.max()) <= 2.1e-3
 
 
+def test_config4_resnet18_train_step_batch256_vs_oracle(amd, dev):
+    """BASELINE configs[3]'s per-GPU shape (256 images per GPU): forward of the fused train step -- loss and joints under batch-statistics
+    BatchNorm over 256 images -- against the oracle's training-mode forward (a minute of host time)."""
+    from awr_amd.trainer import TrainEngine
+    J, B, ks = 14, 256, 1.0
+    img, jt_gt = O.synth_batch(B, 128, J, seed=304)
+    sd = O.reference_init_state("resnet_18", J, seed=6)
+    m = _net(amd, "resnet_18", J, sd)
+    eng = TrainEngine(m, B, 128, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, autotune=False)
+    losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+    with torch.no_grad():
+        pred = O.backbone_forward("resnet_18", {k: v.clone() for k, v in sd.items()}, img, training=True)[-1]
+        jt_ref = O.offset2joint_softmax(pred, img, ks)
+        loss_ref = float(O.huber(pred, O.joint2offset(jt_gt, img, ks, 64)))
+    assert abs(float(losses[2]) - loss_ref) <= 1e-5 * abs(loss_ref), (float(losses[2]), loss_ref)
+    d = (jt.cpu() - jt_ref).norm(dim=-1) * 150.0
+    assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
+
+
 def test_config3_hourglass1_inference_batch128_vs_oracle_and_slices(amd, dev):
     """BASELINE configs[2] (NYU test pass shape): Hourglass-1 img -> joints at batch 128 against the oracle on the same images, and the
     batch against its own slices (eval-mode images are independent; tile and split-K choices differ with the batch size)."""
