@@ -290,6 +290,8 @@ def main():
         "frac": round(flop_mult * kern[dom]["tflops"] / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flop_per_launch": round(kern[dom]["flops"] / max(kern[dom]["launches"], 1)),
         "avg_launch_us": round(kern[dom]["avg_us"], 2), "launches_per_step": kern[dom]["launches"] // max(nsteps_timed, 1),
+        # HBM rate of the dominant kernel: PMC bytes per launch over the live average launch time, against the 8 TB/s HBM3E figure
+        "hbm_gbps": round(traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9, 1) if traffic and kern[dom]["avg_us"] else None, "hbm_peak_gbps": 8000.0,
         "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2) if tot_sec else 0.0,
         "gemm_seconds_per_step": round(tot_sec / max(nsteps_timed, 1), 6),
         "algorithmic_gflop_per_image": round(tot_fl / max(nsteps_timed, 1) / args.batch / 1e9, 3),
