@@ -142,6 +142,7 @@ _SIGS = {
     "awr_plan_bucket": ([_P, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)], C.c_int),
     "awr_plan_op": ([_P, _I, _I, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(_I)], C.c_int),
     "awr_plan_set_streams": ([_P, _I, _I], C.c_int),
+    "awr_stream_pool_info": ([C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "awr_plan_set_bucket_callback": ([_P, _P, _P], C.c_int),        # (plan, awr_bucket_cb or NULL, user)
     "awr_plan_refresh_weights": ([_P, _P], C.c_int),
     "awr_plan_forward": ([_P, _P], C.c_int),

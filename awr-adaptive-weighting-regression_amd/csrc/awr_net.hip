@@ -646,6 +646,7 @@ struct awr_plan {
     std::vector<hipStream_t> side;
     std::vector<hipStream_t> branch;      // backward branches (an hourglass level's full-resolution skip residual)
     hipStream_t comm = nullptr;
+    bool comm_owned = false;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
     awr_bucket_cb bucket_cb = nullptr;
@@ -1642,7 +1643,7 @@ static int refresh_weights(awr_plan& P, void* stream) {
 
 // waiter waits for everything enqueued on signaler so far (capturable: event record + stream wait)
 static int stream_wait(awr_plan& P, hipStream_t waiter, hipStream_t signaler) {
-    if (P.events.size() < 64) {
+    if (P.events.size() < 2048) {      // (large enough that an event is never re-recorded within one pass: hundreds of waits per Hourglass backward)
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         P.events.push_back(e);
@@ -1668,7 +1669,8 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     void* cur = stream;
     auto hand_off = [&]() -> int {       // everything the bucket needs (main chain so far + weight gradients) -> comm stream
         NET_CHECK(stream_wait(P, comm, main));
-        for (auto st : P.side) NET_CHECK(stream_wait(P, comm, st));
+        for (auto st : P.side)
+            if (st != comm) NET_CHECK(stream_wait(P, comm, st));
         for (auto st : P.branch) NET_CHECK(stream_wait(P, comm, st));
         return AWR_OK;
     };
@@ -1844,9 +1846,7 @@ static void free_all(std::vector<void*>& v) {
 
 static void destroy_plan(awr_plan* p) {
     for (auto e : p->events) (void)hipEventDestroy(e);
-    for (auto s : p->side) (void)hipStreamDestroy(s);
-    for (auto s : p->branch) (void)hipStreamDestroy(s);
-    if (p->comm) (void)hipStreamDestroy(p->comm);
+    if (p->comm && p->comm_owned) (void)hipStreamDestroy(p->comm);      // (side / branch streams belong to the process-wide pool)
     free_all(p->owned);
     delete p;
 }
@@ -2003,27 +2003,113 @@ int awr_plan_op(const awr_plan* p, int list, int i, const char** name, double* m
     return AWR_OK;
 }
 
+}  // extern "C"
+
+// ---- library streams --------------------------------------------------------------------------------------------------------
+// HIP multiplexes streams onto a few hardware queues (4 by default); two streams on one queue run their kernels one after the other,
+// and which streams share depends on how many streams the process created before (a communication library's, the framework's).
+// Side streams only help when they sit on a queue of their own, so the library keeps ONE process-wide pool and orders it by a probe:
+// a 100 us spin kernel on two streams at once takes 100 us when they are independent, 200 us when they share a queue.  pool[0..k) are
+// mutually independent and independent of the null stream; the rest follow.  Plans borrow from the pool (never destroy).
+namespace awrnet {
+
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+static float probe_pair_ms(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, hipEvent_t eb) {
+    const long long ticks = 10000;      // 100 us of the 100 MHz wall clock
+    (void)hipEventRecord(e0, a);
+    (void)hipStreamWaitEvent(b, e0, 0);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipEventRecord(eb, b);
+    (void)hipStreamWaitEvent(a, eb, 0);
+    (void)hipEventRecord(e1, a);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+struct StreamPool {
+    std::vector<hipStream_t> ordered;      // independent ones first
+    int n_independent = 0;
+};
+
+static StreamPool& stream_pool() {
+    static StreamPool pool;
+    static bool built = false;
+    if (built) return pool;
+    built = true;
+    const int NC = 8;
+    std::vector<hipStream_t> cand;
+    for (int i = 0; i < NC; ++i) {
+        hipStream_t s;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        cand.push_back(s);
+    }
+    hipEvent_t e0, e1, eb;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventCreate(&eb);
+    hipStream_t null_stream = nullptr;
+    if (!cand.empty()) (void)probe_pair_ms(null_stream, cand[0], e0, e1, eb);      // warm-up (code load)
+    std::vector<hipStream_t> indep, rest;
+    for (auto c : cand) {
+        bool ok = probe_pair_ms(null_stream, c, e0, e1, eb) < 0.15f;
+        for (size_t k = 0; ok && k < indep.size(); ++k) ok = probe_pair_ms(indep[k], c, e0, e1, eb) < 0.15f;
+        (ok ? indep : rest).push_back(c);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(eb);
+    pool.n_independent = (int)indep.size();
+    pool.ordered = indep;
+    pool.ordered.insert(pool.ordered.end(), rest.begin(), rest.end());
+    return pool;
+}
+
+}  // namespace awrnet
+
+extern "C" {
+
+int awr_stream_pool_info(int* n_streams, int* n_independent) {
+    StreamPool& sp = stream_pool();
+    if (n_streams) *n_streams = (int)sp.ordered.size();
+    if (n_independent) *n_independent = sp.n_independent;
+    return AWR_OK;
+}
+
 int awr_plan_set_streams(awr_plan* p, int n_side, int comm) {
-    AWR_REQUIRE(p && n_side >= 0 && n_side <= 8, "plan_set_streams: 0..8 side streams");
-    for (auto s : p->side) (void)hipStreamDestroy(s);
-    for (auto s : p->branch) (void)hipStreamDestroy(s);
+    AWR_REQUIRE(p && n_side >= 0 && n_side <= 4, "plan_set_streams: 0..4 side streams");
     p->side.clear();
     p->branch.clear();
     if (p->comm) {
-        (void)hipStreamDestroy(p->comm);
+        if (p->comm_owned) (void)hipStreamDestroy(p->comm);
         p->comm = nullptr;
     }
-    for (int i = 0; i < n_side; ++i) {
-        hipStream_t s;
-        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        p->side.push_back(s);
+    StreamPool& sp = stream_pool();
+    AWR_REQUIRE((int)sp.ordered.size() >= n_side + 2 || n_side == 0, "plan_set_streams: could not create the library's streams");
+    for (int i = 0; i < n_side; ++i) p->side.push_back(sp.ordered[i]);
+    // branch streams only for plans whose backward forks (every stream beyond the device's few hardware queues shares one with another
+    // stream and serialises with it: measured on the data-parallel ResNet18 step, whose comm stream is the fourth)
+    int nfork = 0;
+    for (auto& op : p->bwd) nfork += op.kind == OP_FORK ? 1 : 0;
+    for (int i = 0; i < (n_side > 0 && nfork > 0 ? 2 : 0); ++i) p->branch.push_back(sp.ordered[n_side + i]);
+    // the "comm stream" buckets are handed to is the LAST side stream when there is one: a bucket's scatter has to wait for the weight
+    // gradients on it anyway, and a stream of its own would be one too many for the hardware queues -- the collective itself runs on
+    // the communication library's stream behind an event
+    if (comm) {
+        if (!p->side.empty()) {
+            p->comm = p->side.back();
+            p->comm_owned = false;
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&p->comm, hipStreamNonBlocking));
+            p->comm_owned = true;
+        }
     }
-    for (int i = 0; i < (n_side > 0 ? 2 : 0); ++i) {
-        hipStream_t s;
-        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        p->branch.push_back(s);
-    }
-    if (comm) HIP_TRY(hipStreamCreateWithFlags(&p->comm, hipStreamNonBlocking));
     return AWR_OK;
 }
 

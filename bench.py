@@ -116,6 +116,14 @@ def parity_mm(net_name, ks, dev):
     return float(d.mean()), float(d.max())
 
 
+def _pool_info(L):
+    """How many of the library's streams sit on a hardware queue of their own (awr_stream_pool_info)."""
+    import ctypes as C
+    n, k = C.c_int(), C.c_int()
+    L.call("awr_stream_pool_info", C.byref(n), C.byref(k))
+    return k.value
+
+
 def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None):
     """test.py:67-86 path: eval-mode BatchNorm folded into the GEMM epilogues, img -> dense map -> joints.  Returns images/s, ms per
     batch and the fraction of the MFMA roofline (algorithmic conv FLOPs of the forward / time / peak)."""
@@ -310,7 +318,7 @@ def main():
                            args.net, args.batch, {64: " = BASELINE configs[1]", 256: " = BASELINE configs[3] per-GPU shape"}.get(args.batch, ""))
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
-                       "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams,
+                       "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams, "independent_hw_queues_for_side_streams": _pool_info(L),
                        "gemm_products": nprod, "deterministic": bool(args.deterministic), "device_cus": n_cu.value, "final_loss": loss},
             "roofline": roofline,
         }

@@ -394,10 +394,15 @@ int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* 
 int awr_plan_op(const awr_plan* plan, int list, int i, const char** name, double* macs, int* flags);
 /* n_side extra HIP streams (weight gradients in the backward, forked branches in the forward); comm != 0 adds the
  * stream buckets are handed to */
-int awr_plan_set_streams(awr_plan* plan, int n_side, int comm);
+int awr_plan_set_streams(awr_plan* plan, int n_side, int comm);      /* n_side in 0..4 */
 typedef void (*awr_bucket_cb)(void* user, int64_t lo, int64_t hi, void* stream);
 /* cb(user, lo, hi, stream): grads[lo, hi) is final in `stream` order -- start its all-reduce there */
 int awr_plan_set_bucket_callback(awr_plan* plan, awr_bucket_cb cb, void* user);
+/* The library's side / branch streams come from ONE process-wide pool, ordered by a probe (a 100 us spin kernel on two streams at once):
+ * the first n_independent streams share a hardware queue neither with the null stream nor with each other -- HIP multiplexes streams onto
+ * a few hardware queues and streams on one queue serialise, so which streams a plan gets decides whether its side streams overlap anything.
+ * Built on first use (a few milliseconds, synchronises the device once). */
+int awr_stream_pool_info(int* n_streams, int* n_independent);
 /* repack every conv weight (and re-fold eval BatchNorms) from the arena; forward; backward */
 int awr_plan_refresh_weights(awr_plan* plan, void* stream);
 int awr_plan_forward(awr_plan* plan, void* stream);
