@@ -141,6 +141,12 @@ _SIGS = {
     "awr_plan_info": ([_P, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], C.c_int),
     "awr_plan_bucket": ([_P, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)], C.c_int),
     "awr_plan_op": ([_P, _I, _I, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(_I)], C.c_int),
+    "awr_plan_head_nhwc": ([_P, _I, _PP, _PP, C.POINTER(_I)], C.c_int),
+    "awr_plan_set_nhwc_boundary": ([_P, _I], C.c_int),
+    "awr_head_nhwc_scratch": ([_I, _I, _I], C.c_int64),
+    "awr_head_forward_nhwc": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P], C.c_int),
+    "awr_head_loss_step_nhwc": ([_P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "awr_plan_tensor": ([_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), _PP, _PP, C.POINTER(_I), _PP, _PP], C.c_int),
     "awr_plan_set_streams": ([_P, _I, _I], C.c_int),
     "awr_stream_pool_info": ([C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "awr_plan_set_bucket_callback": ([_P, _P, _P], C.c_int),        # (plan, awr_bucket_cb or NULL, user)

@@ -27,6 +27,8 @@ constexpr float kDepthBg = 0.99f;  // util/feature_tool.py:35, :57
 // pixel-centre coordinate in [-1,1]; util/feature_tool.py:23-24, :50-51 (exact in fp32 for F = 2^k)
 __device__ __forceinline__ float grid_coord(int i, int F) { return 2.0f * ((float)i + 0.5f) / (float)F - 1.0f; }
 
+__device__ __forceinline__ float ks_dis(float ks, float h) { return ks - h * ks; }      // util/feature_tool.py:61
+
 struct Px4 {  // 4 consecutive pixels of one feature row
     float d[4], cx[4], cy;
 };
@@ -229,9 +231,10 @@ __device__ __forceinline__ float huber_grad(float z, float delta) { return fminf
 
 // Loss accumulators.  Default: fp64 atomic adds of the block partials.  Deterministic mode (awr_set_deterministic): the SAME 8 bytes
 // hold a signed 2^-50 fixed-point number and the partials are added with INTEGER atomics -- associative, so the sum does not depend
-// on the order in which the workgroups finish.  Range +-8192 (losses are O(1) and below), resolution 9e-16 per partial: far below
+// on the order in which the workgroups finish.  Range [0, 2048) (losses are O(1) and below; larger / NaN values are flagged, not wrapped), resolution 9e-16 per partial: far below
 // the fp32 loss that is reported.  awr_loss_finalize converts back.
-constexpr double LOSS_FIX = 1125899906842624.0;      // 2^50
+constexpr double LOSS_FIX = 1125899906842624.0;      // 2^50 (the encoding is chosen by awr_get_deterministic() at launch time: do not
+                                                      // toggle the mode between accumulating into `acc` and awr_loss_finalize)
 
 __device__ __forceinline__ void block_accumulate(double local, double scale, double* acc, int fixed_point) {
     __shared__ double part[4];
@@ -240,8 +243,17 @@ __device__ __forceinline__ void block_accumulate(double local, double scale, dou
     __syncthreads();
     if (threadIdx.x == 0) {
         const double v = (part[0] + part[1] + part[2] + part[3]) * scale;
-        if (fixed_point) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(v * LOSS_FIX));
-        else atomicAdd(acc, v);
+        if (fixed_point) {
+            // Huber partials are >= 0, so the running integer stays far below bit 61 for any finite loss < 2048.  A NaN partial sets
+            // bit 61, a partial that does not fit (an exploding loss) bit 62: loss_finalize_kernel maps them back to NaN / +inf instead
+            // of letting the integer wrap into a plausible finite number.
+            unsigned long long* a = reinterpret_cast<unsigned long long*>(acc);
+            if (v != v) atomicOr(a, 1ULL << 61);
+            else if (!(v < 2048.0)) atomicOr(a, 1ULL << 62);
+            else atomicAdd(a, (unsigned long long)__double2ll_rn(v * LOSS_FIX));
+        } else {
+            atomicAdd(acc, v);
+        }
     }
 }
 
@@ -301,6 +313,218 @@ __global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x,
     block_accumulate(local, lscale, acc, fixed_point);
 }
 
+// ------------------------------------------------------------------------------------------
+// NHWC forms (round 3): head forward, fused GT map + dense Huber, head backward on the backbone's own layout.
+// ------------------------------------------------------------------------------------------
+// The head GEMM leaves the dense map as (B, P, Cp) rows -- Cp = 4J rounded up to 32, channel 3j + c = offset component c of joint
+// j, channel 3J + j = its heat map (util/feature_tool.py:46-48) -- and the backward wants its gradient in the same layout; the NCHW
+// kernels above forced a transpose pass in each direction (2 x 29 us, 235 MB per batch-64 step).  Here a workgroup walks a run of
+// 64-pixel tiles of one image: the tile (64 x Cp floats, one contiguous piece of HBM) is requested one tile ahead with 16-byte loads
+// (4-16 in flight per thread), parked in LDS, and thread (pixel slot, joint) reads its four values from there -- every element of the
+// map is fetched once, whatever the per-joint reduction needs.  MODE bits: 1 = online-softmax partials of offset2joint_softmax
+// (util/feature_tool.py:41-65) per (image, chunk, joint), merged by head_finish_kernel; 2 = GT map + dense Huber value and gradient
+// (util/feature_tool.py:12-39, model/loss.py:8-25), written in place into the tile and streamed out as the NHWC gradient;
+// 4 = the head's backward (closed form, see head_bwd_kernel) added onto that gradient.  One launch does 1|2 (coord_weight == 0: the
+// reference default) -- the dense map is read ONCE per step -- or 1, then 2|4 once the joints exist.
+constexpr int TPX = 64;      // pixels per tile
+
+struct nhwc_args {
+    const float* pred;       // (B, P, Cp)
+    const float* img;        // (B, 1, H, H)
+    const float* jt_gt;      // (B, J, 3)     MODE & 2
+    const float* jt;         // (B, J, 3)     MODE & 4: the head's output
+    const float* stat;       // (B, J, 2)     MODE & 4: softmax max / sum
+    const float* g_jt;       // (B, J, 3)     MODE & 4: upstream gradient
+    float* partial;          // (B, chunks, J, 5)   MODE & 1
+    float* grad;             // (B, P, Cp)    MODE & 6
+    double* acc;             // dense-loss accumulator   MODE & 2
+    int J, F, H, Cp, tiles_per_wg;
+    float ks, delta, gscale;
+    double lscale;
+    int fixed_point;
+};
+
+template <int JS, int MODE>
+__global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
+    constexpr int NS = 256 / JS;          // pixel slots per pass
+    constexpr int PPT = TPX / NS;         // pixels per thread per tile
+    constexpr int NLMAX = JS / 4;         // float4 loads per thread per tile: 64 * Cp / 4 / 256 = Cp / 16 <= 4 JS / 16
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pitch = a.Cp + 4;
+    float* const tile = smem;                    // [TPX][pitch]
+    float* const dtile = smem + TPX * pitch;     // [TPX] depth of the tile's pixels
+    const int tid = threadIdx.x, j = tid % JS, slot = tid / JS;
+    const int b = blockIdx.y, chunk = blockIdx.x, J = a.J, F = a.F, P = F * F;
+    const bool active = j < J;
+    const int rs = a.H / F;
+    const int NL = a.Cp >> 4, C4 = a.Cp >> 2;
+    const int tile0 = chunk * a.tiles_per_wg;
+    int ntile = P / TPX - tile0;
+    if (ntile > a.tiles_per_wg) ntile = a.tiles_per_wg;
+    const float* src = a.pred + ((int64_t)b * P + (int64_t)tile0 * TPX) * a.Cp;
+    float* dst = (MODE & 6) ? a.grad + ((int64_t)b * P + (int64_t)tile0 * TPX) * a.Cp : nullptr;
+    const float* dimg = a.img + (int64_t)b * a.H * a.H;
+
+    // per-(image, joint) constants
+    float gj0 = 0.f, gj1 = 0.f, gj2 = 0.f;                 // GT joint
+    float mx = 0.f, inv_s = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (active) {
+        const int bj = b * J + j;
+        if (MODE & 2) { gj0 = a.jt_gt[bj * 3]; gj1 = a.jt_gt[bj * 3 + 1]; gj2 = a.jt_gt[bj * 3 + 2]; }
+        if (MODE & 4) {
+            mx = a.stat[2 * bj]; inv_s = 1.0f / a.stat[2 * bj + 1];
+            g0 = a.g_jt[bj * 3]; g1 = a.g_jt[bj * 3 + 1]; g2 = a.g_jt[bj * 3 + 2];
+            o0 = a.jt[bj * 3]; o1 = a.jt[bj * 3 + 1]; o2 = a.jt[bj * 3 + 2];
+        }
+    }
+    SoftAcc sa = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+
+    float4 r[NLMAX];
+    float rd = 0.f;
+    auto request = [&](int t) {       // tile t of this workgroup: 64 * Cp contiguous floats + the 64 depth samples
+        const float* s = src + (int64_t)t * TPX * a.Cp;
+#pragma unroll
+        for (int i = 0; i < NLMAX; ++i)
+            if (i < NL) r[i] = ld4(s + ((int64_t)(tid + 256 * i) << 2));
+        if (tid < TPX) {
+            const int p = (tile0 + t) * TPX + tid, y = p / F, x = p - y * F;
+            rd = dimg[(int64_t)y * rs * a.H + x * rs];
+        }
+    };
+    if (ntile > 0) request(0);
+    for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+        for (int i = 0; i < NLMAX; ++i)
+            if (i < NL) {
+                const int e = tid + 256 * i, px = e / C4, c4 = e - px * C4;
+                st4(tile + px * pitch + 4 * c4, r[i]);
+            }
+        if (tid < TPX) dtile[tid] = rd;
+        __syncthreads();
+        if (t + 1 < ntile) request(t + 1);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = slot + NS * k;
+                const int p = (tile0 + t) * TPX + px, y = p / F, x = p - y * F;
+                const float d = dtile[px], cx = grid_coord(x, F), cy = grid_coord(y, F);
+                float* row = tile + px * pitch;
+                const float v0 = row[3 * j], v1 = row[3 * j + 1], v2 = row[3 * j + 2], hraw = row[3 * J + j];
+                const float mk = d < kDepthBg ? 1.f : 0.f;
+                const float h = hraw * mk;             // masked pixels keep logit 0 (feature_tool.py:59-60)
+                const float dis = ks_dis(a.ks, h);
+                if (MODE & 1) {
+                    const float l = h * kBeta;
+                    if (l > sa.m) {
+                        const float sc = (sa.m == -INFINITY) ? 0.f : expf(sa.m - l);
+                        sa.s *= sc; sa.a0 *= sc; sa.a1 *= sc; sa.a2 *= sc;
+                        sa.m = l;
+                    }
+                    const float e = expf(l - sa.m);
+                    sa.s += e;
+                    sa.a0 += (v0 * mk * dis + cx) * e;
+                    sa.a1 += (v1 * mk * dis + cy) * e;
+                    sa.a2 += (v2 * mk * dis + d) * e;
+                }
+                if (MODE & 6) {
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f, qh = 0.f;
+                    if (MODE & 2) {       // util/feature_tool.py:29-39, operation for operation (gt_map4)
+                        const float e0 = gj0 - cx, e1 = gj1 - cy, e2 = gj2 - d;
+                        const float dist = sqrtf(((e0 * e0 + e1 * e1) + e2 * e2) + 1e-8f);
+                        const float hm = (a.ks - dist) / a.ks;
+                        const float gm = (hm >= 0.f ? 1.f : 0.f) * mk;
+                        const float z0 = v0 - e0 / dist * gm, z1 = v1 - e1 / dist * gm, z2 = v2 - e2 / dist * gm, zh = hraw - hm * gm;
+                        lsum += huber_val(z0, a.delta); lsum += huber_val(z1, a.delta); lsum += huber_val(z2, a.delta); lsum += huber_val(zh, a.delta);
+                        q0 = huber_grad(z0, a.delta) * a.gscale; q1 = huber_grad(z1, a.delta) * a.gscale;
+                        q2 = huber_grad(z2, a.delta) * a.gscale; qh = huber_grad(zh, a.delta) * a.gscale;
+                    }
+                    if (MODE & 4) {       // head_bwd_kernel's closed form
+                        const float w = expf(h * kBeta - mx) * inv_s;
+                        const float a0 = v0 * mk, a1 = v1 * mk, a2 = v2 * mk;
+                        const float wd = w * dis * mk;
+                        const float t0 = -a.ks * a0 + kBeta * (a0 * dis + cx - o0);
+                        const float t1 = -a.ks * a1 + kBeta * (a1 * dis + cy - o1);
+                        const float t2 = -a.ks * a2 + kBeta * (a2 * dis + d - o2);
+                        q0 += g0 * wd; q1 += g1 * wd; q2 += g2 * wd;
+                        qh += mk * w * (g0 * t0 + g1 * t1 + g2 * t2);
+                    }
+                    row[3 * j] = q0; row[3 * j + 1] = q1; row[3 * j + 2] = q2; row[3 * J + j] = qh;
+                }
+            }
+        }
+        if (MODE & 6) {       // the tile now holds the gradient (padding channels: the map's own zeros): stream it out
+            __syncthreads();
+            float* o = dst + (int64_t)t * TPX * a.Cp;
+#pragma unroll
+            for (int i = 0; i < NLMAX; ++i)
+                if (i < NL) {
+                    const int e = tid + 256 * i, px = e / C4, c4 = e - px * C4;
+                    st4(o + ((int64_t)e << 2), ld4(tile + px * pitch + 4 * c4));
+                }
+        }
+        __syncthreads();
+    }
+    if (MODE & 1) {
+        // lanes j, j + JS, ... of a wave hold partials of the same joint: fold them, then the four waves through LDS
+#pragma unroll
+        for (int o = 32; o >= JS; o >>= 1) {
+            SoftAcc other;
+            other.m = __shfl_xor(sa.m, o, 64); other.s = __shfl_xor(sa.s, o, 64);
+            other.a0 = __shfl_xor(sa.a0, o, 64); other.a1 = __shfl_xor(sa.a1, o, 64); other.a2 = __shfl_xor(sa.a2, o, 64);
+            sa = combine(sa, other);
+        }
+        SoftAcc* part = reinterpret_cast<SoftAcc*>(smem);      // [4][JS] (the tile is dead)
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < JS) part[wave * JS + lane] = sa;
+        __syncthreads();
+        if (tid < JS && tid < J) {
+            SoftAcc tacc = part[tid];
+            if (JS < 64) {
+#pragma unroll
+                for (int w = 1; w < 4; ++w) tacc = combine(tacc, part[w * JS + tid]);
+            } else {
+                tacc = combine(combine(part[tid], part[JS + tid]), combine(part[2 * JS + tid], part[3 * JS + tid]));
+            }
+            float* o = a.partial + (((int64_t)b * gridDim.x + chunk) * J + tid) * 5;
+            o[0] = tacc.m; o[1] = tacc.s; o[2] = tacc.a0; o[3] = tacc.a1; o[4] = tacc.a2;
+        }
+        __syncthreads();
+    }
+    if (MODE & 2) block_accumulate((double)lsum, a.lscale, a.acc, a.fixed_point);
+}
+
+// merge the per-chunk softmax partials -> joints (B, J, 3) + (max, sum) for the backward; optionally the coordinate Huber loss
+// (train.py:125: crit(jt_uvd_pred, jt_uvd_gt)) and its gradient w.r.t. the joints
+__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ partial, int chunks, int J, int BJ, const float* __restrict__ jt_gt,
+                                                          float delta, float gscale, double lscale, float* __restrict__ jt, float* __restrict__ stat,
+                                                          float* __restrict__ g_jt, double* __restrict__ acc, int fixed_point) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double local = 0.0;
+    if (i < BJ) {
+        const int b = i / J, j = i - b * J;
+        SoftAcc t = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < chunks; ++c) {
+            const float* q = partial + (((int64_t)b * chunks + c) * J + j) * 5;
+            SoftAcc o = {q[0], q[1], q[2], q[3], q[4]};
+            t = combine(t, o);
+        }
+        const float out[3] = {t.a0 / t.s, t.a1 / t.s, t.a2 / t.s};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jt[i * 3 + c] = out[c];
+        if (stat) { stat[2 * i] = t.m; stat[2 * i + 1] = t.s; }
+        if (acc) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float z = out[c] - jt_gt[i * 3 + c];
+                local += (double)huber_val(z, delta);
+                if (g_jt) g_jt[i * 3 + c] = huber_grad(z, delta) * gscale;
+            }
+        }
+    }
+    if (acc) block_accumulate(local, lscale, acc, fixed_point);
+}
+
 __global__ void zero_f64_kernel(double* p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -309,7 +533,11 @@ __global__ void loss_finalize_kernel(const double* acc, int n, float* out, int f
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < n; ++i) {
-            const double v = fixed_point ? (double)reinterpret_cast<const long long*>(acc)[i] / LOSS_FIX : acc[i];
+            double v = acc[i];
+            if (fixed_point) {
+                const unsigned long long q = reinterpret_cast<const unsigned long long*>(acc)[i];
+                v = (q & (1ULL << 61)) ? (double)NAN : (q >> 62) ? (double)INFINITY : (double)(long long)q / LOSS_FIX;
+            }
             out[i] = (float)v;
             t += v;
         }
@@ -365,6 +593,16 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }  // namespace awr
 
 using namespace awr;
+
+template <int MODE>
+static int launch_dense_nhwc(const nhwc_args& a, int B, int chunks, hipStream_t st) {
+    const dim3 grid((unsigned)chunks, (unsigned)B);
+    const size_t lds = (size_t)(TPX * (a.Cp + 4) + TPX) * sizeof(float);
+    if (a.J <= 16) hipLaunchKernelGGL((dense_nhwc_kernel<16, MODE>), grid, dim3(256), lds, st, a);
+    else if (a.J <= 32) hipLaunchKernelGGL((dense_nhwc_kernel<32, MODE>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((dense_nhwc_kernel<64, MODE>), grid, dim3(256), lds, st, a);
+    return check_launch("dense_nhwc_kernel");
+}
 
 extern "C" {
 
@@ -430,6 +668,74 @@ int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* im
     hipLaunchKernelGGL(dense_loss_kernel, dim3((P / 4 + 255) / 256, B * J), dim3(256), 0, as_stream(stream), offset_pred, jt_gt, img,
                        J, F, H, ks, delta, (float)((double)weight / n), (double)weight / n, acc, g_offset, accumulate, awr_get_deterministic());
     return check_launch("dense_loss_kernel");
+}
+
+// ---- NHWC forms ------------------------------------------------------------------------------------------------------
+static int nhwc_geometry(int B, int J, int F, int H, int Cp, int* chunks, int* tiles_per_wg) {
+    if (int e = check_head_dims(B, J, F, H)) return e;
+    AWR_REQUIRE(J <= 64, "head (NHWC): at most 64 joints (got %d)", J);
+    AWR_REQUIRE(Cp >= 4 * J && Cp % 32 == 0 && Cp <= 256, "head (NHWC): Cp=%d must be a multiple of 32 in [4J, 256]", Cp);
+    AWR_REQUIRE(Cp <= 4 * (J <= 16 ? 16 : J <= 32 ? 32 : 64), "head (NHWC): Cp=%d too wide for %d joints (expected 4J rounded up to 32)", Cp, J);
+    const int P = F * F;
+    AWR_REQUIRE(P % TPX == 0, "head (NHWC): F*F must be a multiple of %d", TPX);
+    const int tiles = P / TPX;
+    // ~2048 workgroups per launch (8 per CU), at least one tile and at most 16 tiles per workgroup
+    int per = 1;
+    while (per < 16 && per * 2 <= tiles && (int64_t)B * (tiles / (per * 2)) >= 2048) per *= 2;
+    if ((int64_t)B * tiles <= 2048) per = 1;
+    *tiles_per_wg = per;
+    *chunks = (tiles + per - 1) / per;
+    return AWR_OK;
+}
+
+int64_t awr_head_nhwc_scratch(int B, int J, int F) {
+    if (B <= 0 || J <= 0 || F <= 0) return 0;
+    return (int64_t)B * ((int64_t)F * F / TPX + 1) * J * 5;      // floats: one partial per (image, tile, joint) at most
+}
+
+int awr_head_forward_nhwc(const float* pred, int Cp, const float* img, int B, int J, int F, int H, float ks, float* scratch, float* jt,
+                          float* stat, void* stream) {
+    AWR_REQUIRE(pred && img && scratch && jt, "head_forward_nhwc: null pointer");
+    int chunks, per;
+    if (int e = nhwc_geometry(B, J, F, H, Cp, &chunks, &per)) return e;
+    nhwc_args a;
+    memset(&a, 0, sizeof a);
+    a.pred = pred; a.img = img; a.partial = scratch; a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks;
+    hipStream_t st = as_stream(stream);
+    if (int e = launch_dense_nhwc<1>(a, B, chunks, st)) return e;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 255) / 256), dim3(256), 0, st, scratch, chunks, J, B * J, nullptr, 0.f, 0.f, 0.0, jt, stat,
+                       nullptr, nullptr, 0);
+    return check_launch("head_finish_kernel");
+}
+
+int awr_head_loss_step_nhwc(const float* pred, int Cp, const float* img, const float* jt_gt, int B, int J, int F, int H, float ks, float delta,
+                            float coord_weight, float dense_weight, float* scratch, float* jt, float* stat, float* g_jt, double* acc, float* grad,
+                            void* stream) {
+    AWR_REQUIRE(pred && img && jt_gt && scratch && jt && stat && acc && grad, "head_loss_step_nhwc: null pointer");
+    AWR_REQUIRE(coord_weight == 0.f || g_jt, "head_loss_step_nhwc: a coordinate loss needs the g_jt buffer");
+    int chunks, per;
+    if (int e = nhwc_geometry(B, J, F, H, Cp, &chunks, &per)) return e;
+    const int P = F * F;
+    const double nd = (double)B * 4.0 * J * P, nc = (double)B * J * 3.0;
+    const int fixed = awr_get_deterministic();
+    nhwc_args a;
+    memset(&a, 0, sizeof a);
+    a.pred = pred; a.img = img; a.jt_gt = jt_gt; a.partial = scratch; a.grad = grad; a.acc = acc + 1;
+    a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks; a.delta = delta;
+    a.gscale = (float)((double)dense_weight / nd); a.lscale = (double)dense_weight / nd; a.fixed_point = fixed;
+    hipStream_t st = as_stream(stream);
+    const bool coord = coord_weight != 0.f;
+    // coord_weight == 0 (config.py:41, the reference default): ONE pass over the map does the softmax partials, the dense loss and its
+    // gradient; otherwise the joints have to exist before the head's backward can run: partials -> finish -> dense loss + head backward
+    if (int e = coord ? launch_dense_nhwc<1>(a, B, chunks, st) : launch_dense_nhwc<3>(a, B, chunks, st)) return e;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 255) / 256), dim3(256), 0, st, scratch, chunks, J, B * J, jt_gt, delta,
+                       (float)((double)coord_weight / nc), (double)coord_weight / nc, jt, stat, coord ? g_jt : nullptr, acc, fixed);
+    if (int e = check_launch("head_finish_kernel")) return e;
+    if (coord) {
+        a.jt = jt; a.stat = stat; a.g_jt = g_jt;
+        if (int e = launch_dense_nhwc<6>(a, B, chunks, st)) return e;
+    }
+    return AWR_OK;
 }
 
 int awr_huber(const float* x, const float* y, int64_t n, float delta, float weight, double* acc, float* gx, int accumulate,

@@ -14,6 +14,7 @@
 // awr_bn_*, awr_stem_*, ...) and the HIP runtime for memory, streams and events.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -22,6 +23,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -582,6 +584,7 @@ struct Op {
     int sid = 0;              // fork / join stream id
     bool side_ok = false;     // weight-gradient launch that may run on a side stream
     bool gemm = false;        // conv / stem family (timed by run_timed)
+    bool boundary = false;    // NCHW <-> NHWC bridge at the reference boundary: skipped while the plan's NHWC boundary is on
     double macs = 0.0;
 };
 
@@ -622,8 +625,9 @@ struct awr_plan {
     int64_t bytes = 0;
     float* img = nullptr;
     std::vector<float*> outputs, grad_outs;
-    std::vector<Tn*> head_preds;
-    std::vector<bool> head_used;
+    std::vector<Tn*> head_preds;               // per stage: the head GEMM's NHWC output
+    std::vector<float*> head_grads;            // per stage: NHWC buffer the backward reads d(pred) from (nullptr: second producer)
+    bool nhwc_boundary = false;
     // wgrad split-K scratch arena
     float* scratch = nullptr;
     int64_t scratch_used = 0, scratch_cap = 0;
@@ -944,6 +948,7 @@ struct Builder {
             int ns = 0;
             NET_CHECK(awr_conv_wgrad_splits(wa, &ns));
             nsum = ns; rstride = (int)rsize; bslots = ns; bstride = wp.Cd;
+            wa->max_split = ns;      // the copies that exist: a later tile / target change can never make the kernel write beyond them
             R = alloc<float>((int64_t)nsum * rsize);
             if (fused_bias) bsum = alloc<float>((int64_t)nsum * wp.Cd);
         } else {
@@ -1208,11 +1213,13 @@ struct Builder {
         const int B = pred->B, F = pred->H, Cp = pred->C;
         {
             const float* pb = pred->buf;
-            f("awr_nhwc_to_nchw", [=](void* s) { return awr_nhwc_to_nchw(pb, B, F * F, Cp, 4 * J, out, s); });
+            f("awr_nhwc_to_nchw", [=](void* s) { return awr_nhwc_to_nchw(pb, B, F * F, Cp, 4 * J, out, s); }).boundary = true;
         }
         const int stage = (int)P.outputs.size();
         P.outputs.push_back(out);
         P.grad_outs.push_back(gout);
+        P.head_preds.push_back(pred);
+        P.head_grads.push_back(nullptr);
         if (P.training) {
             P.nodes.push_back([=]() {
                 if (!(P.supervised & (1u << stage))) return (int)AWR_OK;   // no loss on this stage (hourglass: only the last stage, train.py:116-121)
@@ -1224,7 +1231,8 @@ struct Builder {
                     b("awr_nchw_to_nhwc", [=](void* s) { return awr_nchw_to_nhwc(gout, B, F * F, Cp, 4 * J, tmp, s); });
                     b("awr_add", [=](void* s) { return awr_add(g, tmp, g, n, s); });
                 } else {
-                    b("awr_nchw_to_nhwc", [=](void* s) { return awr_nchw_to_nhwc(gout, B, F * F, Cp, 4 * J, g, s); });
+                    b("awr_nchw_to_nhwc", [=](void* s) { return awr_nchw_to_nhwc(gout, B, F * F, Cp, 4 * J, g, s); }).boundary = true;
+                    P.head_grads[stage] = g;      // the only producer: a caller on the NHWC boundary writes d(pred) here itself
                 }
                 return err;
             });
@@ -1469,7 +1477,8 @@ struct NetBuilder {
 
     DualLayer* dual_for(const std::string& p) {
         // conv3 + skip_layer as one launch: FP32-MFMA mode only (the split-operand kernels take one input tensor)
-        if (awr_get_gemm_products() != 1 || !N.convs.count(p + ".skip_layer")) return nullptr;
+        static const bool no_dual = getenv("AWR_NO_DUAL") != nullptr;      // bisecting hook (tools/diag_parity.py)
+        if (no_dual || awr_get_gemm_products() != 1 || !N.convs.count(p + ".skip_layer")) return nullptr;
         DualLayer& d = N.duals[p];
         if (!d.c3) {
             d.c3 = C(p + ".conv3");
@@ -1667,6 +1676,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     bool pending = false, handed = false;
     size_t nside = 0;
     void* cur = stream;
+    bool after_join = false;
     auto hand_off = [&]() -> int {       // everything the bucket needs (main chain so far + weight gradients) -> comm stream
         NET_CHECK(stream_wait(P, comm, main));
         for (auto st : P.side)
@@ -1675,6 +1685,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         return AWR_OK;
     };
     for (auto& op : ops) {
+        if (op.boundary && P.nhwc_boundary) continue;
         if (comm && op.kind == OP_CALL && op.name == "awr_unpack_wgrads_batched") {
             NET_CHECK(hand_off());
             handed = true;
@@ -1696,6 +1707,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
                 for (auto st : P.side) NET_CHECK(stream_wait(P, main, st));
                 for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
                 pending = false;
+                after_join = true;      // ... and issue it on MAIN: inside an open fork region `cur` is a branch stream that did not wait
             }
         }
         switch (op.kind) {
@@ -1732,8 +1744,9 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
             rc = op.fn((void*)st);
             pending = true;
         } else {
-            rc = op.fn(cur);
+            rc = op.fn(after_join ? stream : cur);
         }
+        after_join = false;
         if (rc) return rc;
     }
     if (wside && (pending || comm)) {
@@ -1753,7 +1766,7 @@ static int run_timed(awr_plan& P, std::vector<Op>& ops, void* stream, float* ms)
         Op& op = ops[i];
         if (op.kind == OP_ZERO) { if (hipMemsetAsync(op.p, 0, op.bytes, main) != hipSuccess) rc = AWR_ERR_HIP; continue; }
         if (op.kind == OP_COPY) { if (hipMemcpyAsync(op.p, op.q, op.bytes, hipMemcpyDeviceToDevice, main) != hipSuccess) rc = AWR_ERR_HIP; continue; }
-        if (op.kind != OP_CALL) continue;
+        if (op.kind != OP_CALL || (op.boundary && P.nhwc_boundary)) continue;
         if (op.gemm) {
             (void)hipEventCreate(&ev[i].first);
             (void)hipEventCreate(&ev[i].second);
@@ -1993,6 +2006,43 @@ int awr_plan_bucket(const awr_plan* p, int i, int64_t* lo, int64_t* hi, int* rea
     return AWR_OK;
 }
 
+int awr_plan_head_nhwc(const awr_plan* p, int stage, const float** pred, float** grad, int* Cp) {
+    AWR_REQUIRE(p && stage >= 0 && stage < (int)p->head_preds.size(), "plan_head_nhwc: stage out of range");
+    if (pred) *pred = p->head_preds[stage]->buf;
+    if (grad) *grad = p->head_grads[stage];
+    if (Cp) *Cp = p->head_preds[stage]->C;
+    return AWR_OK;
+}
+
+int awr_plan_set_nhwc_boundary(awr_plan* p, int on) {
+    AWR_REQUIRE(p, "plan_set_nhwc_boundary: null pointer");
+    if (on && p->training) {
+        for (size_t s = 0; s < p->head_grads.size(); ++s)
+            if ((p->supervised & (1u << s)) && !p->head_grads[s]) {
+                set_error("plan_set_nhwc_boundary: the gradient of stage %d has a second producer inside the network (a later stack reads the prediction): "
+                          "it has to be accumulated through grad_outs", (int)s);
+                return AWR_ERR_UNSUPPORTED;
+            }
+    }
+    p->nhwc_boundary = on != 0;
+    return AWR_OK;
+}
+
+int awr_plan_tensor(const awr_plan* p, int i, const char** name, int dims[4], float** buf, float** grad, int* lazy, const float** lz_scale,
+                    const float** lz_shift) {
+    AWR_REQUIRE(p, "plan_tensor: null pointer");
+    if (i < 0 || i >= (int)p->tensors.size()) return AWR_ERR_ARG;      // (no error string: callers iterate until this)
+    const Tn& t = p->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (dims) { dims[0] = t.B; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+    if (buf) *buf = t.buf;
+    if (grad) *grad = t.grad;
+    if (lazy) *lazy = t.lazy ? (t.lz_relu ? 2 : 1) : 0;
+    if (lz_scale) *lz_scale = t.lz_scale;
+    if (lz_shift) *lz_shift = t.lz_shift;
+    return AWR_OK;
+}
+
 int awr_plan_op(const awr_plan* p, int list, int i, const char** name, double* macs, int* flags) {
     AWR_REQUIRE(p && (list == 0 || list == 1), "plan_op: list must be 0 (forward) or 1 (backward)");
     const auto& v = list ? p->bwd : p->fwd;
@@ -2039,10 +2089,15 @@ struct StreamPool {
 };
 
 static StreamPool& stream_pool() {
-    static StreamPool pool;
-    static bool built = false;
-    if (built) return pool;
-    built = true;
+    // one pool per HIP device (streams belong to the device that was current when they were created), built once under a lock
+    static std::map<int, StreamPool> pools;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    auto it = pools.find(devid);
+    if (it != pools.end()) return it->second;
+    StreamPool& pool = pools[devid];
     const int NC = 8;
     std::vector<hipStream_t> cand;
     for (int i = 0; i < NC; ++i) {
@@ -2090,14 +2145,15 @@ int awr_plan_set_streams(awr_plan* p, int n_side, int comm) {
         if (p->comm_owned) (void)hipStreamDestroy(p->comm);
         p->comm = nullptr;
     }
-    StreamPool& sp = stream_pool();
-    AWR_REQUIRE((int)sp.ordered.size() >= n_side + 2 || n_side == 0, "plan_set_streams: could not create the library's streams");
-    for (int i = 0; i < n_side; ++i) p->side.push_back(sp.ordered[i]);
+    StreamPool& sp = stream_pool();      // (the pool of the CURRENT device: call with the plan's device current, like every other entry point)
     // branch streams only for plans whose backward forks (every stream beyond the device's few hardware queues shares one with another
     // stream and serialises with it: measured on the data-parallel ResNet18 step, whose comm stream is the fourth)
     int nfork = 0;
     for (auto& op : p->bwd) nfork += op.kind == OP_FORK ? 1 : 0;
-    for (int i = 0; i < (n_side > 0 && nfork > 0 ? 2 : 0); ++i) p->branch.push_back(sp.ordered[n_side + i]);
+    const int nbranch = n_side > 0 && nfork > 0 ? 2 : 0;
+    AWR_REQUIRE((int)sp.ordered.size() >= n_side + nbranch, "plan_set_streams: could not create the library's streams");
+    for (int i = 0; i < n_side; ++i) p->side.push_back(sp.ordered[i]);
+    for (int i = 0; i < nbranch; ++i) p->branch.push_back(sp.ordered[n_side + i]);
     // the "comm stream" buckets are handed to is the LAST side stream when there is one: a bucket's scatter has to wait for the weight
     // gradients on it anyway, and a stream of its own would be one too many for the hardware queues -- the collective itself runs on
     // the communication library's stream behind an event
@@ -2161,6 +2217,7 @@ int awr_plan_set_gemm(awr_plan* p, int i, int tile_m, int tile_n, int target_blo
     AWR_REQUIRE(p && i >= 0 && i < (int)p->gemms.size(), "plan_set_gemm: index out of range");
     AWR_REQUIRE((tile_m == 1 || tile_m == 2) && (tile_n == 1 || tile_n == 2) && target_blocks >= 0, "plan_set_gemm: tiles in {1,2}");
     GemmRef& g = p->gemms[i];
+    AWR_REQUIRE(!(p->det && g.wa), "plan_set_gemm: a deterministic plan sizes the per-chunk copies of its weight gradients for the default geometry");
     if (g.ca) {
         g.ca->tile_m = tile_m; g.ca->tile_n = tile_n;
         if (target_blocks && g.ca->partial && target_blocks <= g.ca->split_max) g.ca->split_k = target_blocks;      // conv launches: split-K depth

@@ -114,10 +114,63 @@ class Plan:
                     self._side_ok.add(nm)
         self.tuned = {}
         self.n_side, self._hook, self._cb = 0, None, None
+        self.nhwc, self._hook_exc = False, None
 
     # ---- introspection ---------------------------------------------------------------------------------------
     def op_names(self, which):
         return [n for n, _ in self._ops[0 if which in (0, "fwd", "forward") else 1]]
+
+    def tensors(self, lazy=False):
+        """Parity / debugging introspection (awr_plan_tensor): {name: (value, grad or None)} torch views (NHWC, no copy) of the plan's
+        activation buffers in build order.  "<layer>.out" is a conv's raw output (before its BatchNorm).  lazy=True: also the
+        BatchNorm(+ReLU) outputs that are never written -- {name: (value buffer of the tensor they normalise, None, scale[C], shift[C],
+        relu)}: the tensor they stand for is [relu](value * scale + shift).  Gradients are what the last backward replay left behind."""
+        out, i = {}, 0
+        name, lz = C.c_char_p(), C.c_int()
+        dims = (C.c_int * 4)()
+        buf, grad, sc, sh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+
+        def view(p, shape):
+            n = 1
+            for d in shape:
+                n *= d
+            holder = type("DevMem", (), {"__cuda_array_interface__": {"shape": (n,), "typestr": "<f4", "data": (p, False), "version": 2}})()
+            return torch.as_tensor(holder, device=self.dev).view(*shape)
+        while L.lib.awr_plan_tensor(self.h, i, C.byref(name), dims, C.byref(buf), C.byref(grad), C.byref(lz), C.byref(sc), C.byref(sh)) == 0:
+            i += 1
+            if not buf.value:
+                continue
+            shape = tuple(dims)
+            if lz.value:
+                if lazy:
+                    out[name.value.decode()] = (view(buf.value, shape), None, view(sc.value, shape[3:]), view(sh.value, shape[3:]), lz.value == 2)
+                continue
+            out[name.value.decode()] = (view(buf.value, shape), view(grad.value, shape) if grad.value else None)
+        return out
+
+    # ---- NHWC boundary ----------------------------------------------------------------------------------------
+    def head_nhwc(self, stage):
+        """(pred pointer, gradient pointer or None, Cp): stage's dense map as the head GEMM leaves it, (B, F*F, Cp) rows."""
+        pred, grad, cp = C.c_void_p(), C.c_void_p(), C.c_int()
+        L.call("awr_plan_head_nhwc", self.h, int(stage), C.byref(pred), C.byref(grad), C.byref(cp))
+        return pred.value, grad.value, cp.value
+
+    def set_nhwc_boundary(self, on):
+        """on: the plan stops transposing to / from the NCHW boundary tensors (`outputs` / `grad_outs` are then neither written nor
+        read); the caller runs the NHWC head / loss kernels on head_nhwc()'s buffers.  Returns False when the plan cannot serve it
+        (a supervised stage whose gradient has a second producer inside the network)."""
+        if L.lib.awr_plan_set_nhwc_boundary(self.h, int(bool(on))) != 0:
+            return False
+        self.nhwc = bool(on)
+        return True
+
+    def dense_map(self, stage):
+        """The reference-layout (B, 4J, F, F) dense map of `stage` (transposed on demand while the NHWC boundary is on)."""
+        out = self.outputs[stage]
+        if self.nhwc:
+            pred, _, cp = self.head_nhwc(stage)
+            L.call("awr_nhwc_to_nchw", pred, self.B, out.shape[2] * out.shape[3], cp, out.shape[1], L.ptr(out), L.stream())
+        return out
 
     # ---- streams / buckets -----------------------------------------------------------------------------------
     def set_streams(self, n_side, comm=False):
@@ -142,11 +195,19 @@ class Plan:
             return
 
         def trampoline(user, lo, hi, stream):
-            if (stream or 0) == L.stream():          # the stream the plan is being replayed on: torch is already there
-                fn(lo, hi)
-            else:                                     # the plan's comm stream
-                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.dev)):
+            # ctypes swallows exceptions raised inside a callback (it prints "Exception ignored" and the native replay carries on): a
+            # failed collective would leave this bucket un-reduced and the replicas would silently diverge.  Stash the first error;
+            # run_backward() re-raises it once the native call has returned.
+            if self._hook_exc is not None:
+                return
+            try:
+                if (stream or 0) == L.stream():          # the stream the plan is being replayed on: torch is already there
                     fn(lo, hi)
+                else:                                     # the plan's comm stream
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.dev)):
+                        fn(lo, hi)
+            except BaseException as e:                    # noqa: BLE001 -- anything: it must not be lost
+                self._hook_exc = e
         self._cb = L.BUCKET_CB(trampoline)          # keep the ctypes thunk alive as long as the plan may call it
         L.call("awr_plan_set_bucket_callback", self.h, C.cast(self._cb, C.c_void_p), None)
 
@@ -158,7 +219,11 @@ class Plan:
         L.call("awr_plan_forward", self.h, L.stream())
 
     def run_backward(self):
+        self._hook_exc = None
         L.call("awr_plan_backward", self.h, L.stream())
+        if self._hook_exc is not None:
+            e, self._hook_exc = self._hook_exc, None
+            raise L.AwrError("gradient-bucket hook failed during the backward replay (the bucket was NOT reduced): %r" % (e,)) from e
 
     def forward(self):
         self.run_forward()

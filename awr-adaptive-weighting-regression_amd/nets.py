@@ -193,6 +193,8 @@ class _BackboneFn(torch.autograd.Function):
         # training forwards always re-pack (one batched launch): the weights normally changed since the last step, and a
         # missed update (e.g. through `p.data`) would silently train on stale packed copies
         net.sync_weights(plan, force=plan.training)
+        if plan.nhwc:                        # an engine shared this plan and left it on the NHWC boundary: the module returns NCHW maps
+            plan.set_nhwc_boundary(False)
         plan.img.copy_(x.detach().float())
         plan.forward()
         if plan.training:
@@ -209,6 +211,8 @@ class _BackboneFn(torch.autograd.Function):
             raise L.AwrError("backward through an eval-mode forward: call net.train() (the inference plan keeps no activations)")
         if plan.gen != ctx.gen:
             raise L.AwrError("backward after a newer forward of the same (batch, size): saved activations were overwritten")
+        if plan.nhwc:
+            plan.set_nhwc_boundary(False)
         for buf, g in zip(plan.grad_outs, gouts):
             if g is None:
                 buf.zero_()

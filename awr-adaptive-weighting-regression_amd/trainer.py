@@ -63,7 +63,7 @@ class GradSync:
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
-                 _share=None):
+                 nhwc_boundary=None, trace_buckets=False, _share=None):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -82,6 +82,14 @@ class TrainEngine:
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data
         # parallel: one more stream that finished gradient buckets (scatter + all-reduce) are handed to
         self.plan.set_streams(wgrad_streams, comm=(wgrad_streams > 0 and self.dp))
+        # head + losses on the backbone's own NHWC layout (no transposes at the boundary, the dense map read once per step when
+        # coord_weight == 0); AWR_NCHW_BOUNDARY=1 / nhwc_boundary=False keeps the reference-layout kernels (same-box A/B)
+        import os as _os
+        want_nhwc = (_os.environ.get("AWR_NCHW_BOUNDARY") != "1") if nhwc_boundary is None else bool(nhwc_boundary)
+        self.nhwc = want_nhwc and self.plan.set_nhwc_boundary(True)
+        if self.nhwc:
+            self._pred, self._gpred, self._cp = self.plan.head_nhwc(self.stage)
+            self._scratch = torch.zeros(int(L.lib.awr_head_nhwc_scratch(batch_size, self.J, self.F)), device=dev)
         self._autotune = bool(autotune)
         self._compiled = False
         self.jt_gt = torch.zeros(batch_size, self.J, 3, device=dev)
@@ -104,6 +112,7 @@ class TrainEngine:
         self._n_buckets = n_buckets
         self.world = self.sync.world
         self._works = []
+        self.trace_buckets, self._trace, self._tev = bool(trace_buckets), [], None
         if self.dp:             # identical initial parameters and BN buffers on every rank
             if _share is None:
                 self.sync.broadcast(net.flat_params(), net._barena)
@@ -112,8 +121,19 @@ class TrainEngine:
             g = net.flat_grads()
             # torch's NCCL work stream waits for the compute stream at the point of the call and runs concurrently with
             # whatever is enqueued afterwards: the rest of the backward overlaps the bucket's all-reduce over xGMI
-            self.plan.bucket_hook = lambda lo, hi: self._works.append(
-                torch.distributed.all_reduce(g[lo:hi], group=process_group, async_op=True))
+
+            def hook(lo, hi):
+                if self.trace_buckets:       # timestamps on the stream the bucket was handed to (the plan's comm stream)
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                w = torch.distributed.all_reduce(g[lo:hi], group=process_group, async_op=True)
+                self._works.append(w)
+                if self.trace_buckets:       # (tracing serialises this stream behind the collective; untraced steps do not wait here)
+                    w.wait()
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._trace.append((lo, hi, e0, e1))
+            self.plan.bucket_hook = hook
 
     # ---- the captured part: repack -> forward -> head + losses -> backward -------------------------------
     def _core(self):
@@ -122,6 +142,15 @@ class TrainEngine:
         s = L.stream()
         plan.refresh_weights()
         plan.run_forward()
+        if self.nhwc and not plan.nhwc:
+            plan.set_nhwc_boundary(True)      # (the drop-in module shares plans and switches them back to the NCHW boundary)
+        if self.nhwc:      # train.py:118-127 in one call on the NHWC map: joints, both Huber losses, d(loss)/d(map) written where the backward reads it
+            L.call("awr_zero_f64", L.ptr(self.acc), 2, s)
+            L.call("awr_head_loss_step_nhwc", self._pred, self._cp, L.ptr(plan.img), L.ptr(self.jt_gt), B, J, F, H, self.ks, HUBER_DELTA, self.cw, self.dw,
+                   L.ptr(self._scratch), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), L.ptr(self.acc), self._gpred, s)
+            L.call("awr_loss_finalize", L.ptr(self.acc), 2, L.ptr(self.losses), s)
+            plan.run_backward()
+            return
         out = plan.outputs[self.stage]
         gout = plan.grad_outs[self.stage]
         img = plan.img
@@ -138,6 +167,25 @@ class TrainEngine:
         L.call("awr_loss_finalize", L.ptr(self.acc), 2, L.ptr(self.losses), s)
         plan.run_backward()
 
+    def bucket_timeline(self):
+        """trace_buckets=True: where the gradient exchange of the LAST step sat relative to its backward -- milliseconds from the start
+        of the step (stream timestamps): {"backward_end_ms", "buckets": [{"lo", "hi", "mbytes", "start_ms", "end_ms"}], "tail_ms"}.
+        backward_end_ms is taken after the end-of-backward join (all side streams and the last bucket's exchange are in); tail_ms = the
+        time from handing the LAST bucket over to that join -- the only exchange nothing is left to overlap with; every earlier bucket
+        whose end_ms lies before the last bucket's start_ms ran entirely under the backward."""
+        if not self.trace_buckets or self._tev is None:
+            return None
+        torch.cuda.synchronize()
+        t0 = self._tev[0]
+        bk = [{"lo": lo, "hi": hi, "mbytes": round((hi - lo) * 4e-6, 2), "start_ms": round(t0.elapsed_time(e0), 3), "end_ms": round(t0.elapsed_time(e1), 3)}
+              for lo, hi, e0, e1 in self._trace]
+        end = round(t0.elapsed_time(self._tev[1]), 3)
+        return {"backward_end_ms": end, "buckets": bk, "tail_ms": round(end - bk[-1]["start_ms"], 3) if bk else 0.0}
+
+    def dense_map(self, stage=None):
+        """(B, 4J, F, F) dense map of the last step in the reference's layout."""
+        return self.plan.dense_map(self.stage if stage is None else stage)
+
     def timed_core(self):
         """The captured part once more, serially, with a HIP-event pair around every conv / stem launch (bench.py's roofline):
         -> {launch name: seconds}.  Not an optimisation step (no optimiser update)."""
@@ -145,6 +193,46 @@ class TrainEngine:
         per = self.plan.timed("fwd")
         per.update(self.plan.timed("bwd"))
         return per
+
+    def timed_hbm(self, reps=5):
+        """Serial passes with an event pair around the HBM-bound launches of the step that live outside the plan (bench.py's
+        `roofline_hbm`): the head + loss part (train.py:118-127) and the optimiser (on scratch copies: no parameter moves).
+        -> {name: seconds per call}.  Call after a step (the buffers hold real data)."""
+        B, J, F, H = self.B, self.J, self.F, self.H
+        s = L.stream()
+        plan = self.plan
+        res = {}
+
+        def t(name, fn):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) * 1e-3 / reps
+        if self.nhwc:
+            def step_nhwc():
+                L.call("awr_zero_f64", L.ptr(self.acc), 2, s)
+                L.call("awr_head_loss_step_nhwc", self._pred, self._cp, L.ptr(plan.img), L.ptr(self.jt_gt), B, J, F, H, self.ks, HUBER_DELTA, self.cw, self.dw,
+                       L.ptr(self._scratch), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), L.ptr(self.acc), self._gpred, s)
+            t("head_loss_step_nhwc", step_nhwc)
+            t("head_forward_nhwc", lambda: L.call("awr_head_forward_nhwc", self._pred, self._cp, L.ptr(plan.img), B, J, F, H, self.ks, L.ptr(self._scratch),
+                                                  L.ptr(self.jt_pred), L.ptr(self.stat), s))
+        else:
+            out, gout, img = plan.outputs[self.stage], plan.grad_outs[self.stage], plan.img
+            t("head_forward", lambda: L.call("awr_head_forward", L.ptr(out), L.ptr(img), B, J, F, H, self.ks, L.ptr(self.jt_pred), L.ptr(self.stat), s))
+            t("dense_loss", lambda: L.call("awr_dense_loss", L.ptr(out), L.ptr(self.jt_gt), L.ptr(img), B, J, F, H, self.ks, HUBER_DELTA, self.dw,
+                                           self.acc.data_ptr() + 8, L.ptr(gout), 0, s))
+            t("head_backward", lambda: L.call("awr_head_backward", L.ptr(out), L.ptr(img), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), B, J, F, H,
+                                              self.ks, L.ptr(gout), 1, s))
+        if self.opt == "adam":
+            n = self.net.n_active
+            p, g, m, v = (x[:n].clone() for x in (self.net.flat_params(), self.net.flat_grads(), self.m, self.v))
+            t("adam_step", lambda: L.call("awr_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, self.lr, 0.9, 0.999, 1e-8, self.wd, max(self.step_count, 1),
+                                          self.sync.grad_scale, s))
+        return res
 
     def _optimizer(self):
         net = self.net
@@ -185,10 +273,16 @@ class TrainEngine:
         self.jt_gt.copy_(jt_uvd_gt, non_blocking=True)
         if not self._compiled:
             self.compile()
+        if self.trace_buckets:
+            del self._trace[:]
+            self._tev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self._tev[0].record()
         if self.graph is not None:
             self.graph.replay()
         else:
             self._core()
+        if self.trace_buckets:
+            self._tev[1].record()
         self.net._counters += plan.bn_repeat          # num_batches_tracked of every BatchNorm (host side)
         if self.dp:
             for w in self._works:           # compute stream waits for the bucket all-reduces before the optimiser
@@ -293,10 +387,21 @@ class InferEngine:
         self.jt = torch.zeros(batch_size, self.J, 3, device=net.device)
         self.stage = net.nstage - 1
         self.use_graph, self.graph = use_graph, None
+        import os as _os
+        self.nhwc = _os.environ.get("AWR_NCHW_BOUNDARY") != "1" and self.plan.set_nhwc_boundary(True)
+        if self.nhwc:
+            self._pred, _, self._cp = self.plan.head_nhwc(self.stage)
+            self._scratch = torch.zeros(int(L.lib.awr_head_nhwc_scratch(batch_size, self.J, self.F)), device=net.device)
 
     def _core(self):
         plan = self.plan
+        if self.nhwc and not plan.nhwc:
+            plan.set_nhwc_boundary(True)
         plan.run_forward()
+        if self.nhwc:
+            L.call("awr_head_forward_nhwc", self._pred, self._cp, L.ptr(plan.img), self.B, self.J, self.F, self.H, self.ks, L.ptr(self._scratch),
+                   L.ptr(self.jt), None, L.stream())
+            return
         L.call("awr_head_forward", L.ptr(plan.outputs[self.stage]), L.ptr(plan.img), self.B, self.J, self.F, self.H, self.ks, L.ptr(self.jt),
                None, L.stream())
 

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- the AWR hot path on MI355X: depth-images/sec of the full train step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--net resnet_18|hourglass_1] [--graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--net resnet_18|hourglass_1] [--graph] [--dp-selftest]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 works both ways: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one rank;
+started plainly (`python bench.py --gpus 8`) it spawns the N rank processes itself, one per GPU, and relays rank 0's JSON line.
 
 Workload (BASELINE.json configs[1]): ResNet18-deconv, 128x128 depth crops, J=14, batch 64 per GPU, one full
 reference iteration per step (GT map + forward + head + dense/joint Huber + backward + Adam; train.py:107-131)
@@ -61,41 +64,58 @@ def cpu_baseline():
     """the CPU restatement of the path (oracle, kind 'port') on the host cores of the GPU box --
     (i) config 1: ResNet18-deconv, B=4, eval under no_grad, head included; (ii) the same net, B=4, one full train step
     (coord_weight 0, dense_weight 1, Adam lr 1e-3, kernel_size 1).  Synthetic inputs seed 1234, all physical cores,
-    3 warm-up iterations, median of 10.  `value` is the train step (the unit of BASELINE.json's metric)."""
+    3 warm-up iterations, median of 10.  `value` is the train step (the unit of BASELINE.json's metric).  A batch of 4 images cannot
+    feed 128 threads (the all-cores number is SLOWER than the survey's 8-vCPU container): `best_value` / `best_threads` report the
+    host's best over a {8, 16, 32, 64, all} thread sweep of the same two workloads, so the stated baseline is not a handicapped one."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import awr_oracle as O
     cores, model = _host_cpu()
     prev = torch.get_num_threads()
-    torch.set_num_threads(cores)
+    net, ks, b = "resnet_18", 1.0, 4
+    img, jt = O.synth_batch(b, 128, 14, seed=1234)
+    sd = O.reference_init_state(net, 14, seed=0)
+
+    def med(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return 0.5 * (ts[reps // 2 - 1] + ts[reps // 2]) if reps % 2 == 0 else ts[reps // 2]
+
+    def infer():
+        with torch.no_grad():
+            O.offset2joint_softmax(O.resnet18_forward(sd, img, False), img, ks)
+    ost = {"step": 0, "m": {}, "v": {}}
+
+    def train():
+        O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0)
+    sweep = {}
     try:
-        net, ks, b = "resnet_18", 1.0, 4
-        img, jt = O.synth_batch(b, 128, 14, seed=1234)
-        sd = O.reference_init_state(net, 14, seed=0)
-
-        def med(fn, warm=3, reps=10):
-            for _ in range(warm):
-                fn()
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                fn()
-                ts.append(time.perf_counter() - t0)
-            ts.sort()
-            return 0.5 * (ts[reps // 2 - 1] + ts[reps // 2]) if reps % 2 == 0 else ts[reps // 2]
-
-        def infer():
-            with torch.no_grad():
-                O.offset2joint_softmax(O.resnet18_forward(sd, img, False), img, ks)
-        t_eval = med(infer)
-        ost = {"step": 0, "m": {}, "v": {}}
-        t_train = med(lambda: O.train_step(net, sd, ost, img, jt, ks, 0.0, 1.0))
+        torch.set_num_threads(cores)
+        t_eval = med(infer, 3, 10)
+        t_train = med(train, 3, 10)
+        sweep[cores] = (t_eval, t_train)
+        for n in (8, 16, 32, 64):
+            if n >= cores:
+                continue
+            torch.set_num_threads(n)
+            sweep[n] = (med(infer, 1, 3), med(train, 1, 3))
     finally:
         torch.set_num_threads(prev)
+    bt = min(sweep, key=lambda n: sweep[n][1])
+    be = min(sweep, key=lambda n: sweep[n][0])
     return {"value": round(b / t_train, 2), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
             "eval_value": round(b / t_eval, 2), "eval_ms": round(1e3 * t_eval, 2), "train_ms": round(1e3 * t_train, 2),
+            "best_value": round(b / sweep[bt][1], 2), "best_threads": bt, "best_eval_value": round(b / sweep[be][0], 2), "best_eval_threads": be,
+            "thread_sweep_train_images_per_s": {str(n): round(b / sweep[n][1], 2) for n in sorted(sweep)},
             "sample": "BASELINE.md section 4: ResNet18-deconv B=4, (i) eval forward + head under no_grad [eval_value], (ii) one full train step "
                       "GT-map+fwd+head+Huber+bwd+Adam, coord_weight 0 [value]; torch-CPU fp32 restatement (oracle/awr_oracle.py, pinned bit-exact to "
-                      "the reference), %d threads = physical cores, 3 warm-up, median of 10" % cores}
+                      "the reference), %d threads = physical cores, 3 warm-up, median of 10 -- NOTE: 4 images over-subscribe %d threads; best_value "
+                      "is the same step at the best thread count of a {8,16,32,64,all} sweep (1 warm-up, median of 3)" % (cores, cores)}
 
 
 def parity_mm(net_name, ks, dev):
@@ -161,6 +181,64 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
             "mfma_frac": round(flop_mult * 2 * macs / (el / steps) / 1e12 / peak_tf, 4)}
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set), let rank 0 write the JSON line to our stdout, wait for all
+    of them and return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AWR_LAUNCHER="bench.py (self-spawned ranks)")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                c = p.poll()
+                if c is None:
+                    continue
+                procs.remove(p)
+                if c != 0:              # a dead rank leaves the others hanging in a collective: take them down
+                    rc = rc or c
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+def _ranks_seen(pg, dev):
+    """What actually ran: every rank's (rank, device index, device name, uuid / PCI bus id, pid), all-gathered."""
+    pr = torch.cuda.get_device_properties(dev)
+    me = {"rank": int(os.environ.get("RANK", "0")), "device": dev.index, "name": pr.name, "pid": os.getpid()}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "gcnArchName"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            me[k] = str(v)
+    if pg is None:
+        return [me]
+    out = [None] * torch.distributed.get_world_size(pg)
+    torch.distributed.all_gather_object(out, me, group=pg)
+    return out
+
+
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,19 +259,24 @@ def main():
                     help="1 = FP32 MFMA (default, the headline); 6 = split-operand mode (fp32 operands as 3 exact bf16 pieces, 6 bf16 MFMA products)")
     ap.add_argument("--no-split-mode", action="store_true", help="skip the extra split-operand measurement reported under 'split_mode'")
     ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
+    ap.add_argument("--dp-selftest", action="store_true", help="data parallel: fail unless all replicas hold bitwise-identical parameters after the timed steps; "
+                                                               "the per-bucket all-reduce timeline is reported either way when N > 1")
+    ap.add_argument("--no-b256", action="store_true", help="skip the config-4 per-GPU shape (batch 256) sub-record")
     ap.add_argument("--deterministic", action="store_true", help="awr_amd.set_deterministic(True): bitwise-reproducible steps (no atomics on shared "
                                                                   "accumulators, no autotuning); reports what that costs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))          # plain `python bench.py --gpus N`: be our own launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("AWR_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # AWR_FORCE_DEVICE: test hook (several ranks on one GPU)
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
+    if args.gpus != world and not (world == 1 and os.environ.get("AWR_FORCE_DP") == "1"):
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    pg = None
+    pg, backend = None, None
     if world > 1 or os.environ.get("AWR_FORCE_DP") == "1":      # AWR_FORCE_DP: exercise the data-parallel path on a 1-rank group (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("AWR_DIST_BACKEND", "nccl")        # "nccl" is RCCL on ROCm; tests run the same path over gloo on one GPU
@@ -223,32 +306,57 @@ def main():
                           "dtype": dtype, "data": "synthetic", "config": {"workload": res["workload"], "hipgraph": bool(args.graph), "gemm_products": nprod},
                           "mfma_frac": res["mfma_frac"]}), flush=True)
         return
-    eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
-                      use_graph=args.graph, wgrad_streams=args.wgrad_streams)
-    img, jt = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)
-    img, jt = img.to(dev), jt.to(dev)           # inputs resident in HBM before the timed region
-
     def sync():
         torch.cuda.synchronize()
         if pg is not None:
             torch.distributed.barrier()
 
+    def timed_steps(engine, im, jg, steps, warm):
+        """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the MAX over ranks."""
+        for _ in range(warm):
+            engine.step(im, jg)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.step(im, jg)
+        sync()
+        el = time.perf_counter() - t0
+        if pg is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t[0])
+        return el
+
+    eng = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
+                      use_graph=args.graph, wgrad_streams=args.wgrad_streams)
+    img, jt = O.synth_batch(args.batch, 128, 14, seed=1234 + rank)
+    img, jt = img.to(dev), jt.to(dev)           # inputs resident in HBM before the timed region
     graph = bool(eng.use_graph)          # the engine falls back to eager issue in data-parallel mode (RCCL calls inside the backward)
     eng.compile(img, jt)                 # set-up, not a step: kernel warm-up run (rolled back), GEMM tile autotune, hipGraph capture
     warm = args.warmup
-    for _ in range(warm):
-        eng.step(img, jt)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(img, jt)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if pg is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = timed_steps(eng, img, jt, args.steps, warm)
     loss = float(eng.losses[2])
+    ranks_seen = _ranks_seen(pg, dev)
+
+    # data-parallel self-test (after the timed region): replicas must hold bitwise-identical parameters after all those steps (every rank
+    # stepped its own images; the all-reduced gradients and the optimiser are what keeps them together), and one traced step shows where
+    # each bucket's exchange sat relative to the backward
+    selftest = None
+    if pg is not None and (args.dp_selftest or world > 1):
+        flat = net.flat_params()[:net.n_active]
+        mx, mn = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(mn, op=torch.distributed.ReduceOp.MIN)
+        same = bool(torch.equal(mx, mn))
+        eng.trace_buckets = True
+        eng.step(img, jt)
+        tl = eng.bucket_timeline()
+        eng.trace_buckets = False
+        selftest = {"replicas_bitwise_equal_after_steps": same, "steps_checked": warm + args.steps, "n_params": int(net.n_active),
+                    "bucket_timeline_rank0": tl, "note": "timeline of one extra traced step: ms from the start of the step on the stream each bucket was handed to; "
+                                                         "tracing makes that stream wait for its collective"}
+        if args.dp_selftest and not same:
+            raise SystemExit("dp-selftest: parameters differ across ranks after %d steps" % (warm + args.steps))
 
     # per-kernel HIP events only make sense when kernels do not share the GPU: the timed region runs untouched (side streams /
     # graph replay) and the per-kernel roofline comes from serialised passes of the same plan right after it
@@ -307,6 +415,21 @@ def main():
         "step_mfma_frac": round(flop_mult * (tot_fl / max(nsteps_timed, 1)) / (elapsed / args.steps) / 1e12 / peak_tf, 4),
     }
 
+    # HBM-bound kernels of the step that live outside the plan: serial event passes, algorithmic bytes per launch
+    hb = eng.timed_hbm()
+    B_, J_, P_ = args.batch, 14, 64 * 64
+    pred_b, depth_b = 4 * J_ * P_ * 4, P_ * 4
+    alg = {"head_forward_nhwc": ("a4 offset2joint_softmax", B_ * (pred_b + depth_b + J_ * 12)),
+           "head_forward": ("a4 offset2joint_softmax", B_ * (pred_b + depth_b + J_ * 12)),
+           "head_backward": ("a5 head backward", B_ * (2 * pred_b + depth_b)),
+           "dense_loss": ("a6+a7 GT map + dense Huber fwd+bwd", B_ * (2 * pred_b + depth_b)),
+           # one pass does a4's partials AND a6+a7 (coord_weight 0) -- priced at the bytes that pass has to move (map in, gradient out);
+           # with a coordinate loss the map is read twice (partials, then dense loss + head backward)
+           "head_loss_step_nhwc": ("a4 + a6+a7 (+ a5 when coord_weight != 0) in one call", B_ * ((2 if args.coord_weight == 0.0 else 3) * pred_b + depth_b)),
+           "adam_step": ("a8 Adam, 28 B / parameter", 28 * int(net.n_active))}
+    roofline_hbm = {k: {"covers": alg[k][0], "bytes_algorithmic": alg[k][1], "avg_us": round(1e6 * v, 2), "gbps": round(alg[k][1] / v / 1e9, 1),
+                        "frac_of_8TBps": round(alg[k][1] / v / 8e12, 4)} for k, v in hb.items() if k in alg}
+
     if rank == 0:
         n_cu, mhz = L.C.c_int(0), L.C.c_int(0)
         L.lib.awr_device_info(L.C.byref(n_cu), L.C.byref(mhz), None, 0)
@@ -319,18 +442,44 @@ def main():
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
                        "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams, "independent_hw_queues_for_side_streams": _pool_info(L),
-                       "gemm_products": nprod, "deterministic": bool(args.deterministic), "device_cus": n_cu.value, "final_loss": loss},
-            "roofline": roofline,
+                       "gemm_products": nprod, "deterministic": bool(args.deterministic), "device_cus": n_cu.value, "final_loss": loss,
+                       "nhwc_head_loss": bool(eng.nhwc), "launcher": os.environ.get("AWR_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")},
+            "dist_backend": backend, "rccl_version": _rccl_version() if backend == "nccl" else None, "ranks_seen": ranks_seen,
+            "roofline": roofline, "roofline_hbm": roofline_hbm,
         }
+        if selftest is not None:
+            out["dp_selftest"] = selftest
         if world == 1 and not args.no_parity:
             mean_mm, max_mm = parity_mm(args.net, ks, dev)
             out["joint_err_mm_vs_oracle"] = {"mean": round(mean_mm, 6), "max": round(max_mm, 6)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
+    # config 4's per-GPU shape (batch 256 / GPU: north_star states its scaling target there) beside the batch-64 headline, same protocol,
+    # every rank takes part (the all-reduce is part of the step)
+    b256 = None
+    if args.batch != 256 and args.net.startswith("resnet") and nprod == 1 and not args.no_b256 and not args.deterministic:
+        del eng
+        torch.cuda.empty_cache()
+        eng2 = TrainEngine(net, 256, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg, use_graph=args.graph,
+                           wgrad_streams=args.wgrad_streams)
+        im2, jt2 = O.synth_batch(256, 128, 14, seed=4321 + rank)
+        im2, jt2 = im2.to(dev), jt2.to(dev)
+        eng2.compile(im2, jt2)
+        k2 = max(4, min(args.steps, 10))
+        el2 = timed_steps(eng2, im2, jt2, k2, 3)
+        b256 = {"workload": "resnet_18-deconv train step, batch 256/GPU = BASELINE configs[3] per-GPU shape", "value": round(world * 256 * k2 / el2, 2), "unit": "images/s",
+                "n_gpus": world, "steps": k2, "warmup": 3, "ms_per_step": round(1e3 * el2 / k2, 3), "plan_gb": round(eng2.plan.bytes / 1e9, 1),
+                "step_mfma_frac": round(flop_mult * (tot_fl / max(nsteps_timed, 1)) * (256 / args.batch) / (el2 / k2) / 1e12 / peak_tf, 4)}
+        del eng2
+        eng = None
+        torch.cuda.empty_cache()
+    if rank == 0:
+        if b256 is not None:
+            out["b256"] = b256
         if world == 1 and not args.no_extras:
             # north_star's forward target (>= 40 % MFMA utilisation on the ResNet18-deconv forward) and BASELINE config 3, each ~1 s,
             # outside the timed train region
-            del eng
+            eng = None
             torch.cuda.empty_cache()
             out["forward"] = {"b%d" % b: measure_inference(awr_amd, O, "resnet_18", b, dev, rank, 30, 5, args.graph, peak_tf, flop_mult) for b in (64, 128)}
             out["config3"] = measure_inference(awr_amd, O, "hourglass_1", 128, dev, rank, 20, 5, args.graph, peak_tf, flop_mult)

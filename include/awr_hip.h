@@ -95,6 +95,21 @@ int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* im
                    int F, int H, float ks, float delta, float weight, double* acc, float* g_offset,
                    int accumulate, void* stream);
 
+/* NHWC forms (round 3) for a host that keeps the dense map in the backbone's own layout: pred / grad are (B, F*F, Cp) rows, Cp = 4J
+ * rounded up to 32 (channel 3j+c = offset component c of joint j, 3J+j = its heat map; padding channels zero), as awr_plan_head_nhwc
+ * hands them out -- no NCHW transposes on either side of the loss.  scratch: awr_head_nhwc_scratch(B, J, F) floats.
+ * awr_head_forward_nhwc = FeatureModule.offset2joint_softmax (util/feature_tool.py:41-65).
+ * awr_head_loss_step_nhwc = train.py:118-127 in one call: joints + (max, sum) statistics, the coordinate Huber loss (acc[0] +=
+ * coord_weight * mean) and, when coord_weight != 0, its gradient through the head; the fused GT map + dense Huber loss (acc[1] +=
+ * dense_weight * mean; util/feature_tool.py:12-39, model/loss.py:8-25); the total gradient w.r.t. the dense map written (not
+ * accumulated) to grad.  coord_weight == 0 reads the map once (one pass + a merge kernel), otherwise twice.  acc: two doubles, zeroed
+ * by the caller (awr_zero_f64) and read back with awr_loss_finalize. */
+int64_t awr_head_nhwc_scratch(int B, int J, int F);
+int awr_head_forward_nhwc(const float* pred, int Cp, const float* img, int B, int J, int F, int H, float ks, float* scratch,
+                          float* jt, float* stat /* optional */, void* stream);
+int awr_head_loss_step_nhwc(const float* pred, int Cp, const float* img, const float* jt_gt, int B, int J, int F, int H, float ks,
+                            float delta, float coord_weight, float dense_weight, float* scratch, float* jt, float* stat,
+                            float* g_jt /* needed when coord_weight != 0 */, double* acc, float* grad, void* stream);
 int awr_zero_f64(double* p, int64_t n, void* stream);
 /* out[i] = (float)acc[i] for i<n, out[n] = sum -- e.g. {coord, dense, total} */
 int awr_loss_finalize(const double* acc, int n, float* out, void* stream);
@@ -392,6 +407,20 @@ int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* 
 /* op i of the forward (list 0) / backward (list 1) launch list: name, algorithmic MACs (GEMM-family launches),
  * flags bit 0 = weight gradient that may run on a side stream, bit 1 = conv / stem family (timed by awr_plan_run_timed) */
 int awr_plan_op(const awr_plan* plan, int list, int i, const char** name, double* macs, int* flags);
+/* parity / debugging introspection: activation tensor i of the plan in build order (i past the end returns AWR_ERR_ARG): name
+ * ("<layer>.out" = a conv's raw output, "<bn>.act" = a materialised BatchNorm(+ReLU) output, "<bn>.act(lazy)" = one that is never
+ * written, ...), NHWC dims {B,H,W,C}, the value buffer and, after a backward replay, its gradient buffer (NULL if none; identity skips
+ * alias the buffer of the tensor they come from).  lazy != 0: the handle stands for buf * scale[c] + shift[c] (2: with a ReLU on top) of
+ * ANOTHER tensor's buffer, applied by the consumers' loaders; lz_scale / lz_shift are those per-channel coefficients. */
+int awr_plan_tensor(const awr_plan* plan, int i, const char** name, int dims[4], float** buf, float** grad, int* lazy,
+                    const float** lz_scale, const float** lz_shift);
+/* NHWC boundary (round 3): stage s's dense map as the head GEMM leaves it, (B, F*F, Cp) rows, and -- training plans, supervised stages
+ * -- the buffer the backward reads its gradient from (NULL when that stage's gradient has a second producer and must go through
+ * grad_outs).  awr_plan_set_nhwc_boundary(plan, 1): the plan stops transposing to / from the NCHW boundary tensors (outs / grad_outs are
+ * then neither written nor read): the caller runs awr_head_forward_nhwc / awr_head_loss_step_nhwc on these buffers between
+ * awr_plan_forward and awr_plan_backward.  Refused (AWR_ERR_UNSUPPORTED) when a supervised stage has no NHWC gradient buffer. */
+int awr_plan_head_nhwc(const awr_plan* plan, int stage, const float** pred, float** grad, int* Cp);
+int awr_plan_set_nhwc_boundary(awr_plan* plan, int on);
 /* n_side extra HIP streams (weight gradients in the backward, forked branches in the forward); comm != 0 adds the
  * stream buckets are handed to */
 int awr_plan_set_streams(awr_plan* plan, int n_side, int comm);      /* n_side in 0..4 */

@@ -32,6 +32,12 @@ def test_bench_single_process_line():
     assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["algorithmic_gflop_per_image"] - 22.603) < 0.01                      # 22.60 GFLOP / image
     assert d["joint_err_mm_vs_oracle"]["mean"] < 1e-3                                 # north_star: 1e-3 mm mean
+    # round 3: what ran, the HBM-bound kernels' roofline block, config 4's per-GPU shape beside the headline
+    assert len(d["ranks_seen"]) == 1 and d["ranks_seen"][0]["rank"] == 0 and d["dist_backend"] is None
+    for k, v in d["roofline_hbm"].items():
+        assert v["bytes_algorithmic"] > 0 and v["avg_us"] > 0 and abs(v["frac_of_8TBps"] - v["gbps"] / 8000.0) < 2e-3, (k, v)
+    assert "adam_step" in d["roofline_hbm"] and ("head_loss_step_nhwc" in d["roofline_hbm"] or "dense_loss" in d["roofline_hbm"])
+    assert d["b256"]["n_gpus"] == 1 and abs(d["b256"]["value"] - 256 * 1e3 / d["b256"]["ms_per_step"]) < 1e-2 * d["b256"]["value"]
 
 
 def test_bench_under_torchrun_with_forced_dp_path():
@@ -50,12 +56,39 @@ def test_bench_two_ranks_exactly_as_the_driver_launches_it():
     RCCL -- the only difference to the 8-GPU run): one JSON line from rank 0, whole-job throughput, weak scaling."""
     env = dict(os.environ, AWR_DIST_BACKEND="gloo", AWR_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+           "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-b256"]
     out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=1100, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
+    _check_two_rank_line(d)
+    assert d["config"]["launcher"] == "torch.distributed.run"
+
+
+def _check_two_rank_line(d):
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     assert "cpu_baseline" not in d and "split_mode" not in d            # rank-0-at-N=1 extras only
+    # the line proves what ran: backend, one entry per rank (rank, device, pid), replicas bitwise equal after the steps, bucket timeline
+    assert d["dist_backend"] == "gloo" and sorted(r["rank"] for r in d["ranks_seen"]) == [0, 1]
+    assert len({r["pid"] for r in d["ranks_seen"]}) == 2
+    st = d["dp_selftest"]
+    assert st["replicas_bitwise_equal_after_steps"] is True and st["steps_checked"] == 3
+    tl = st["bucket_timeline_rank0"]
+    assert len(tl["buckets"]) >= 2 and all(b["end_ms"] >= b["start_ms"] for b in tl["buckets"]) and tl["backward_end_ms"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """a plain `python3 bench.py --gpus 2` (no torchrun) used to be a SystemExit.  It now starts its rank processes
+    itself; here two ranks share GPU 0 over gloo (the 1-GPU box), everything else is the 8-GPU launch."""
+    env = dict(os.environ, AWR_DIST_BACKEND="gloo", AWR_FORCE_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-b256", "--dp-selftest"]
+    out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=1100, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = _last_json(out.stdout)
+    _check_two_rank_line(d)
+    assert d["config"]["launcher"].startswith("bench.py")

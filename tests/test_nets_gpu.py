@@ -290,7 +290,7 @@ def test_config5_hourglass2_256_j21(amd, dev, golden_dir):
     assert abs(l0 - ref0) <= 2e-4 * abs(ref0), (l0, ref0)
     assert abs(float(losses[0]) - float(g["lcoord0"])) <= 2e-4 * abs(float(g["lcoord0"])) + 1e-9
     assert abs(float(losses[1]) - float(g["ldense0"])) <= 2e-4 * abs(float(g["ldense0"])) + 1e-9
-    pred = eng.plan.outputs[1].cpu().reshape(-1).numpy()[g["pred_idx"]]               # last stage's dense map, training-mode BN
+    pred = eng.dense_map(1).cpu().reshape(-1).numpy()[g["pred_idx"]]               # last stage's dense map, training-mode BN
     assert float(np.abs(pred - g["pred_val"]).max()) <= 2e-4 * max(1.0, float(np.abs(g["pred_val"]).max()))
     gap = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=3), img, ks, True)[-1]
     assert_joints("config5/train", jt.cpu().numpy(), g["jt0"], gap)
@@ -342,78 +342,63 @@ def test_reference_initialised_weights_meet_north_star(amd, dev, net):
                 (net, mode, s_, float(d.mean()), float(d.max()), gaps[s_])
 
 
-def _fp64_grads_and_kink_mass(net, sd, img, jt_gt, ks, cw, tol=1e-5):
-    """float64 evaluation of the oracle's loss gradients, plus the ReLU-kink sensitivity of this input: for every ReLU, the share of
-    the gradient norm (w.r.t. its output) that sits on elements whose pre-activation is within `tol` of zero.  relu'(0) is a
-    coin toss between any two fp32 implementations there, and a flipped element moves every upstream gradient by up to that share;
-    the root-sum-square over the ReLUs is the noise floor no fp32 path can be held below."""
-    import torch.nn.functional as TF
-    recs, orig = [], O.TF.relu
-
-    def relu_rec(x, *a, **k):
-        y = orig(x, *a, **k)
-        if x.requires_grad:
-            y.retain_grad()
-            recs.append((x, y))
-        return y
-
-    O.TF.relu, O.HIGH_PRECISION = relu_rec, True
-    try:
-        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-        man = O.manifest_for(net, jt_gt.shape[1])
-        pkeys = O.params_of(sd64, man)
-        leaves = {k: sd64[k].detach().clone().requires_grad_(True) for k in pkeys}
-        work = {k: (leaves[k] if k in leaves else sd64[k]) for k in sd64}
-        gt = O.joint2offset(jt_gt.double(), img.double(), ks, img.shape[-1] // 2)
-        pred = O.backbone_forward(net, work, img.double(), True)[-1]
-        loss = cw * O.huber(O.offset2joint_softmax(pred, img.double(), ks), jt_gt.double()) + O.huber(pred, gt)
-        loss.backward()
-    finally:
-        O.TF.relu, O.HIGH_PRECISION = orig, False
-    mass = [float((y.grad * (x.detach().abs() < tol)).norm() / (y.grad.norm() + 1e-300)) for x, y in recs]
-    return {k: leaves[k].grad for k in pkeys}, float(np.sqrt(np.sum(np.square(mass))))
-
-
 @pytest.mark.parametrize("cw", [0.0, 1.0])
 @pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
 def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
-    """Whole gradient tensors (not norms): the relative L2 distance of the HIP gradients from the float64 evaluation of the same
-    formulas, tensor by tensor, is held to 4x the distance the fp32 oracle (torch-CPU, the reference's own numerics) itself sits
-    from float64 -- the conditioning yardstick DESIGN.md section 5 argues with, asserted here -- plus the ReLU-kink noise floor of
-    the input (see _fp64_grads_and_kink_mass).  Weights from the reference's own initialisers, single-stage nets (the fused
-    multi-stack step has its own golden test)."""
+    """Whole gradient tensors (not norms) against float64, tensor by tensor -- with the ReLU decisions of the implementation under
+    test (tests/yardstick.py).  The loss is piecewise smooth and a ReLU whose pre-activation is ~1e-6 gets derivative 0 in one fp32
+    implementation and 1 in another; everything upstream in the backward inherits that.  Round 2 widened the tolerance by a "kink noise
+    floor" so large (1.8e-2) that it could hide a 4x regression; round 3 removes the noise instead: the plan's own ReLU decisions
+    (awr_plan_tensor: materialised activations and the lazy BatchNorm coefficients) are fed to the float64 evaluation, which then
+    differentiates exactly the branch the HIP step took (and likewise for the fp32 oracle with ITS decisions).  What is left is rounding:
+    the HIP gradients must sit within 3x the fp32 oracle's own distance from float64 (the MFMA accumulates K sequentially; its forward
+    activations carry 1.8-2.6x oneDNN's rounding error on the same inputs: tools/diag_parity.py, profiles/r03_diag_parity.txt).
+    Decisions may only differ from float64's where the float64 pre-activation is within 1e-4 of zero."""
+    import yardstick as Y
     from awr_amd.trainer import TrainEngine
     J, B = 14, 2
     ks = 1.0 if net.startswith("resnet") else 0.4
     img, jt_gt = O.synth_batch(B, 128, J, seed=23)
     sd = O.reference_init_state(net, J, seed=9)
-    pkeys = O.params_of(sd, O.manifest_for(net, J))
-    g32 = O.loss_and_grads(net, {k: v.clone() for k, v in sd.items()}, img, jt_gt, ks, cw, 1.0)[3]
-    g64, kink = _fp64_grads_and_kink_mass(net, sd, img, jt_gt, ks, cw)
+    ref = Y.trace(net, sd, img, jt_gt, ks, cw, True)
+    f32 = Y.trace(net, sd, img, jt_gt, ks, cw, False)
+    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=Y.decisions_from_trace(ref, f32))
     m = make_net(amd, net, J, sd)
     eng = TrainEngine(m, B, 128, ks, coord_weight=cw, dense_weight=1.0, lr=1e-3, autotune=False)
     eng.step(img.to(dev), jt_gt.to(dev))
-    gmax = max(float(g64[k].norm()) for k in pkeys if g64[k] is not None)
+    torch.cuda.synchronize()
+    flips, rep = Y.decisions_from_plan(ref, eng.plan.tensors(lazy=True))
+    for tag, n, mx in rep:
+        assert mx < 1e-4, ("ReLU decision differs from float64 away from a kink", tag, n, mx)
+    ref_hip = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=flips)
+    # the fused ResNet stem never materialises its ReLU: its decisions stay float64's, its kinks stay a (small) allowance
+    stem = [k for k in Y.kink_table(ref, 1e-5) if k[0] == "pre.1"]
+    stem_kink = stem[0][2] if stem else 0.0
+    pkeys = O.params_of(sd, O.manifest_for(net, J))
+    gmax = max(float(ref["grads"][k].norm()) for k in pkeys if ref["grads"][k] is not None)
     rows = []
     for k in pkeys:
-        if g64[k] is None:
+        if ref["grads"][k] is None:
             assert k in m._unused
             continue
-        ref = g64[k].reshape(-1)
-        den = float(ref.norm()) + 1e-3 * gmax       # (a conv bias in front of a BatchNorm has a zero true gradient: pure rounding noise)
-        e_hip = float((m.grad_view(k).cpu().double().reshape(-1) - ref).norm()) / den
-        e_f32 = float((g32[k].double().reshape(-1) - ref).norm()) / den
-        rows.append((e_hip / max(e_f32, 1e-7), k, e_hip, e_f32))
-        assert e_hip <= 4.0 * e_f32 + 1.5 * kink + 2e-5, (k, e_hip, e_f32, kink)
+        floor = 1e-3 * gmax       # (a conv bias in front of a BatchNorm has a zero true gradient: pure rounding noise)
+        e_hip = Y.rel_l2(m.grad_view(k).cpu(), ref_hip["grads"][k], floor)
+        e_f32 = Y.rel_l2(f32["grads"][k], ref_f32["grads"][k], floor)
+        e_raw = Y.rel_l2(m.grad_view(k).cpu(), ref["grads"][k], floor)
+        rows.append((e_hip / max(e_f32, 1e-7), k, e_hip, e_f32, e_raw))
+        assert e_hip <= 3.0 * e_f32 + 1.5 * stem_kink + 2e-5, (k, e_hip, e_f32, stem_kink)
     ratios = [r[0] for r in rows]
-    report("%s/cw%d/grad_vs_fp64/median_ratio_hip_over_fp32_oracle" % (net, int(cw)), float(np.median(ratios)))
-    report("%s/cw%d/grad_vs_fp64/max_rel_l2_err_hip" % (net, int(cw)), max(r[2] for r in rows))
-    report("%s/cw%d/grad_vs_fp64/max_rel_l2_err_fp32_oracle" % (net, int(cw)), max(r[3] for r in rows))
-    report("%s/cw%d/grad_vs_fp64/relu_kink_noise_floor" % (net, int(cw)), kink)
-    print("median error ratio HIP / fp32 oracle %.2f, max rel. L2 error HIP %.2e / fp32 oracle %.2e, ReLU-kink floor %.2e" %
-          (float(np.median(ratios)), max(r[2] for r in rows), max(r[3] for r in rows), kink))
+    tagp = "%s/cw%d/grad_vs_fp64/" % (net, int(cw))
+    report(tagp + "median_ratio_hip_over_fp32_oracle", float(np.median(ratios)))
+    report(tagp + "max_rel_l2_err_hip", max(r[2] for r in rows))
+    report(tagp + "max_rel_l2_err_fp32_oracle", max(r[3] for r in rows))
+    report(tagp + "max_rel_l2_err_hip_without_relu_decisions", max(r[4] for r in rows))
+    report(tagp + "relu_decisions_flipped_hip", sum(n for _, n, _ in rep))
+    report(tagp + "relu_decisions_flipped_fp32_oracle", sum(int(v.sum()) for v in Y.decisions_from_trace(ref, f32).values()))
+    print("median error ratio HIP / fp32 oracle %.2f, max rel. L2 error HIP %.2e (%.2e before the ReLU decisions) / fp32 oracle %.2e; decisions flipped: %s" %
+          (float(np.median(ratios)), max(r[2] for r in rows), max(r[4] for r in rows), max(r[3] for r in rows), rep))
     for r in sorted(rows, reverse=True)[:4]:
-        print("  %6.2f  %-40s hip %.2e  fp32 oracle %.2e" % r)
+        print("  %6.2f  %-40s hip %.2e  fp32 oracle %.2e  (raw %.2e)" % r)
 
 
 def test_dropin_loop_sees_every_optimizer_step(amd, dev):
@@ -594,6 +579,38 @@ def test_bucketed_backward_matches_and_is_final_at_the_marker(amd, dev, net, str
                 assert torch.equal(snap, m.flat_grads()[lo:hi]), (lo, hi)      # nothing wrote the range after its marker
     d = (grads[0] - grads[1]).abs().max() / grads[0].abs().max()
     assert float(d) < 1e-4          # same kernels, split-K atomics order differs
+
+
+def test_a_failing_bucket_hook_is_raised_not_swallowed(amd, dev):
+    """the bucket hook runs inside a ctypes callback in the middle of the native backward replay; ctypes prints
+    'Exception ignored' and carries on, the optimiser would then step an un-reduced bucket.  The binding stashes the error and
+    run_backward() re-raises it after the native call has returned."""
+    from awr_amd._lib import AwrError
+    J = 14
+    img, _ = O.synth_batch(2, 128, J, seed=62)
+    m = make_net(amd, "resnet_18", J, O.procedural_state(O.manifest_for("resnet_18", J), seed=6))
+    m.train()
+    plan = m.get_plan(2, 128, True, supervised=(0,), n_buckets=4)
+    plan.set_streams(2, comm=True)
+    calls = []
+
+    def hook(lo, hi):
+        calls.append((lo, hi))
+        if len(calls) == 2:
+            raise RuntimeError("collective failed")
+    plan.bucket_hook = hook
+    m.sync_weights(plan, force=True)
+    plan.img.copy_(img.to(dev))
+    plan.forward()
+    plan.grad_outs[0].copy_(_hashed_like(plan.grad_outs[0]))
+    with pytest.raises(AwrError, match="bucket hook failed"):
+        plan.backward()
+    torch.cuda.synchronize()
+    assert len(calls) == 2          # later buckets are not handed out after a failure
+    plan.bucket_hook = lambda lo, hi: None
+    plan.forward()
+    plan.backward()                 # the plan stays usable
+    torch.cuda.synchronize()
 
 
 def _hashed_like(t):
