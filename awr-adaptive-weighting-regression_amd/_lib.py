@@ -92,6 +92,7 @@ _SIGS = {
     "awr_dense_loss": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _I, _P], C.c_int),
     "awr_zero_f64": ([_P, _L, _P], C.c_int),
     "awr_loss_finalize": ([_P, _I, _P, _P], C.c_int),
+    "awr_loss_finalize_reset": ([_P, _I, _P, _P], C.c_int),
     "awr_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P], C.c_int),
     "awr_sgd_step": ([_P, _P, _P, _L, _F, _F, _F, _L, _F, _P], C.c_int),
     "awr_pack_weight": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
@@ -157,6 +158,16 @@ _SIGS = {
     "awr_plan_autotune": ([_P, _I, _P], C.c_int),
     "awr_plan_gemm": ([_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), C.POINTER(_I)], C.c_int),
     "awr_plan_set_gemm": ([_P, _I, _I, _I, _I, _F], C.c_int),
+    # data-parallel API (csrc/awr_dp.hip)
+    "awr_dp_available": ([C.POINTER(_I), C.POINTER(C.c_char_p)], C.c_int),
+    "awr_dp_unique_id": ([_P], C.c_int),
+    "awr_dp_init": ([_I, _I, _P, _PP], C.c_int),
+    "awr_dp_destroy": ([_P], C.c_int),
+    "awr_dp_info": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], C.c_int),
+    "awr_dp_allreduce": ([_P, _P, _L, _P], C.c_int),
+    "awr_dp_broadcast": ([_P, _P, _L, _I, _P], C.c_int),
+    "awr_dp_wait": ([_P, _P], C.c_int),
+    "awr_plan_set_dp": ([_P, _P], C.c_int),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -23,6 +23,7 @@ SOURCES = {
     "awr_conv.hip": [],
     "awr_stem.hip": [],
     "awr_net.hip": [],        # host-only: network-level plan builder / runner
+    "awr_dp.hip": [],         # host-only: RCCL communicators through dlopen (no link-time dependency)
 }
 
 
@@ -59,7 +60,7 @@ def build_lib(force=False, verbose=True):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print("[awr build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

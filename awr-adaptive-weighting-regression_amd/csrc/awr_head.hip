@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "awr_common.h"
 
@@ -328,6 +329,18 @@ __global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x,
 // reference default) -- the dense map is read ONCE per step -- or 1, then 2|4 once the joints exist.
 constexpr int TPX = 64;      // pixels per tile
 
+// exp(x) for x <= 0 (softmax terms after the max subtraction): two-term range reduction with explicit FMAs (x log2 e = n + r,
+// |r| <= 1/2, log2 e split into a high and a low part so that r keeps full precision for |x| up to several hundred), the hardware
+// exp2 on r (1 ulp there) and an exact scaling by 2^n -- 7 instructions against ~18 for the library expf (which also guards overflow
+// and positive arguments), ~2 ulp.  The NHWC kernels are VALU-bound (ISA count: ~300 instructions per (pixel, joint)), not HBM-bound.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const float n = rintf(x * L2E_HI);
+    float r = __builtin_fmaf(x, L2E_HI, -n);
+    r = __builtin_fmaf(x, L2E_LO, r);
+    return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+}
+
 struct nhwc_args {
     const float* pred;       // (B, P, Cp)
     const float* img;        // (B, 1, H, H)
@@ -338,13 +351,13 @@ struct nhwc_args {
     float* partial;          // (B, chunks, J, 5)   MODE & 1
     float* grad;             // (B, P, Cp)    MODE & 6
     double* acc;             // dense-loss accumulator   MODE & 2
-    int J, F, H, Cp, tiles_per_wg;
+    int J, F, H, Cp, tiles_per_wg, lgF;      // lgF: log2(F) when F is a power of two (every map of both backbones), else -1
     float ks, delta, gscale;
     double lscale;
     int fixed_point;
 };
 
-template <int JS, int MODE>
+template <int JS, int MODE, int DEPTH, bool POW2>
 __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
     constexpr int NS = 256 / JS;          // pixel slots per pass
     constexpr int PPT = TPX / NS;         // pixels per thread per tile
@@ -379,36 +392,47 @@ __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
     }
     SoftAcc sa = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
+    const float inv_f = 1.0f / (float)F;
 
-    float4 r[NLMAX];
-    float rd = 0.f;
-    auto request = [&](int t) {       // tile t of this workgroup: 64 * Cp contiguous floats + the 64 depth samples
+    // DEPTH register sets: tile t + DEPTH is requested while tile t is being worked on (DEPTH = 2 doubles the bytes a workgroup keeps
+    // in flight for 16 more registers)
+    float4 r[DEPTH][NLMAX];
+    float rd[DEPTH];
+    auto request = [&](int t, float4 (&rr)[NLMAX], float& rdd) {       // tile t of this workgroup: 64 * Cp contiguous floats + the 64 depth samples
         const float* s = src + (int64_t)t * TPX * a.Cp;
 #pragma unroll
         for (int i = 0; i < NLMAX; ++i)
-            if (i < NL) r[i] = ld4(s + ((int64_t)(tid + 256 * i) << 2));
+            if (i < NL) rr[i] = ld4(s + ((int64_t)(tid + 256 * i) << 2));
         if (tid < TPX) {
             const int p = (tile0 + t) * TPX + tid, y = p / F, x = p - y * F;
-            rd = dimg[(int64_t)y * rs * a.H + x * rs];
+            rdd = dimg[(int64_t)y * rs * a.H + x * rs];
         }
     };
-    if (ntile > 0) request(0);
-    for (int t = 0; t < ntile; ++t) {
+    auto body = [&](int t, float4 (&rr)[NLMAX], float& rdd) {
 #pragma unroll
         for (int i = 0; i < NLMAX; ++i)
             if (i < NL) {
                 const int e = tid + 256 * i, px = e / C4, c4 = e - px * C4;
-                st4(tile + px * pitch + 4 * c4, r[i]);
+                st4(tile + px * pitch + 4 * c4, rr[i]);
             }
-        if (tid < TPX) dtile[tid] = rd;
+        if (tid < TPX) dtile[tid] = rdd;
         __syncthreads();
-        if (t + 1 < ntile) request(t + 1);
+        if (t + DEPTH < ntile) request(t + DEPTH, rr, rdd);
         if (active) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int px = slot + NS * k;
-                const int p = (tile0 + t) * TPX + px, y = p / F, x = p - y * F;
-                const float d = dtile[px], cx = grid_coord(x, F), cy = grid_coord(y, F);
+                const int p = (tile0 + t) * TPX + px;
+                int x, y;
+                float cx, cy;
+                if (POW2) {            // shifts, and 1/F is exact: (2 i + 1) * (1/F) - 1 == 2 (i + 0.5) / F - 1 bit for bit
+                    y = p >> a.lgF; x = p & (F - 1);
+                    cx = (float)(2 * x + 1) * inv_f - 1.0f; cy = (float)(2 * y + 1) * inv_f - 1.0f;
+                } else {
+                    y = p / F; x = p - y * F;
+                    cx = grid_coord(x, F); cy = grid_coord(y, F);
+                }
+                const float d = dtile[px];
                 float* row = tile + px * pitch;
                 const float v0 = row[3 * j], v1 = row[3 * j + 1], v2 = row[3 * j + 2], hraw = row[3 * J + j];
                 const float mk = d < kDepthBg ? 1.f : 0.f;
@@ -417,11 +441,11 @@ __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
                 if (MODE & 1) {
                     const float l = h * kBeta;
                     if (l > sa.m) {
-                        const float sc = (sa.m == -INFINITY) ? 0.f : expf(sa.m - l);
+                        const float sc = (sa.m == -INFINITY) ? 0.f : exp_nonpos(sa.m - l);
                         sa.s *= sc; sa.a0 *= sc; sa.a1 *= sc; sa.a2 *= sc;
                         sa.m = l;
                     }
-                    const float e = expf(l - sa.m);
+                    const float e = exp_nonpos(l - sa.m);
                     sa.s += e;
                     sa.a0 += (v0 * mk * dis + cx) * e;
                     sa.a1 += (v1 * mk * dis + cy) * e;
@@ -430,11 +454,16 @@ __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
                 if (MODE & 6) {
                     float q0 = 0.f, q1 = 0.f, q2 = 0.f, qh = 0.f;
                     if (MODE & 2) {       // util/feature_tool.py:29-39, operation for operation (gt_map4)
-                        const float e0 = gj0 - cx, e1 = gj1 - cy, e2 = gj2 - d;
-                        const float dist = sqrtf(((e0 * e0 + e1 * e1) + e2 * e2) + 1e-8f);
-                        const float hm = (a.ks - dist) / a.ks;
-                        const float gm = (hm >= 0.f ? 1.f : 0.f) * mk;
-                        const float z0 = v0 - e0 / dist * gm, z1 = v1 - e1 / dist * gm, z2 = v2 - e2 / dist * gm, zh = hraw - hm * gm;
+                        // The GT map is zero wherever its mask is (background pixels; pixels farther than ks from the joint): there
+                        // x - (+-0) == x exactly, so the correctly rounded sqrt / divides (~150 VALU instructions per (pixel, joint),
+                        // what made the NCHW kernel compute-bound at 2.2 TB/s) only run where the mask can be 1.
+                        float z0 = v0, z1 = v1, z2 = v2, zh = hraw;
+                        if (mk != 0.f) {
+                            const float e0 = gj0 - cx, e1 = gj1 - cy, e2 = gj2 - d;
+                            const float dist = sqrtf(((e0 * e0 + e1 * e1) + e2 * e2) + 1e-8f);
+                            const float hm = (a.ks - dist) / a.ks;
+                            if (hm >= 0.f) { z0 = v0 - e0 / dist; z1 = v1 - e1 / dist; z2 = v2 - e2 / dist; zh = hraw - hm; }
+                        }
                         lsum += huber_val(z0, a.delta); lsum += huber_val(z1, a.delta); lsum += huber_val(z2, a.delta); lsum += huber_val(zh, a.delta);
                         q0 = huber_grad(z0, a.delta) * a.gscale; q1 = huber_grad(z1, a.delta) * a.gscale;
                         q2 = huber_grad(z2, a.delta) * a.gscale; qh = huber_grad(zh, a.delta) * a.gscale;
@@ -464,6 +493,14 @@ __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
                 }
         }
         __syncthreads();
+    };
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q)
+        if (q < ntile) request(q, r[q], rd[q]);
+    for (int t = 0; t < ntile; t += DEPTH) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q)
+            if (t + q < ntile) body(t + q, r[q], rd[q]);
     }
     if (MODE & 1) {
         // lanes j, j + JS, ... of a wave hold partials of the same joint: fold them, then the four waves through LDS
@@ -495,20 +532,31 @@ __global__ __launch_bounds__(256) void dense_nhwc_kernel(const nhwc_args a) {
 }
 
 // merge the per-chunk softmax partials -> joints (B, J, 3) + (max, sum) for the backward; optionally the coordinate Huber loss
-// (train.py:125: crit(jt_uvd_pred, jt_uvd_gt)) and its gradient w.r.t. the joints
+// (train.py:125: crit(jt_uvd_pred, jt_uvd_gt)) and its gradient w.r.t. the joints.  A 32-lane half-wave per (image, joint): lane c takes
+// chunks c, c + 32, ... and the halves fold with the softmax-merge operator (a thread per joint walking the chunks one after the other
+// took 16 us -- as long as the streaming pass itself).
 __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ partial, int chunks, int J, int BJ, const float* __restrict__ jt_gt,
                                                           float delta, float gscale, double lscale, float* __restrict__ jt, float* __restrict__ stat,
                                                           float* __restrict__ g_jt, double* __restrict__ acc, int fixed_point) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), c0 = threadIdx.x & 31;
     double local = 0.0;
+    SoftAcc t = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
     if (i < BJ) {
         const int b = i / J, j = i - b * J;
-        SoftAcc t = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < chunks; ++c) {
+        for (int c = c0; c < chunks; c += 32) {
             const float* q = partial + (((int64_t)b * chunks + c) * J + j) * 5;
             SoftAcc o = {q[0], q[1], q[2], q[3], q[4]};
             t = combine(t, o);
         }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        SoftAcc other;
+        other.m = __shfl_xor(t.m, o, 64); other.s = __shfl_xor(t.s, o, 64);
+        other.a0 = __shfl_xor(t.a0, o, 64); other.a1 = __shfl_xor(t.a1, o, 64); other.a2 = __shfl_xor(t.a2, o, 64);
+        t = combine(t, other);
+    }
+    if (i < BJ && c0 == 0) {
         const float out[3] = {t.a0 / t.s, t.a1 / t.s, t.a2 / t.s};
 #pragma unroll
         for (int c = 0; c < 3; ++c) jt[i * 3 + c] = out[c];
@@ -529,7 +577,7 @@ __global__ void zero_f64_kernel(double* p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
-__global__ void loss_finalize_kernel(const double* acc, int n, float* out, int fixed_point) {
+__global__ void loss_finalize_kernel(double* acc, int n, float* out, int fixed_point, int reset) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < n; ++i) {
@@ -540,6 +588,7 @@ __global__ void loss_finalize_kernel(const double* acc, int n, float* out, int f
             }
             out[i] = (float)v;
             t += v;
+            if (reset) acc[i] = 0.0;      // (all-zero bits in both encodings) the next step accumulates from zero without a fill launch
         }
         out[n] = (float)t;
     }
@@ -598,9 +647,17 @@ template <int MODE>
 static int launch_dense_nhwc(const nhwc_args& a, int B, int chunks, hipStream_t st) {
     const dim3 grid((unsigned)chunks, (unsigned)B);
     const size_t lds = (size_t)(TPX * (a.Cp + 4) + TPX) * sizeof(float);
-    if (a.J <= 16) hipLaunchKernelGGL((dense_nhwc_kernel<16, MODE>), grid, dim3(256), lds, st, a);
-    else if (a.J <= 32) hipLaunchKernelGGL((dense_nhwc_kernel<32, MODE>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((dense_nhwc_kernel<64, MODE>), grid, dim3(256), lds, st, a);
+    static const int depth = []() { const char* e = getenv("AWR_NHWC_DEPTH"); return e ? atoi(e) : 1; }();      // tuning hook (measured: 2 is no faster, profiles/r03_summary.md)
+#define AWR_NHWC_LAUNCH(js, dp)                                                                                           \
+    do {                                                                                                                   \
+        if (a.lgF >= 0) hipLaunchKernelGGL((dense_nhwc_kernel<js, MODE, dp, true>), grid, dim3(256), lds, st, a);          \
+        else hipLaunchKernelGGL((dense_nhwc_kernel<js, MODE, dp, false>), grid, dim3(256), lds, st, a);                    \
+    } while (0)
+    if (a.J <= 16 && depth == 2) AWR_NHWC_LAUNCH(16, 2);
+    else if (a.J <= 16) AWR_NHWC_LAUNCH(16, 1);
+    else if (a.J <= 32) AWR_NHWC_LAUNCH(32, 1);
+    else AWR_NHWC_LAUNCH(64, 1);
+#undef AWR_NHWC_LAUNCH
     return check_launch("dense_nhwc_kernel");
 }
 
@@ -671,6 +728,12 @@ int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* im
 }
 
 // ---- NHWC forms ------------------------------------------------------------------------------------------------------
+static int log2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+}
+
 static int nhwc_geometry(int B, int J, int F, int H, int Cp, int* chunks, int* tiles_per_wg) {
     if (int e = check_head_dims(B, J, F, H)) return e;
     AWR_REQUIRE(J <= 64, "head (NHWC): at most 64 joints (got %d)", J);
@@ -679,10 +742,11 @@ static int nhwc_geometry(int B, int J, int F, int H, int Cp, int* chunks, int* t
     const int P = F * F;
     AWR_REQUIRE(P % TPX == 0, "head (NHWC): F*F must be a multiple of %d", TPX);
     const int tiles = P / TPX;
-    // ~2048 workgroups per launch (8 per CU), at least one tile and at most 16 tiles per workgroup
+    // every tile after a workgroup's first is requested while the previous one is being worked on: as many tiles per workgroup as
+    // still leave ~4 workgroups per CU (1024 per launch), at most 16
+    static const int want_wgs = []() { const char* e = getenv("AWR_NHWC_WGS"); return e ? atoi(e) : 1024; }();      // tuning hook
     int per = 1;
-    while (per < 16 && per * 2 <= tiles && (int64_t)B * (tiles / (per * 2)) >= 2048) per *= 2;
-    if ((int64_t)B * tiles <= 2048) per = 1;
+    while (per < 16 && per * 2 <= tiles && (int64_t)B * (tiles / (per * 2)) >= want_wgs) per *= 2;
     *tiles_per_wg = per;
     *chunks = (tiles + per - 1) / per;
     return AWR_OK;
@@ -700,10 +764,10 @@ int awr_head_forward_nhwc(const float* pred, int Cp, const float* img, int B, in
     if (int e = nhwc_geometry(B, J, F, H, Cp, &chunks, &per)) return e;
     nhwc_args a;
     memset(&a, 0, sizeof a);
-    a.pred = pred; a.img = img; a.partial = scratch; a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks;
+    a.pred = pred; a.img = img; a.partial = scratch; a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks; a.lgF = log2_exact(F);
     hipStream_t st = as_stream(stream);
     if (int e = launch_dense_nhwc<1>(a, B, chunks, st)) return e;
-    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 255) / 256), dim3(256), 0, st, scratch, chunks, J, B * J, nullptr, 0.f, 0.f, 0.0, jt, stat,
+    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 7) / 8), dim3(256), 0, st, scratch, chunks, J, B * J, nullptr, 0.f, 0.f, 0.0, jt, stat,
                        nullptr, nullptr, 0);
     return check_launch("head_finish_kernel");
 }
@@ -721,14 +785,14 @@ int awr_head_loss_step_nhwc(const float* pred, int Cp, const float* img, const f
     nhwc_args a;
     memset(&a, 0, sizeof a);
     a.pred = pred; a.img = img; a.jt_gt = jt_gt; a.partial = scratch; a.grad = grad; a.acc = acc + 1;
-    a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks; a.delta = delta;
+    a.J = J; a.F = F; a.H = H; a.Cp = Cp; a.tiles_per_wg = per; a.ks = ks; a.delta = delta; a.lgF = log2_exact(F);
     a.gscale = (float)((double)dense_weight / nd); a.lscale = (double)dense_weight / nd; a.fixed_point = fixed;
     hipStream_t st = as_stream(stream);
     const bool coord = coord_weight != 0.f;
     // coord_weight == 0 (config.py:41, the reference default): ONE pass over the map does the softmax partials, the dense loss and its
     // gradient; otherwise the joints have to exist before the head's backward can run: partials -> finish -> dense loss + head backward
     if (int e = coord ? launch_dense_nhwc<1>(a, B, chunks, st) : launch_dense_nhwc<3>(a, B, chunks, st)) return e;
-    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 255) / 256), dim3(256), 0, st, scratch, chunks, J, B * J, jt_gt, delta,
+    hipLaunchKernelGGL(head_finish_kernel, dim3((B * J + 7) / 8), dim3(256), 0, st, scratch, chunks, J, B * J, jt_gt, delta,
                        (float)((double)coord_weight / nc), (double)coord_weight / nc, jt, stat, coord ? g_jt : nullptr, acc, fixed);
     if (int e = check_launch("head_finish_kernel")) return e;
     if (coord) {
@@ -756,7 +820,13 @@ int awr_zero_f64(double* p, int64_t n, void* stream) {
 
 int awr_loss_finalize(const double* acc, int n, float* out, void* stream) {
     AWR_REQUIRE(acc && out && n > 0 && n <= 16, "loss_finalize: bad arguments");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), acc, n, out, awr_get_deterministic());
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), const_cast<double*>(acc), n, out, awr_get_deterministic(), 0);
+    return check_launch("loss_finalize_kernel");
+}
+
+int awr_loss_finalize_reset(double* acc, int n, float* out, void* stream) {
+    AWR_REQUIRE(acc && out && n > 0 && n <= 16, "loss_finalize_reset: bad arguments");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), acc, n, out, awr_get_deterministic(), 1);
     return check_launch("loss_finalize_kernel");
 }
 

@@ -655,6 +655,10 @@ struct awr_plan {
     size_t ev_next = 0;
     awr_bucket_cb bucket_cb = nullptr;
     void* bucket_user = nullptr;
+    awr_dp* dp = nullptr;                 // native RCCL exchange of the buckets (awr_plan_set_dp)
+    int dp_error = 0;
+    awr_bucket_cb saved_cb = nullptr;     // the host's callback while dp is attached
+    void* saved_user = nullptr;
 };
 
 namespace awrnet {
@@ -1754,6 +1758,14 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
         if (comm) NET_CHECK(stream_wait(P, main, comm));      // next step's scratch fill / optimiser must see the scatters
     }
+    if (is_bwd && P.dp && P.n_buckets <= 1 && !P.dp_error)        // a one-bucket plan has no markers: one exchange after the backward
+        P.dp_error = awr_dp_allreduce(P.dp, P.net->grads, P.net->layout.n_active, stream);
+    if (is_bwd && P.dp) NET_CHECK(awr_dp_wait(P.dp, stream));      // ... and the reduced gradients
+    if (is_bwd && P.dp_error) {
+        const int e = P.dp_error;
+        P.dp_error = 0;
+        return e;
+    }
     return AWR_OK;
 }
 
@@ -2171,8 +2183,38 @@ int awr_plan_set_streams(awr_plan* p, int n_side, int comm) {
 
 int awr_plan_set_bucket_callback(awr_plan* p, awr_bucket_cb cb, void* user) {
     AWR_REQUIRE(p, "plan_set_bucket_callback: null pointer");
+    if (p->dp) {      // takes effect when the communicator is detached
+        p->saved_cb = cb;
+        p->saved_user = user;
+        return AWR_OK;
+    }
     p->bucket_cb = cb;
     p->bucket_user = user;
+    return AWR_OK;
+}
+
+// the plan's own bucket callback while a communicator is attached: gradient arena [lo, hi) is final in `stream` order
+static void dp_bucket(void* user, int64_t lo, int64_t hi, void* stream) {
+    awr_plan* p = static_cast<awr_plan*>(user);
+    if (p->dp_error) return;
+    p->dp_error = awr_dp_allreduce(p->dp, p->net->grads + lo, hi - lo, stream);
+}
+
+int awr_plan_set_dp(awr_plan* p, awr_dp* dp) {
+    AWR_REQUIRE(p && p->built_bwd, "plan_set_dp: needs a training plan");
+    if (dp && !p->dp) {
+        p->saved_cb = p->bucket_cb;
+        p->saved_user = p->bucket_user;
+    }
+    p->dp = dp;
+    p->dp_error = 0;
+    if (dp) {
+        p->bucket_cb = dp_bucket;
+        p->bucket_user = p;
+    } else {
+        p->bucket_cb = p->saved_cb;
+        p->bucket_user = p->saved_user;
+    }
     return AWR_OK;
 }
 

@@ -73,6 +73,56 @@ class NetHandle:
             pass
 
 
+class DpComm:
+    """awr_dp: an RCCL communicator owned by the library (include/awr_hip.h "Data-parallel API"; librccl.so is dlopen'ed).  One per
+    rank process, on the current device.  `unique_id()` on rank 0 -> ship the 128 bytes to the other ranks -> `DpComm(rank, world, id)`."""
+
+    @staticmethod
+    def available():
+        v, p = C.c_int(), C.c_char_p()
+        ok = L.lib.awr_dp_available(C.byref(v), C.byref(p)) == 0
+        return ok, v.value, (p.value or b"").decode()
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        L.call("awr_dp_unique_id", buf)
+        return buf.raw
+
+    def __init__(self, rank, world, uid):
+        self.h = C.c_void_p()
+        self.rank, self.world = rank, world
+        L.call("awr_dp_init", int(rank), int(world), C.create_string_buffer(bytes(uid), 128), C.byref(self.h))
+
+    @classmethod
+    def from_process_group(cls, pg):
+        """Bootstrap over an existing torch.distributed group (any backend): rank 0's id is broadcast as an object."""
+        rank, world = torch.distributed.get_rank(pg), torch.distributed.get_world_size(pg)
+        box = [cls.unique_id() if rank == 0 else None]
+        torch.distributed.broadcast_object_list(box, src=torch.distributed.get_global_rank(pg, 0) if hasattr(torch.distributed, "get_global_rank") else 0, group=pg)
+        return cls(rank, world, box[0])
+
+    def allreduce(self, t):
+        L.call("awr_dp_allreduce", self.h, L.ptr(t), t.numel(), L.stream())
+
+    def broadcast(self, t, root=0):
+        L.call("awr_dp_broadcast", self.h, L.ptr(t), t.numel(), int(root), L.stream())
+
+    def wait(self):
+        L.call("awr_dp_wait", self.h, L.stream())
+
+    def close(self):
+        if self.h:
+            L.lib.awr_dp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Plan:
     """awr_plan + its boundary tensors.  Building allocates every buffer; replaying allocates nothing and never synchronises."""
 
@@ -147,6 +197,12 @@ class Plan:
                 continue
             out[name.value.decode()] = (view(buf.value, shape), view(grad.value, shape) if grad.value else None)
         return out
+
+    def set_dp(self, dp):
+        """Attach (or detach: None) a library-owned RCCL communicator: the backward replay all-reduces every gradient bucket itself
+        (no Python in the loop, no ctypes trampoline)."""
+        L.call("awr_plan_set_dp", self.h, dp.h if dp is not None else None)
+        self._dp = dp
 
     # ---- NHWC boundary ----------------------------------------------------------------------------------------
     def head_nhwc(self, stage):

@@ -60,11 +60,15 @@ def bounds2crop(img, ustart, uend, vstart, vend, zstart, zend, thresh_z=True, bg
 
 
 def resize_nearest(img, size):
-    """cv2.resize(img, (w, h), interpolation=cv2.INTER_NEAREST): src index = min(floor(dst * src/dst_size), src-1)."""
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_NEAREST), OpenCV's resizeNN (imgproc/resize.cpp): with fx = dst / src as a
+    double and ifx = 1. / fx, source index = min(floor(dst_index * ifx), src - 1).  The order of the two divisions matters: for 4.7 % of
+    the (src, dst) size pairs up to 700 x 256 the one-division form floor(i * (src / dst)) picks a different source pixel somewhere
+    (tests/test_nyu_data_cpu.py::test_resize_nearest_follows_opencv_division_order)."""
     w, h = size
     sh, sw = img.shape[:2]
-    ys = np.minimum(np.floor(np.arange(h) * (sh / float(h))).astype(np.int64), sh - 1)
-    xs = np.minimum(np.floor(np.arange(w) * (sw / float(w))).astype(np.int64), sw - 1)
+    ify, ifx = 1.0 / (h / float(sh)), 1.0 / (w / float(sw))
+    ys = np.minimum(np.floor(np.arange(h) * ify).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(w) * ifx).astype(np.int64), sw - 1)
     return img[ys][:, xs]
 
 

@@ -63,7 +63,7 @@ class GradSync:
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
-                 nhwc_boundary=None, trace_buckets=False, _share=None):
+                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, _share=None):
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -111,13 +111,21 @@ class TrainEngine:
         self.sync = GradSync(n, process_group, n_buckets)
         self._n_buckets = n_buckets
         self.world = self.sync.world
-        self._works = []
+        self._works, self.dpcomm = [], None
         self.trace_buckets, self._trace, self._tev = bool(trace_buckets), [], None
         if self.dp:             # identical initial parameters and BN buffers on every rank
             if _share is None:
                 self.sync.broadcast(net.flat_params(), net._barena)
                 net.weights_changed()
             self.use_graph = False          # the bucket markers interleave RCCL calls with the backward: run it eagerly
+            # native_rccl (opt-in; AWR_NATIVE_RCCL=1): the library's own RCCL communicator (awr_dp_*, csrc/awr_dp.hip) exchanges the buckets
+            # from inside the native replay -- no Python callback, no torch work objects; bootstrapped over `process_group`
+            import os as _os2
+            want_native = (_os2.environ.get("AWR_NATIVE_RCCL") == "1") if native_rccl is None else bool(native_rccl)
+            if want_native and not trace_buckets:
+                from .engine import DpComm
+                self.dpcomm = _share.dpcomm if (_share is not None and getattr(_share, "dpcomm", None) is not None) else DpComm.from_process_group(process_group)
+                self.plan.set_dp(self.dpcomm)
             g = net.flat_grads()
             # torch's NCCL work stream waits for the compute stream at the point of the call and runs concurrently with
             # whatever is enqueued afterwards: the rest of the backward overlaps the bucket's all-reduce over xGMI
@@ -133,7 +141,8 @@ class TrainEngine:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     self._trace.append((lo, hi, e0, e1))
-            self.plan.bucket_hook = hook
+            if self.dpcomm is None:
+                self.plan.bucket_hook = hook
 
     # ---- the captured part: repack -> forward -> head + losses -> backward -------------------------------
     def _core(self):
@@ -145,10 +154,10 @@ class TrainEngine:
         if self.nhwc and not plan.nhwc:
             plan.set_nhwc_boundary(True)      # (the drop-in module shares plans and switches them back to the NCHW boundary)
         if self.nhwc:      # train.py:118-127 in one call on the NHWC map: joints, both Huber losses, d(loss)/d(map) written where the backward reads it
-            L.call("awr_zero_f64", L.ptr(self.acc), 2, s)
+            # (self.acc starts at zero and awr_loss_finalize_reset leaves it zeroed: no fill launch per step)
             L.call("awr_head_loss_step_nhwc", self._pred, self._cp, L.ptr(plan.img), L.ptr(self.jt_gt), B, J, F, H, self.ks, HUBER_DELTA, self.cw, self.dw,
                    L.ptr(self._scratch), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), L.ptr(self.acc), self._gpred, s)
-            L.call("awr_loss_finalize", L.ptr(self.acc), 2, L.ptr(self.losses), s)
+            L.call("awr_loss_finalize_reset", L.ptr(self.acc), 2, L.ptr(self.losses), s)
             plan.run_backward()
             return
         out = plan.outputs[self.stage]
@@ -214,7 +223,6 @@ class TrainEngine:
             res[name] = e0.elapsed_time(e1) * 1e-3 / reps
         if self.nhwc:
             def step_nhwc():
-                L.call("awr_zero_f64", L.ptr(self.acc), 2, s)
                 L.call("awr_head_loss_step_nhwc", self._pred, self._cp, L.ptr(plan.img), L.ptr(self.jt_gt), B, J, F, H, self.ks, HUBER_DELTA, self.cw, self.dw,
                        L.ptr(self._scratch), L.ptr(self.jt_pred), L.ptr(self.stat), L.ptr(self.g_jt), L.ptr(self.acc), self._gpred, s)
             t("head_loss_step_nhwc", step_nhwc)
@@ -232,6 +240,7 @@ class TrainEngine:
             p, g, m, v = (x[:n].clone() for x in (self.net.flat_params(), self.net.flat_grads(), self.m, self.v))
             t("adam_step", lambda: L.call("awr_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, self.lr, 0.9, 0.999, 1e-8, self.wd, max(self.step_count, 1),
                                           self.sync.grad_scale, s))
+        self.acc.zero_()          # the passes above accumulated into the loss accumulators
         return res
 
     def _optimizer(self):
@@ -309,6 +318,9 @@ class TrainEngine:
         if not (self.use_graph or tune):
             return
         hook, self.plan.bucket_hook = self.plan.bucket_hook, None          # no collectives during set-up
+        dpc = getattr(self, "dpcomm", None)
+        if dpc is not None:
+            self.plan.set_dp(None)
         keep = self.net._barena.clone()
         self._core()
         if tune:
@@ -320,6 +332,8 @@ class TrainEngine:
                 self._core()
         self.net._barena.copy_(keep)
         self.plan.bucket_hook = hook
+        if dpc is not None:
+            self.plan.set_dp(dpc)
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -627,27 +641,49 @@ class Trainer:
 
     @torch.no_grad()
     def test(self, epoch=0):
+        """train.py:178-227 / test.py:51-110 -- DataLoader(batch_size, shuffle=False, num_workers) like the reference (worker processes
+        decode the 8 252 NYU PNGs while the GPU runs), no per-sample host loop.  Data parallel: rank r evaluates batches r, r + world, ...
+        of that loader's order; the per-frame error rows and original-image uvd predictions are gathered and re-assembled in dataset order
+        on every rank, so mpe / AUC / the results txt are identical to the single-process run and rank-uniform."""
         import os
         import numpy as np
         cfg = self.config
+        world = torch.distributed.get_world_size(self.pg) if self.pg is not None else 1
         inf = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False)
         ev = self.EvalUtil(self.testData.img_size, self.testData.paras, self.testData.flip, self.testData.jt_num)
-        n = len(self.testData)
-        for i0 in range(0, n, cfg.batch_size):
-            items = [self.testData[i] for i in range(i0, min(n, i0 + cfg.batch_size))]
-            img, jt_xyz_gt, _, center_xyz, M, cube = (torch.stack([torch.as_tensor(it[k]) for it in items]) for k in range(6))
+        n, bs = len(self.testData), cfg.batch_size
+        mine = [b for b in range((n + bs - 1) // bs) if b % world == self.rank]
+        idx = [i for b in mine for i in range(b * bs, min(n, (b + 1) * bs))]
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(self.testData, idx), batch_size=bs, shuffle=False,
+                                             num_workers=int(getattr(cfg, "num_workers", 0)), drop_last=False)
+        pad = None
+        for k, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(loader):
             nb = img.shape[0]
-            if nb < cfg.batch_size:                                  # ragged last batch: pad, then drop the padding
-                img = torch.cat([img, img[-1:].expand(cfg.batch_size - nb, -1, -1, -1)])
-            jt = inf(img.cuda().float())[:nb].cpu().numpy()
+            x = img.cuda(non_blocking=True).float()
+            if nb < bs:                                              # ragged last batch: fill the static plan's batch with zeros, drop them after
+                if pad is None:
+                    pad = torch.zeros((bs,) + tuple(x.shape[1:]), device=x.device)
+                pad.zero_()
+                pad[:nb] = x
+                x = pad
+            jt = inf(x)[:nb].cpu().numpy()
             ev.feed_batch(jt, jt_xyz_gt.numpy(), center_xyz.numpy(), M.numpy(), cube.numpy())
-            ib = i0 // cfg.batch_size + 1
-            if self.rank == 0 and getattr(cfg, "vis_freq", 0) and ib % cfg.vis_freq == 0 and self._vis is not None:    # train.py:203-213
+            ib = mine[k] + 1
+            if getattr(cfg, "vis_freq", 0) and ib % cfg.vis_freq == 0 and self._vis is not None:    # train.py:203-213
                 half = cfg.img_size / 2.0
-                self._vis.plot(items[0][0].numpy() if torch.is_tensor(items[0][0]) else np.asarray(items[0][0]),
-                               os.path.join(self.result_dir, "test_epoch_{}_iter_{}.png".format(epoch, ib)),
-                               (jt[0] + 1) * half, (np.asarray(items[0][2], np.float32) + 1) * half)
+                self._vis.plot(img[0].numpy(), os.path.join(self.result_dir, "test_epoch_{}_iter_{}.png".format(epoch, ib)),
+                               (jt[0] + 1) * half, (jt_uvd_gt[0].numpy() + 1) * half)
         self.net.train()
+        if world > 1:          # every rank ends up with the whole test set, in dataset order
+            J = self.testData.jt_num
+            err = np.concatenate(ev._err, 0) if ev._err else np.zeros((0, J), np.float32)
+            uvd = np.asarray(ev.jt_uvd_pred, np.float32).reshape(-1, J, 3)
+            parts = [None] * world
+            torch.distributed.all_gather_object(parts, (idx, err, uvd), group=self.pg)
+            full_e, full_u = np.zeros((n, J), err.dtype), np.zeros((n, J, 3), np.float32)
+            for ids, e, u in parts:
+                full_e[ids], full_u[ids] = e, u
+            ev._err, ev.jt_uvd_pred = [full_e], list(full_u)
         mpe, mid, auc, pck, thresh = ev.get_measures()
         if self.rank == 0:
             ev.plot_pck(os.path.join(self.work_dir, "test_pck_epoch_{}.png".format(epoch)), pck, thresh)                # train.py:216

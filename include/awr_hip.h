@@ -113,6 +113,8 @@ int awr_head_loss_step_nhwc(const float* pred, int Cp, const float* img, const f
 int awr_zero_f64(double* p, int64_t n, void* stream);
 /* out[i] = (float)acc[i] for i<n, out[n] = sum -- e.g. {coord, dense, total} */
 int awr_loss_finalize(const double* acc, int n, float* out, void* stream);
+/* the same, and acc[0..n) is left zeroed: a step loop needs no awr_zero_f64 launch between steps */
+int awr_loss_finalize_reset(double* acc, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.Adam defaults semantics (train.py:66-67, :131) over flat arenas.
@@ -444,6 +446,33 @@ int awr_plan_autotune(awr_plan* plan, int reps, void* stream);
 int awr_plan_gemm(const awr_plan* plan, int i, const char** name, int* tile_m, int* tile_n, int* target_blocks,
                   float* us, int* tuned);
 int awr_plan_set_gemm(awr_plan* plan, int i, int tile_m, int tile_n, int target_blocks, float us);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel API (net-new w.r.t. the reference, which hard-wires one GPU: train.py:29,:233).
+ * One process per GPU.  The library opens librccl.so at run time (dlopen; AWR_RCCL_LIB overrides the path) -- libawr_hip.so has
+ * no link-time dependency on RCCL and a host that exchanges gradients itself (awr_plan_set_bucket_callback) never loads it.
+ *   rank 0:      awr_dp_unique_id(id)            -> ship the 128 bytes to the other ranks out of band (file, socket, MPI, ...)
+ *   every rank:  awr_dp_init(rank, world, id, &dp)   (collective; the communicator lives on the CURRENT device)
+ *                awr_dp_broadcast(dp, params, n, 0, stream) / (..., bn_buffers, ...): identical replicas
+ *                awr_plan_set_dp(plan, dp): awr_plan_backward all-reduces (SUM) every gradient bucket as soon as it is final -- on the
+ *                communicator's own stream, behind the bucket's scatter, overlapping the rest of the backward -- and returns with the
+ *                caller's stream ordered after all of them; pass grad_scale = 1/world to awr_adam_step / awr_sgd_step.
+ * BatchNorm statistics stay rank-local (what stock DDP does).  awr_dp_allreduce / awr_dp_broadcast order themselves behind `stream`
+ * and run on the communicator's stream; awr_dp_wait(dp, stream) orders `stream` behind everything issued so far.
+ * -----------------------------------------------------------------------------------------*/
+#define AWR_DP_ID_BYTES 128
+typedef struct awr_dp awr_dp;
+int awr_dp_available(int* version, const char** path);          /* AWR_OK if librccl.so and its symbols were found */
+int awr_dp_unique_id(void* id128);
+int awr_dp_init(int rank, int world, const void* id128, awr_dp** out);
+int awr_dp_destroy(awr_dp* dp);
+int awr_dp_info(const awr_dp* dp, int* rank, int* world, int* device);
+int awr_dp_allreduce(awr_dp* dp, float* buf, int64_t n, void* stream);               /* in place, SUM */
+int awr_dp_broadcast(awr_dp* dp, float* buf, int64_t n, int root, void* stream);     /* in place */
+int awr_dp_wait(awr_dp* dp, void* stream);
+/* dp != NULL: the plan's gradient buckets (n_buckets of awr_plan_create; 1 = one exchange after the backward) go through `dp`;
+ * NULL detaches.  Replaces the bucket callback while set. */
+int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
 
 #ifdef __cplusplus
 }

@@ -348,6 +348,29 @@ def joint2offset(jt_uvd, img, ks, F):
     return _fl(torch.cat([(unit * mask.unsqueeze(2)).reshape(B, 3 * J, F, F), hm * mask], 1))
 
 
+def joint2offset_ieee(jt_uvd, img, ks, F):
+    """joint2offset restated with numpy float32 scalars-and-arrays only: every operation (subtract, multiply, add, sqrt, divide) is a
+    single correctly rounded IEEE-754 binary32 operation in the order of util/feature_tool.py:29-39.  torch's CPU sqrt is NOT
+    correctly rounded (MKL VML: ~0.6 % of arguments come out 1 ulp off on this host, more on others), so `joint2offset` above --
+    bit-identical to the reference on the SAME host -- is not a host-independent answer; this one is, and it is what the HIP
+    kernel (correctly rounded v_sqrt / v_div sequences, no FMA contraction) reproduces bit for bit."""
+    f32 = np.float32
+    jt = jt_uvd.numpy().astype(np.float32)
+    B, J, _ = jt.shape
+    r = img.shape[-1] // F
+    d = img.numpy()[:, 0, ::r, ::r].astype(np.float32)
+    a = (f32(2.0) * (np.arange(F, dtype=np.float32) + f32(0.5)) / f32(F) - f32(1.0)).astype(np.float32)
+    o0 = jt[:, :, 0, None, None] - a[None, None, None, :]
+    o1 = jt[:, :, 1, None, None] - a[None, None, :, None]
+    o2 = jt[:, :, 2, None, None] - d[:, None]
+    o0, o1 = np.broadcast_to(o0, o2.shape), np.broadcast_to(o1, o2.shape)
+    dist = np.sqrt(((o0 * o0 + o1 * o1) + o2 * o2) + f32(1e-8))
+    hm = (f32(ks) - dist) / f32(ks)
+    mk = (hm >= 0).astype(np.float32) * (d[:, None] < f32(DEPTH_BG)).astype(np.float32)
+    unit = np.stack([o0 / dist * mk, o1 / dist * mk, o2 / dist * mk], 2).reshape(B, 3 * J, F, F)
+    return np.concatenate([unit, hm * mk], 1).astype(np.float32)
+
+
 def offset2joint_softmax(offset, img, ks):
     """Dense map (B,4J,F,F) + depth -> joints (B,J,3); feature_tool.py:41-65."""
     B, C4, F, _ = offset.shape

@@ -35,6 +35,18 @@ def main():
             per_step.append(net.flat_params()[:net.n_active].cpu())       # replicas must stay bitwise equal after EVERY step
         torch.cuda.synchronize()
         res[mode] = {"params": net.flat_params()[:net.n_active].cpu(), "buffers": net._barena.cpu(), "losses": losses, "per_step": per_step}
+    # sharded evaluation (Trainer.test): rank r scores batches r, r + world, ... of the test loader, the error rows are gathered and
+    # re-assembled in dataset order: every rank must report the single-process mpe
+    from awr_amd.config import Config
+    from awr_amd.trainer import SyntheticHands, Trainer
+
+    class Cfg(Config):
+        net, kernel_size, batch_size, num_workers, max_epoch, output_dir, load_model, exp_id, use_hipgraph, vis_freq = \
+            "resnet_18", 1.0, 4, 0, 1, out + "_work%d" % rank, "", "dp", False, 0
+    torch.manual_seed(99)
+    tr = Trainer(Cfg(), None, SyntheticHands(10, seed=2), process_group=torch.distributed.group.WORLD)
+    res["test_mpe"] = float(tr.test(1))
+    res["test_params"] = tr.net.flat_params()[:tr.net.n_active].cpu()
     torch.save(res, "%s.rank%d" % (out, rank))
     torch.distributed.destroy_process_group()
 

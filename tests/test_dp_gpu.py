@@ -63,6 +63,19 @@ def test_two_rank_data_parallel_engine(tmp_path):
         for a, b in zip(r0[mode]["per_step"], r1[mode]["per_step"]):
             assert torch.equal(a, b), mode
     assert not torch.equal(b0["buffers"], b1["buffers"])
+    # sharded Trainer.test (10 frames, batch 4: a ragged last batch, 3 batches over 2 ranks): both ranks report the same mpe, equal to
+    # the single-process evaluation of the same (broadcast) weights
+    from awr_amd.config import Config
+    from awr_amd.trainer import SyntheticHands, Trainer
+    assert r0["test_mpe"] == r1["test_mpe"] and torch.equal(r0["test_params"], r1["test_params"])
+
+    class Cfg(Config):
+        net, kernel_size, batch_size, num_workers, max_epoch, output_dir, load_model, exp_id, use_hipgraph, vis_freq = \
+            "resnet_18", 1.0, 4, 0, 1, str(tmp_path), "", "single", False, 0
+    tr = Trainer(Cfg(), None, SyntheticHands(10, seed=2))
+    tr.net.flat_params()[:tr.net.n_active].copy_(r0["test_params"].cuda())
+    tr.net.weights_changed()
+    assert abs(tr.test(1) - r0["test_mpe"]) < 1e-4
 
 
 @pytest.mark.timeout(1200)

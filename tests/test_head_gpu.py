@@ -42,14 +42,20 @@ CASES = [(2, 14, 128, 0.4), (3, 14, 128, 1.0), (2, 21, 256, 0.4), (1, 14, 64, 0.
 
 @pytest.mark.parametrize("B,J,H,ks", CASES)
 def test_joint2offset_bit_exact(amd, dev, B, J, H, ks):
+    """The GT map has hard thresholds (heat map >= 0, depth < 0.99): the kernel restates util/feature_tool.py:29-39 operation for
+    operation (no FMA contraction, correctly rounded sqrt / divide) and must reproduce the IEEE-754 restatement of those lines
+    (oracle.joint2offset_ieee: numpy float32, every operation correctly rounded) BIT FOR BIT.  The torch-CPU oracle itself is NOT that:
+    torch's CPU sqrt (MKL VML) is off by one ulp for 0.6 % of arguments on an Intel host and more elsewhere (tools/debug_j2o.py), so against
+    it the map may differ by one unit in the last place of the affected elements -- never in its mask."""
     img, jt = O.synth_batch(B, H, J, seed=21)
     F = H // 2
     out = amd.FeatureModule().joint2offset(jt.to(dev), img.to(dev), ks, F).cpu()
+    ieee = torch.from_numpy(O.joint2offset_ieee(jt, img, ks, F))
+    nbad = int((out != ieee).sum())
+    assert torch.equal(out, ieee), "max diff %g, %d elements differ from the IEEE restatement" % (float((out - ieee).abs().max()), nbad)
     ref = O.joint2offset(jt, img, ks, F)
-    # the GT map has hard thresholds (heat map >= 0, depth < 0.99): the kernel restates util/feature_tool.py:29-39 operation for operation
-    # (compiled without FMA contraction, correctly rounded sqrt / divide) and must reproduce the oracle BIT FOR BIT
-    nbad = int((out != ref).sum())
-    assert torch.equal(out, ref), "max diff %g, %d elements differ" % (float((out - ref).abs().max()), nbad)
+    assert torch.equal(out != 0, ref != 0)                                   # same mask as the torch oracle
+    assert float((out - ref).abs().max()) <= 2.4e-7                          # <= 1 ulp of values in [1, 2): torch's sqrt
 
 
 @pytest.mark.parametrize("B,J,H,ks", CASES)

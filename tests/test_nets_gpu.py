@@ -350,7 +350,8 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     implementation and 1 in another; everything upstream in the backward inherits that.  Round 2 widened the tolerance by a "kink noise
     floor" so large (1.8e-2) that it could hide a 4x regression; round 3 removes the noise instead: the plan's own ReLU decisions
     (awr_plan_tensor: materialised activations and the lazy BatchNorm coefficients) are fed to the float64 evaluation, which then
-    differentiates exactly the branch the HIP step took (and likewise for the fp32 oracle with ITS decisions).  What is left is rounding:
+    differentiates exactly the branch the HIP step took (and likewise for the fp32 oracle with ITS decisions); max-pool windows whose
+    two largest elements are within rounding of each other are the same kind of decision and are handled the same way.  What is left is rounding:
     the HIP gradients must sit within 3x the fp32 oracle's own distance from float64 (the MFMA accumulates K sequentially; its forward
     activations carry 1.8-2.6x oneDNN's rounding error on the same inputs: tools/diag_parity.py, profiles/r03_diag_parity.txt).
     Decisions may only differ from float64's where the float64 pre-activation is within 1e-4 of zero."""
@@ -362,18 +363,19 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     sd = O.reference_init_state(net, J, seed=9)
     ref = Y.trace(net, sd, img, jt_gt, ks, cw, True)
     f32 = Y.trace(net, sd, img, jt_gt, ks, cw, False)
-    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=Y.decisions_from_trace(ref, f32))
+    fl32, pl32 = Y.decisions_from_trace(ref, f32)
+    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=fl32, pools=pl32)
     m = make_net(amd, net, J, sd)
     eng = TrainEngine(m, B, 128, ks, coord_weight=cw, dense_weight=1.0, lr=1e-3, autotune=False)
     eng.step(img.to(dev), jt_gt.to(dev))
     torch.cuda.synchronize()
-    flips, rep = Y.decisions_from_plan(ref, eng.plan.tensors(lazy=True))
+    flips, pools, rep = Y.decisions_from_plan(ref, eng.plan.tensors(lazy=True))
     for tag, n, mx in rep:
-        assert mx < 1e-4, ("ReLU decision differs from float64 away from a kink", tag, n, mx)
-    ref_hip = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=flips)
-    # the fused ResNet stem never materialises its ReLU: its decisions stay float64's, its kinks stay a (small) allowance
-    stem = [k for k in Y.kink_table(ref, 1e-5) if k[0] == "pre.1"]
-    stem_kink = stem[0][2] if stem else 0.0
+        assert mx < 1e-4, ("ReLU / max-pool decision differs from float64 away from a kink", tag, n, mx)
+    ref_hip = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=flips, pools=pools)
+    # the fused ResNet stem never materialises its ReLU / pooling decisions: they stay float64's, their near-kinks stay a (small) allowance
+    # for the tensors upstream of them: the stem's own parameters
+    stem_kink = Y.stem_allowance(ref) if net.startswith("resnet") else 0.0
     pkeys = O.params_of(sd, O.manifest_for(net, J))
     gmax = max(float(ref["grads"][k].norm()) for k in pkeys if ref["grads"][k] is not None)
     rows = []
@@ -386,7 +388,8 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
         e_f32 = Y.rel_l2(f32["grads"][k], ref_f32["grads"][k], floor)
         e_raw = Y.rel_l2(m.grad_view(k).cpu(), ref["grads"][k], floor)
         rows.append((e_hip / max(e_f32, 1e-7), k, e_hip, e_f32, e_raw))
-        assert e_hip <= 3.0 * e_f32 + 1.5 * stem_kink + 2e-5, (k, e_hip, e_f32, stem_kink)
+        allow = 1.5 * stem_kink if k.startswith("pre.") else 0.0
+        assert e_hip <= 3.0 * e_f32 + allow + 2e-5, (k, e_hip, e_f32, stem_kink)
     ratios = [r[0] for r in rows]
     tagp = "%s/cw%d/grad_vs_fp64/" % (net, int(cw))
     report(tagp + "median_ratio_hip_over_fp32_oracle", float(np.median(ratios)))
@@ -394,7 +397,8 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     report(tagp + "max_rel_l2_err_fp32_oracle", max(r[3] for r in rows))
     report(tagp + "max_rel_l2_err_hip_without_relu_decisions", max(r[4] for r in rows))
     report(tagp + "relu_decisions_flipped_hip", sum(n for _, n, _ in rep))
-    report(tagp + "relu_decisions_flipped_fp32_oracle", sum(int(v.sum()) for v in Y.decisions_from_trace(ref, f32).values()))
+    report(tagp + "stem_kink_allowance", stem_kink)
+    report(tagp + "relu_decisions_flipped_fp32_oracle", sum(int(v.sum()) for v in fl32.values()) + len(pl32))
     print("median error ratio HIP / fp32 oracle %.2f, max rel. L2 error HIP %.2e (%.2e before the ReLU decisions) / fp32 oracle %.2e; decisions flipped: %s" %
           (float(np.median(ratios)), max(r[2] for r in rows), max(r[4] for r in rows), max(r[3] for r in rows), rep))
     for r in sorted(rows, reverse=True)[:4]:
@@ -543,7 +547,7 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     tr2 = Trainer(Cfg2(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
     assert torch.equal(tr2.net.flat_params(), tr.net.flat_params()) and tr2.engine.step_count == tr.engine.step_count
     assert torch.equal(tr2.engine.m, tr.engine.m) and abs(tr2.engine.lr - 1e-3) < 1e-12       # LR force-reset (train.py:94-96)
-    assert abs(tr2.test(1) - tr.test(1)) < 1e-6
+    assert abs(tr2.test(1) - tr.test(1)) < 1e-5       # (mm, of ~80: two engines, independently autotuned tiles = different summation orders)
 
 
 @pytest.mark.parametrize("net,streams", [("resnet_18", 0), ("resnet_18", 2), ("hourglass_1", 2)])
@@ -632,17 +636,60 @@ def test_train_engine_with_one_rank_rccl_group(amd, dev, monkeypatch):
         img, jt_gt = O.synth_batch(2, 128, J, seed=71)
         man = O.manifest_for("resnet_18", J)
         out = []
-        for pg in (None, dist.group.WORLD):
+        # (None: single process; torch: the Python bucket hook + torch.distributed all-reduce; native: the library's own RCCL communicator
+        # -- awr_dp_*, librccl.so through dlopen -- attached to the plan, no Python in the exchange)
+        for pg, native in ((None, False), (dist.group.WORLD, False), (dist.group.WORLD, True)):
             m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=7))
-            eng = TrainEngine(m, 2, 128, 1.0, coord_weight=1.0, use_graph=False, process_group=pg)
+            eng = TrainEngine(m, 2, 128, 1.0, coord_weight=1.0, use_graph=False, process_group=pg, native_rccl=native)
             assert eng.dp == (pg is not None) and len(eng.plan.buckets) == (4 if pg is not None else 1)
+            assert (eng.dpcomm is not None) == native
             l = [float(eng.step(img.to(dev), jt_gt.to(dev))[0][2]) for _ in range(2)]
             out.append((l, m.flat_params().clone()))
-        assert np.allclose(out[0][0], out[1][0], rtol=1e-4)
-        d = (out[0][1] - out[1][1]).abs()
-        assert float(torch.quantile(d[:1000000], 0.9)) <= 2e-4
+        for k in (1, 2):
+            assert np.allclose(out[0][0], out[k][0], rtol=1e-4)
+            d = (out[0][1] - out[k][1]).abs()
+            assert float(torch.quantile(d[:1000000], 0.9)) <= 2e-4
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_communicator_through_the_c_abi(amd, dev):
+    """awr_dp_* (include/awr_hip.h "Data-parallel API"): what a non-Python host uses.  One rank here (RCCL refuses two ranks on one
+    device; tests/test_dp_gpu.py runs the two-rank form where two GPUs are visible): unique id, communicator on the current device,
+    in-place all-reduce / broadcast ordered behind the caller's stream, and a one-bucket plan whose backward exchanges the whole
+    gradient arena itself."""
+    from awr_amd.engine import DpComm
+    ok, version, path = DpComm.available()
+    assert ok and version > 0 and "rccl" in path
+    dp = DpComm(0, 1, DpComm.unique_id())
+    x = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+    y = x.clone()
+    dp.allreduce(y)
+    dp.broadcast(y, 0)
+    dp.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)                       # SUM over one rank
+    J = 14
+    img, _ = O.synth_batch(2, 128, J, seed=72)
+    grads = []
+    for attach in (False, True):
+        m = make_net(amd, "resnet_18", J, O.procedural_state(O.manifest_for("resnet_18", J), seed=7))
+        m.train()
+        plan = m.get_plan(2, 128, True, supervised=(0,), n_buckets=1 if not attach else 4)
+        plan.set_streams(2, comm=attach)
+        if attach:
+            plan.set_dp(dp)
+        m.sync_weights(plan, force=True)
+        plan.img.copy_(img.to(dev))
+        plan.forward()
+        plan.grad_outs[0].copy_(_hashed_like(plan.grad_outs[0]))
+        plan.backward()
+        torch.cuda.synchronize()
+        grads.append(m.flat_grads()[:m.n_active].clone())
+        if attach:
+            plan.set_dp(None)
+    assert float((grads[0] - grads[1]).abs().max() / grads[0].abs().max()) < 1e-4
+    dp.close()
 
 
 @pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])

@@ -190,3 +190,76 @@ def test_resamplers_reproduce_analytic_known_answers(ND):
     assert np.array_equal(ND.resize_nearest(img, (20, 16)), img[::2, ::2])
     assert np.array_equal(ND.resize_nearest(img, (80, 64)), np.repeat(np.repeat(img, 2, 0), 2, 1))
     assert np.array_equal(ND.resize_nearest(img, (120, 96)), np.repeat(np.repeat(img, 3, 0), 3, 1))
+
+
+def test_resize_nearest_follows_opencv_division_order(ND):
+    """OpenCV's resizeNN computes fx = dst / src, ifx = 1. / fx, index = min(cvFloor(i * ifx), src - 1) in doubles (imgproc/resize.cpp).
+    A literal scalar restatement of that loop is the independent check here; the one-division shortcut
+    floor(i * (src / dst)) is NOT equivalent (a different pixel for ~5 % of size pairs) and the exact-rational rule (i * src) // dst
+    is not either -- both are counted so a later 'simplification' shows up."""
+    import math
+    rng = np.random.RandomState(3)
+    naive = exact = total = 0
+    for sw, w in [(int(a), int(b)) for a, b in zip(rng.randint(1, 700, 600), rng.randint(1, 257, 600))] + [(6, 34), (241, 128), (173, 128), (320, 128)]:
+        row = np.arange(sw, dtype=np.float32)[None, :]
+        got = ND.resize_nearest(row, (w, 1))[0].astype(np.int64)
+        fx = w / float(sw)
+        ifx = 1.0 / fx
+        lit = np.array([min(int(math.floor(i * ifx)), sw - 1) for i in range(w)])
+        assert np.array_equal(got, lit), (sw, w)
+        total += 1
+        naive += int((np.minimum(np.floor(np.arange(w) * (sw / float(w))).astype(np.int64), sw - 1) != lit).any())
+        exact += int((np.minimum((np.arange(w) * sw) // w, sw - 1) != lit).any())
+    assert naive > 0 and exact > 0, "the shortcuts became equivalent?"
+    # rows and columns are decoded independently
+    img = rng.rand(37, 53).astype(np.float32)
+    out = ND.resize_nearest(img, (128, 90))
+    ys = [min(int(math.floor(i * (1.0 / (90 / 37.0)))), 36) for i in range(90)]
+    xs = [min(int(math.floor(i * (1.0 / (128 / 53.0)))), 52) for i in range(128)]
+    assert np.array_equal(out, img[np.array(ys)][:, np.array(xs)])
+
+
+def _lipschitz(img, border):
+    """largest jump between neighbouring samples of the image extended by the constant border: the bilinear interpolant moves by at
+    most this much per pixel of coordinate error along an axis"""
+    p = np.pad(img.astype(np.float64), 1, constant_values=border)
+    return max(np.abs(np.diff(p, axis=0)).max(), np.abs(np.diff(p, axis=1)).max())
+
+
+def test_bilinear_warps_cross_checked_against_scipy(ND):
+    """warp_affine / warp_perspective (the restatements of cv2.warpAffine / warpPerspective the augmentation uses,
+    dataloader/loader.py:53-179) against an INDEPENDENT bilinear sampler -- scipy.ndimage.map_coordinates(order=1,
+    mode='grid-constant') at the exact inverse-mapped coordinates.  OpenCV quantises source coordinates to 1/32 pixel (INTER_BITS = 5)
+    with round-to-nearest, i.e. up to 1/64 pixel of coordinate error per axis (plus 2^-10-pixel rounding of the affine increments), so
+    the two may differ by at most L * (1/64 + 1/64 + slack) where L bounds the jump between neighbouring samples.  That turns 'compared with
+    itself' into 'cross-checked within the fixed-point bound'; OpenCV's own rounding stays unverified (no cv2 here: pin_report.json)."""
+    from scipy import ndimage
+    rng = np.random.RandomState(7)
+    yy, xx = np.mgrid[0:128, 0:128].astype(np.float64)
+    worst = 0.0
+    for trial in range(24):
+        img = (300.0 + 40.0 * np.sin(xx / (5.0 + trial)) * np.cos(yy / (7.0 + trial % 5)) + 10.0 * rng.rand(128, 128)).astype(np.float32)
+        border = float(rng.choice([0.0, 300.0]))
+        L = _lipschitz(img, border)
+        ang, sc = rng.uniform(-180, 180), rng.uniform(0.8, 1.25)
+        M = ND.rotation_matrix_2d((64.0 + rng.uniform(-3, 3), 64.0 + rng.uniform(-3, 3)), ang, sc)
+        M[:, 2] += rng.uniform(-12, 12, 2)
+        got = ND.warp_affine(img, M, (128, 128), border)
+        iM = np.linalg.inv(np.vstack([M, [0, 0, 1]]))
+        sx, sy = iM[0, 0] * xx + iM[0, 1] * yy + iM[0, 2], iM[1, 0] * xx + iM[1, 1] * yy + iM[1, 2]
+        ref = ndimage.map_coordinates(img.astype(np.float64), [sy, sx], order=1, mode="grid-constant", cval=border)
+        err = np.abs(got - ref).max()
+        assert err <= L * (2.0 / 64 + 2.0 / 1024) + 1e-3, ("affine", trial, err, L)
+        worst = max(worst, err / L)
+        # homography: the same similarity plus a small projective part (what a scale / rotation augmentation composes to is affine;
+        # warpPerspective is called with such matrices in homogeneous form, loader.py:127-151)
+        Hm = np.vstack([M, [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]])
+        got = ND.warp_perspective(img, Hm, (128, 128), border)
+        iH = np.linalg.inv(Hm)
+        wq = iH[2, 0] * xx + iH[2, 1] * yy + iH[2, 2]
+        sx, sy = (iH[0, 0] * xx + iH[0, 1] * yy + iH[0, 2]) / wq, (iH[1, 0] * xx + iH[1, 1] * yy + iH[1, 2]) / wq
+        ref = ndimage.map_coordinates(img.astype(np.float64), [sy, sx], order=1, mode="grid-constant", cval=border)
+        err = np.abs(got - ref).max()
+        assert err <= L * (2.0 / 64) + 1e-3, ("perspective", trial, err, L)
+        worst = max(worst, err / L)
+    assert worst > 1e-4      # the quantisation is really there (a float sampler would agree to rounding)

@@ -63,10 +63,10 @@ def main():
     torch.cuda.synchronize()
     hip = eng.plan.tensors()
     # the float64 yardstick with the ReLU decisions of each implementation (tests/yardstick.py)
-    fl32 = Y.decisions_from_trace(ref, f32)
-    flh, rep_h = Y.decisions_from_plan(ref, eng.plan.tensors(lazy=True))
-    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, args.cw, True, flips=fl32)
-    ref_hip = Y.trace(net, sd, img, jt_gt, ks, args.cw, True, flips=flh)
+    fl32, pl32 = Y.decisions_from_trace(ref, f32)
+    flh, plh, rep_h = Y.decisions_from_plan(ref, eng.plan.tensors(lazy=True))
+    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, args.cw, True, flips=fl32, pools=pl32)
+    ref_hip = Y.trace(net, sd, img, jt_gt, ks, args.cw, True, flips=flh, pools=plh)
     lines = []
     P = lines.append
     P("# %s cw=%g seed=%d wseed=%d B=%d streams=%d det=%d NO_DUAL=%s | loss hip %.9g  f32 %.9g  f64 %.9g" % (
@@ -75,7 +75,7 @@ def main():
     for k in Y.kink_table(ref):
         P("#   %-36s n=%d  grad share %.2e" % k)
     P("# ReLU decisions that differ from float64's: HIP %s" % (rep_h,))
-    P("#                                    fp32 oracle %s" % ([(t, int(v.sum()), float(ref["relus"][t][0][v].abs().max())) for t, v in fl32.items() if bool(v.any())],))
+    P("#                                    fp32 oracle %s + max-pools %s" % ([(t, int(v.sum()), float(ref["relus"][t][0][v].abs().max())) for t, v in fl32.items() if bool(v.any())], sorted(pl32)))
 
     def oracle_name(hn):
         """HIP tensor name -> (oracle record name(s) summed, channel count)"""

@@ -421,7 +421,13 @@ def main():
                 "vector exists and these three resamplers are UNPINNED.  The entries below ran the reference's augmentation with its cv2 calls "
                 "forwarded to those restatements, i.e. they compare the build with itself (they pin the surrounding logic only).  "
                 "tests/test_nyu_data_cpu.py holds analytic known-answer cases (integer shifts, 90/180 degree turns, exact x2 scale, identity) "
-                "that any correct nearest / bilinear implementation must reproduce bit for bit.",
+                "that any correct nearest / bilinear implementation must reproduce bit for bit.  Round 3: CROSS-CHECKED against independent "
+                "implementations -- resize_nearest against a literal scalar restatement of OpenCV's resizeNN index rule (fx = dst/src, ifx = 1/fx, "
+                "floor(i*ifx): the division order matters for ~5 % of size pairs), warp_affine / warp_perspective against "
+                "scipy.ndimage.map_coordinates(order=1, mode='grid-constant') at the exact inverse-mapped coordinates within the 1/32-pixel "
+                "fixed-point bound L*(1/64+1/64) (tests/test_nyu_data_cpu.py::test_bilinear_warps_cross_checked_against_scipy).  "
+                "Status: cross-checked, cv2's own rounding unverified.",
+        "cross_check_bound": "max |delta| <= L * (2/64 + 2/1024) (affine) / L * 2/64 (perspective), L = largest jump between neighbouring samples incl. the border value",
         "functions": ["nyu_data.resize_nearest", "nyu_data.warp_affine", "nyu_data.warp_perspective"],
         "self_comparisons": {k: {"max_abs_diff": v[0], "tolerance": v[1], "comparisons": v[2]} for k, v in sorted(SELF.items())},
     }
