@@ -133,25 +133,44 @@ static std::string fmt(const char* f, ...) {
     return buf;
 }
 
-// get_deconv_net(18, J, downsample).state_dict() (resnet_deconv.py:31-53)
-static void resnet18_layout(Layout& L, int J, int downsample) {
+// get_deconv_net(depth, J, downsample).state_dict() (resnet_deconv.py:8-16, :31-53): BasicBlock [2,2,2,2] for depth 18, Bottleneck
+// (expansion 4) [3,4,6,3] / [3,4,23,3] / [3,8,36,3] for 50 / 101 / 152.  Registration order inside a block: conv1, bn1, conv2, bn2,
+// (conv3, bn3,) downsample (resnet_deconv.py:148-156, :182-195).
+static const int* resnet_blocks(int depth) {
+    static const int b18[4] = {2, 2, 2, 2}, b50[4] = {3, 4, 6, 3}, b101[4] = {3, 4, 23, 3}, b152[4] = {3, 8, 36, 3};
+    return depth == 50 ? b50 : depth == 101 ? b101 : depth == 152 ? b152 : b18;
+}
+
+static void resnet_layout(Layout& L, int depth, int J, int downsample) {
+    const bool bott = depth != 18;
+    const int exp = bott ? 4 : 1;
+    const int* nb = resnet_blocks(depth);
     L.add("pre.0.weight", {64, 1, 5, 5}, CONV_W);
     L.bn("pre.1", 64);
     int cin = 64;
     const int planes_[4] = {64, 128, 256, 512};
     for (int li = 1; li <= 4; ++li) {
         const int planes = planes_[li - 1];
-        for (int bi = 0; bi < 2; ++bi) {
+        for (int bi = 0; bi < nb[li - 1]; ++bi) {
             const std::string p = fmt("layer%d.%d", li, bi);
-            L.add(p + ".conv1.weight", {planes, cin, 3, 3}, CONV_W);
-            L.bn(p + ".bn1", planes);
-            L.add(p + ".conv2.weight", {planes, planes, 3, 3}, CONV_W);
-            L.bn(p + ".bn2", planes);
-            if (bi == 0 && cin != planes) {
-                L.add(p + ".downsample.0.weight", {planes, cin, 1, 1}, CONV_W);
-                L.bn(p + ".downsample.1", planes);
+            if (!bott) {
+                L.add(p + ".conv1.weight", {planes, cin, 3, 3}, CONV_W);
+                L.bn(p + ".bn1", planes);
+                L.add(p + ".conv2.weight", {planes, planes, 3, 3}, CONV_W);
+                L.bn(p + ".bn2", planes);
+            } else {
+                L.add(p + ".conv1.weight", {planes, cin, 1, 1}, CONV_W);
+                L.bn(p + ".bn1", planes);
+                L.add(p + ".conv2.weight", {planes, planes, 3, 3}, CONV_W);
+                L.bn(p + ".bn2", planes);
+                L.add(p + ".conv3.weight", {planes * exp, planes, 1, 1}, CONV_W);
+                L.bn(p + ".bn3", planes * exp);
             }
-            cin = planes;
+            if (bi == 0 && (li > 1 || cin != planes * exp)) {      // _make_layer: stride != 1 or inplanes != planes * expansion
+                L.add(p + ".downsample.0.weight", {planes * exp, cin, 1, 1}, CONV_W);
+                L.bn(p + ".downsample.1", planes * exp);
+            }
+            cin = planes * exp;
         }
     }
     int lg = 0;
@@ -414,6 +433,7 @@ struct awr_plan;
 
 struct awr_net {
     int kind = 0, nstack = 1, J = 14, downsample = 2, f = 256;
+    int depth = 18;                      // kind 0: ResNet depth (18 BasicBlock; 50 / 101 / 152 Bottleneck)
     int nstage = 1, ndeconv = 3;
     Layout layout;
     float *params = nullptr, *grads = nullptr, *buffers = nullptr;
@@ -504,19 +524,31 @@ static int make_layers(awr_net* n) {
         n->bns["pre.1"] = bn_layer(n, "pre.1");
         int cin = 64;
         const int planes_[4] = {64, 128, 256, 512}, stride_[4] = {1, 2, 2, 2};
+        const bool bott = n->depth != 18;
+        const int exp = bott ? 4 : 1;
+        const int* nb = resnet_blocks(n->depth);
         for (int li = 1; li <= 4; ++li)
-            for (int bi = 0; bi < 2; ++bi) {
+            for (int bi = 0; bi < nb[li - 1]; ++bi) {
                 const std::string p = fmt("layer%d.%d", li, bi);
                 const int planes = planes_[li - 1], s = bi == 0 ? stride_[li - 1] : 1;
-                n->convs[p + ".conv1"] = conv_layer(n, p + ".conv1.weight", make_spec(false, cin, planes, 3, s, 1));
-                n->bns[p + ".bn1"] = bn_layer(n, p + ".bn1");
-                n->convs[p + ".conv2"] = conv_layer(n, p + ".conv2.weight", make_spec(false, planes, planes, 3, 1, 1));
-                n->bns[p + ".bn2"] = bn_layer(n, p + ".bn2");
-                if (bi == 0 && cin != planes) {
-                    n->convs[p + ".downsample.0"] = conv_layer(n, p + ".downsample.0.weight", make_spec(false, cin, planes, 1, s, 0));
+                if (!bott) {
+                    n->convs[p + ".conv1"] = conv_layer(n, p + ".conv1.weight", make_spec(false, cin, planes, 3, s, 1));
+                    n->bns[p + ".bn1"] = bn_layer(n, p + ".bn1");
+                    n->convs[p + ".conv2"] = conv_layer(n, p + ".conv2.weight", make_spec(false, planes, planes, 3, 1, 1));
+                    n->bns[p + ".bn2"] = bn_layer(n, p + ".bn2");
+                } else {      // Bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 x4 (resnet_deconv.py:177-215)
+                    n->convs[p + ".conv1"] = conv_layer(n, p + ".conv1.weight", make_spec(false, cin, planes, 1, 1, 0));
+                    n->bns[p + ".bn1"] = bn_layer(n, p + ".bn1");
+                    n->convs[p + ".conv2"] = conv_layer(n, p + ".conv2.weight", make_spec(false, planes, planes, 3, s, 1));
+                    n->bns[p + ".bn2"] = bn_layer(n, p + ".bn2");
+                    n->convs[p + ".conv3"] = conv_layer(n, p + ".conv3.weight", make_spec(false, planes, planes * exp, 1, 1, 0));
+                    n->bns[p + ".bn3"] = bn_layer(n, p + ".bn3");
+                }
+                if (n->layout.has(p + ".downsample.0.weight")) {
+                    n->convs[p + ".downsample.0"] = conv_layer(n, p + ".downsample.0.weight", make_spec(false, cin, planes * exp, 1, s, 0));
                     n->bns[p + ".downsample.1"] = bn_layer(n, p + ".downsample.1");
                 }
-                cin = planes;
+                cin = planes * exp;
             }
         for (int i = 0; i < n->ndeconv; ++i) {
             n->convs[fmt("deconv_layers.%d", 3 * i)] = conv_layer(n, fmt("deconv_layers.%d.weight", 3 * i), make_spec(true, cin, 256, 4, 2, 1));
@@ -1456,22 +1488,29 @@ struct NetBuilder {
 
     void resnet(float* img, int H, float* out, float* gout) {
         Tn* c = b.stem(img, C("pre.0"), BN("pre.1"), H, H, true);      // conv 5x5 -> BN -> ReLU -> MaxPool(3,2,1), one fused kernel family
+        const bool bott = N.depth != 18;
+        const int* nb = resnet_blocks(N.depth);
         for (int li = 1; li <= 4; ++li)
-            for (int bi = 0; bi < 2; ++bi) {
+            for (int bi = 0; bi < nb[li - 1]; ++bi) {
                 const std::string p = fmt("layer%d.%d", li, bi);
                 Tn* r;
-                if (N.convs.count(p + ".downsample.0")) {   // 1x1 stride-2 projection + its BatchNorm: independent of conv1 / conv2 until the residual add
+                if (N.convs.count(p + ".downsample.0")) {   // 1x1 projection (+ stride) + its BatchNorm: independent of the main branch until the residual add
                     b.fork(0);
                     r = cbr(c, p + ".downsample.0", p + ".downsample.1", false);
                     b.end_fork(r);
                 } else {
                     r = c;
                 }
-                // bn1 + ReLU feeds conv2 only: un-materialised (applied by conv2's loaders) while that is cheaper than one write +
-                // read of the tensor -- the loader arithmetic costs 8-15 % of a GEMM whose K grows with the channel count, the
-                // tensor pass does not: beyond 128 channels the activation is written out
+                // bn1 (+ bn2 of a Bottleneck) + ReLU feed ONE conv only: un-materialised (applied by that conv's loaders) while that is
+                // cheaper than one write + read of the tensor -- the loader arithmetic costs 8-15 % of a GEMM whose K grows with the
+                // channel count, the tensor pass does not: beyond 128 channels the activation is written out
                 Tn* o = cbr(c, p + ".conv1", p + ".bn1", true, nullptr, C(p + ".conv1")->spec.cout <= 128);
-                c = cbr(o, p + ".conv2", p + ".bn2", true, r);
+                if (!bott) {
+                    c = cbr(o, p + ".conv2", p + ".bn2", true, r);
+                } else {
+                    o = cbr(o, p + ".conv2", p + ".bn2", true, nullptr, C(p + ".conv2")->spec.cout <= 128);
+                    c = cbr(o, p + ".conv3", p + ".bn3", true, r);
+                }
             }
         for (int i = 0; i < N.ndeconv; ++i)   // feeds the next transposed conv (K = 4 x 256 per phase: materialised) or the 1x1 head GEMM (lazy)
             c = cbr(c, fmt("deconv_layers.%d", 3 * i), fmt("deconv_layers.%d", 3 * i + 1), true, nullptr, i == N.ndeconv - 1);
@@ -1886,16 +1925,19 @@ int awr_net_create(int kind, int nstack, int J, int downsample, awr_net** out) {
     AWR_REQUIRE(J >= 1 && J <= 64, "net_create: J=%d joints", J);
     AWR_REQUIRE(kind == 1 || downsample == 1 || downsample == 2 || downsample == 4, "net_create: downsample must be 1, 2 or 4 (config.py:31)");
     AWR_REQUIRE(kind == 0 || (nstack >= 1 && nstack <= 8), "net_create: nstack=%d", nstack);
+    AWR_REQUIRE(kind == 1 || nstack == 0 || nstack == 1 || nstack == 18 || nstack == 50 || nstack == 101 || nstack == 152,
+                "net_create: kind 0 takes the ResNet depth in `nstack`: 18 (also 0 / 1), 50, 101 or 152 (resnet_deconv.py:9-13), got %d", nstack);
     awr_net* n = new awr_net();
     n->kind = kind;
     n->J = J;
     if (kind == 0) {
+        n->depth = nstack <= 1 ? 18 : nstack;
         n->nstack = n->nstage = 1;
         n->downsample = downsample;
         int lg = 0;
         while ((1 << lg) < downsample) ++lg;
         n->ndeconv = 4 - lg;
-        resnet18_layout(n->layout, J, downsample);
+        resnet_layout(n->layout, n->depth, J, downsample);
     } else {
         n->nstack = n->nstage = nstack;
         n->downsample = 2;

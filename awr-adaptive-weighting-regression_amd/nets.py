@@ -226,13 +226,14 @@ class _BackboneFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------
-class ResNet18Deconv(AwrBackbone):
-    """get_deconv_net(18, J, downsample): resnet_deconv.py:8-16, :19-136, BasicBlock :145-174."""
+class ResNetDeconv(AwrBackbone):
+    """get_deconv_net(depth, J, downsample): resnet_deconv.py:8-16, :19-136; BasicBlock (:145-174) for depth 18, Bottleneck (:177-215)
+    for 50 / 101 / 152."""
 
-    def __init__(self, J, downsample=2):
-        self.downsample = downsample
+    def __init__(self, J, downsample=2, depth=18):
+        self.downsample, self.depth = downsample, depth
         self.ndeconv = 4 - int(math.log2(downsample))
-        super().__init__(0, 1, J, downsample)
+        super().__init__(0, depth, J, downsample)           # (kind 0 takes the depth in the `nstack` slot of awr_net_create)
 
     def _init_conv(self, key, shape, kind, g):
         if kind == "deconv_w" or key.startswith("final"):
@@ -241,6 +242,11 @@ class ResNet18Deconv(AwrBackbone):
 
     def _init_bias(self, key, shape, wshape, g):
         return torch.zeros(shape)                                                    # :110, :114
+
+
+class ResNet18Deconv(ResNetDeconv):
+    def __init__(self, J, downsample=2):
+        super().__init__(J, downsample, 18)
 
 
 class HourglassNet(AwrBackbone):

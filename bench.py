@@ -118,6 +118,11 @@ def cpu_baseline():
                       "is the same step at the best thread count of a {8,16,32,64,all} sweep (1 warm-up, median of 3)" % (cores, cores)}
 
 
+def _make_net(awr_amd, name, J=14):
+    """'resnet_<18|50|101|152>' | 'hourglass_<n>' (train.py:51-57)"""
+    return awr_amd.get_deconv_net(int(name.split("_")[1]), J, 2) if name.startswith("resnet") else awr_amd.PoseNet(name, J)
+
+
 def parity_mm(net_name, ks, dev):
     """mean / max 3D joint difference (mm, 300 mm cube => x150) between the HIP path and the oracle, eval mode."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -126,7 +131,7 @@ def parity_mm(net_name, ks, dev):
     from awr_amd.trainer import InferEngine
     img, _ = O.synth_batch(4, 128, 14, seed=99)
     sd = O.procedural_state(O.manifest_for(net_name, 14), seed=0)
-    m = awr_amd.get_deconv_net(18, 14, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, 14)
+    m = _make_net(awr_amd, net_name)
     m.load_state_dict(sd)
     m = m.cuda()
     jt = InferEngine(m, 4, 128, ks, use_graph=False)(img.to(dev)).cpu()
@@ -151,7 +156,7 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
     ks = 1.0 if net_name.startswith("resnet") else 0.4
     if net is None:
         torch.manual_seed(0)
-        net = (awr_amd.get_deconv_net(18, 14, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, 14)).cuda()
+        net = _make_net(awr_amd, net_name).cuda()
     inf = InferEngine(net, batch, 128, ks, use_graph=graph)
     imgs, _ = O.synth_batch(batch, 128, 14, seed=1234 + rank)
     imgs = imgs.to(dev)
@@ -297,7 +302,7 @@ def main():
     # MFMA roofline of the mode: FP32 MFMA peak, or the bf16 dense peak against 6 MFMA flops per algorithmic flop
     peak_tf, flop_mult = (PEAK_FP32_MFMA_TFLOPS, 1) if nprod == 1 else (PEAK_BF16_MFMA_TFLOPS, 6)
     torch.manual_seed(0)
-    net = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
+    net = _make_net(awr_amd, args.net).cuda()
     if args.mode == "infer":
         res = measure_inference(awr_amd, O, args.net, args.batch, dev, rank, args.steps, max(args.warmup, 3), args.graph, peak_tf, flop_mult,
                                 per_layer=args.per_layer, net=net)
@@ -392,7 +397,7 @@ def main():
     traffic, traffic_src = None, None
     tfiles = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))
     tpath = os.path.join(REPO, "profiles", tfiles[-1]) if tfiles else ""
-    if tpath and args.net.startswith("resnet") and args.batch == 64 and nprod == 1:      # the PMC passes profile exactly this command
+    if tpath and args.net == "resnet_18" and args.batch == 64 and nprod == 1:      # the PMC passes profile exactly this command
         tj = json.load(open(tpath))
         key = "conv_gemm_kernel" if dom.startswith("conv_gemm") else "conv_wgrad_kernel"
         ent = [v for k, v in tj.items() if key in k]
@@ -438,7 +443,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s-deconv NYU-shape 128x128 J=14 train step (GT-map+fwd+head+Huber+bwd+Adam), batch %d/GPU%s" % (
-                           args.net, args.batch, {64: " = BASELINE configs[1]", 256: " = BASELINE configs[3] per-GPU shape"}.get(args.batch, ""))
+                           args.net, args.batch, {64: " = BASELINE configs[1]", 256: " = BASELINE configs[3] per-GPU shape"}.get(args.batch, "") if args.net == "resnet_18" else "")
                        if args.net.startswith("resnet") else "%s NYU-shape 128x128 J=14 train step, batch %d/GPU" % (args.net, args.batch),
                        "global_batch": world * args.batch, "img_size": 128, "joints": 14, "parallelism": "dp%d" % world,
                        "kernel_size": ks, "coord_weight": args.coord_weight, "dense_weight": 1.0, "hipgraph": graph, "wgrad_streams": args.wgrad_streams, "independent_hw_queues_for_side_streams": _pool_info(L),
@@ -457,7 +462,7 @@ def main():
     # config 4's per-GPU shape (batch 256 / GPU: north_star states its scaling target there) beside the batch-64 headline, same protocol,
     # every rank takes part (the all-reduce is part of the step)
     b256 = None
-    if args.batch != 256 and args.net.startswith("resnet") and nprod == 1 and not args.no_b256 and not args.deterministic:
+    if args.batch != 256 and args.net == "resnet_18" and nprod == 1 and not args.no_b256 and not args.deterministic:
         del eng
         torch.cuda.empty_cache()
         eng2 = TrainEngine(net, 256, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg, use_graph=args.graph,
@@ -487,7 +492,7 @@ def main():
             # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)
             awr_amd.set_gemm_products(6)
             torch.manual_seed(0)
-            net6 = (awr_amd.get_deconv_net(18, 14, 2) if args.net.startswith("resnet") else awr_amd.PoseNet(args.net, 14)).cuda()
+            net6 = _make_net(awr_amd, args.net).cuda()
             eng6 = TrainEngine(net6, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, use_graph=args.graph,
                                wgrad_streams=args.wgrad_streams)
             eng6.compile(img, jt)

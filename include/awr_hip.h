@@ -379,7 +379,8 @@ int awr_nchw_to_nhwc(const float* in, int B, int P, int Cp, int C, float* out, v
 typedef struct awr_net awr_net;
 typedef struct awr_plan awr_plan;
 
-/* kind 0: ResNet18-deconv (nstack ignored); kind 1: stacked hourglass (downsample ignored, feature size H/2).
+/* kind 0: ResNet-deconv -- `nstack` carries the depth: 18 (also 0 / 1; BasicBlock) or 50 / 101 / 152 (Bottleneck), resnet_deconv.py:9-13;
+ * kind 1: stacked hourglass (downsample ignored, feature size H/2).
  * Creates the checkpoint layout only: no device memory is touched until awr_net_bind. */
 int awr_net_create(int kind, int nstack, int J, int downsample, awr_net** out);
 int awr_net_destroy(awr_net* net);

@@ -62,22 +62,37 @@ def _bn_entries(prefix, c):
     ]
 
 
-def resnet18_manifest(J=14, downsample=2):
-    """Ordered (key, shape, kind) list of ResNet18-deconv; resnet_deconv.py:19-53."""
+RESNET_BLOCKS = {18: [2, 2, 2, 2], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}      # resnet_deconv.py:9-13
+
+
+def resnet_manifest(depth=18, J=14, downsample=2):
+    """Ordered (key, shape, kind) list of get_deconv_net(depth, J, downsample); resnet_deconv.py:8-16, :19-53 -- BasicBlock (:145-174)
+    for depth 18, Bottleneck with expansion 4 (:177-215) for 50 / 101 / 152; a block registers conv1, bn1, conv2, bn2, (conv3, bn3,)
+    downsample in that order."""
+    bott = depth != 18
+    exp = 4 if bott else 1
     m = [("pre.0.weight", (64, 1, 5, 5), "conv_w")] + _bn_entries("pre.1", 64)
     cin = 64
     for li, (planes, stride) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)], start=1):
-        for bi in range(2):
+        for bi in range(RESNET_BLOCKS[depth][li - 1]):
             p = "layer%d.%d" % (li, bi)
             s = stride if bi == 0 else 1
-            m.append((p + ".conv1.weight", (planes, cin, 3, 3), "conv_w"))
-            m += _bn_entries(p + ".bn1", planes)
-            m.append((p + ".conv2.weight", (planes, planes, 3, 3), "conv_w"))
-            m += _bn_entries(p + ".bn2", planes)
-            if bi == 0 and (s != 1 or cin != planes):
-                m.append((p + ".downsample.0.weight", (planes, cin, 1, 1), "conv_w"))
-                m += _bn_entries(p + ".downsample.1", planes)
-            cin = planes
+            if not bott:
+                m.append((p + ".conv1.weight", (planes, cin, 3, 3), "conv_w"))
+                m += _bn_entries(p + ".bn1", planes)
+                m.append((p + ".conv2.weight", (planes, planes, 3, 3), "conv_w"))
+                m += _bn_entries(p + ".bn2", planes)
+            else:
+                m.append((p + ".conv1.weight", (planes, cin, 1, 1), "conv_w"))
+                m += _bn_entries(p + ".bn1", planes)
+                m.append((p + ".conv2.weight", (planes, planes, 3, 3), "conv_w"))
+                m += _bn_entries(p + ".bn2", planes)
+                m.append((p + ".conv3.weight", (planes * exp, planes, 1, 1), "conv_w"))
+                m += _bn_entries(p + ".bn3", planes * exp)
+            if bi == 0 and (s != 1 or cin != planes * exp):
+                m.append((p + ".downsample.0.weight", (planes * exp, cin, 1, 1), "conv_w"))
+                m += _bn_entries(p + ".downsample.1", planes * exp)
+            cin = planes * exp
     ndeconv = 4 - int(math.log2(downsample))
     for i in range(ndeconv):
         m.append(("deconv_layers.%d.weight" % (3 * i), (cin, 256, 4, 4), "deconv_w"))
@@ -86,6 +101,10 @@ def resnet18_manifest(J=14, downsample=2):
     m += [("final1.weight", (3 * J, 256, 1, 1), "conv_w"), ("final1.bias", (3 * J,), "conv_b"),
           ("final2.weight", (J, 256, 1, 1), "conv_w"), ("final2.bias", (J,), "conv_b")]
     return m
+
+
+def resnet18_manifest(J=14, downsample=2):
+    return resnet_manifest(18, J, downsample)
 
 
 def _hg_conv(prefix, cin, cout, k, bn):
@@ -136,10 +155,9 @@ def hourglass_manifest(nstack=1, J=14, f=256):
 
 
 def manifest_for(net, J):
-    """net: 'resnet_18' | 'hourglass_<n>' (train.py:51-57)."""
+    """net: 'resnet_<18|50|101|152>' | 'hourglass_<n>' (train.py:51-57)."""
     if net.startswith("resnet"):
-        assert net == "resnet_18", "only ResNet18-deconv is on the hot path (BASELINE configs)"
-        return resnet18_manifest(J, 2)
+        return resnet_manifest(int(net.split("_")[-1]), J, 2)
     return hourglass_manifest(int(net.split("_")[-1]), J)
 
 
@@ -237,31 +255,45 @@ def _bn_train(sd, p, x):
     return y
 
 
-def resnet18_forward(sd, x, training=False, downsample=2):
-    """(B,1,H,H) -> (B,4J,H/ds,H/ds); resnet_deconv.py:118-136 with BasicBlock :158-174."""
+def resnet_forward(sd, x, training=False, downsample=2):
+    """(B,1,H,H) -> (B,4J,H/ds,H/ds); resnet_deconv.py:118-136 with BasicBlock :158-174 / Bottleneck :194-215 (told apart by the
+    presence of a third conv in the block)."""
     c = TF.conv2d(x, sd["pre.0.weight"], None, 1, 2)
     c = TF.relu(_bn(sd, "pre.1", c, training))
     c = TF.max_pool2d(c, 3, 2, 1)
     for li, stride in enumerate([1, 2, 2, 2], start=1):
-        for bi in range(2):
+        bi = 0
+        while "layer%d.%d.conv1.weight" % (li, bi) in sd:
             p = "layer%d.%d" % (li, bi)
             s = stride if bi == 0 else 1
-            o = TF.conv2d(c, sd[p + ".conv1.weight"], None, s, 1)
-            o = TF.relu(_bn(sd, p + ".bn1", o, training))
-            o = TF.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1)
-            o = _bn(sd, p + ".bn2", o, training)
+            if p + ".conv3.weight" in sd:          # Bottleneck: 1x1 -> 3x3 (stride) -> 1x1
+                o = TF.conv2d(c, sd[p + ".conv1.weight"], None, 1, 0)
+                o = TF.relu(_bn(sd, p + ".bn1", o, training))
+                o = TF.conv2d(o, sd[p + ".conv2.weight"], None, s, 1)
+                o = TF.relu(_bn(sd, p + ".bn2", o, training))
+                o = TF.conv2d(o, sd[p + ".conv3.weight"], None, 1, 0)
+                o = _bn(sd, p + ".bn3", o, training)
+            else:
+                o = TF.conv2d(c, sd[p + ".conv1.weight"], None, s, 1)
+                o = TF.relu(_bn(sd, p + ".bn1", o, training))
+                o = TF.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1)
+                o = _bn(sd, p + ".bn2", o, training)
             if p + ".downsample.0.weight" in sd:
                 r = TF.conv2d(c, sd[p + ".downsample.0.weight"], None, s, 0)
                 r = _bn(sd, p + ".downsample.1", r, training)
             else:
                 r = c
             c = TF.relu(o + r)
+            bi += 1
     for i in range(4 - int(math.log2(downsample))):
         c = TF.conv_transpose2d(c, sd["deconv_layers.%d.weight" % (3 * i)], None, 2, 1)
         c = TF.relu(_bn(sd, "deconv_layers.%d" % (3 * i + 1), c, training))
     vec = TF.conv2d(c, sd["final1.weight"], sd["final1.bias"])
     ht = TF.conv2d(c, sd["final2.weight"], sd["final2.bias"])
     return torch.cat([vec, ht], 1)
+
+
+resnet18_forward = resnet_forward
 
 
 def _hg_res(sd, p, x, training):
@@ -313,7 +345,7 @@ def hourglass_forward(sd, x, nstack, training=False):
 def backbone_forward(net, sd, x, training=False):
     """Returns a list of per-stage dense maps (length 1 for resnet)."""
     if net.startswith("resnet"):
-        return [resnet18_forward(sd, x, training)]
+        return [resnet_forward(sd, x, training)]
     return hourglass_forward(sd, x, int(net.split("_")[-1]), training)
 
 

@@ -79,13 +79,14 @@ def test_network_level_layout_without_a_gpu(lib):
     import json
     man = json.load(open(os.path.join(REPO, "tests", "golden", "statedict_manifest.json")))
     L = lib
-    for name, (kind, nstack, J) in {"resnet_18_J14": (0, 1, 14), "hourglass_1_J14": (1, 1, 14), "hourglass_2_J21": (1, 2, 21)}.items():
+    for name, (kind, nstack, J) in {"resnet_18_J14": (0, 1, 14), "resnet_50_J14": (0, 50, 14), "resnet_101_J14": (0, 101, 14),
+                                    "hourglass_1_J14": (1, 1, 14), "hourglass_2_J21": (1, 2, 21)}.items():
         h = C.c_void_p()
         assert L.lib.awr_net_create(kind, nstack, J, 2, C.byref(h)) == 0, L.last_error()
         nt, npar, nact, nbuf, ncnt, nst = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
         assert L.lib.awr_net_sizes(h, C.byref(nt), C.byref(npar), C.byref(nact), C.byref(nbuf), C.byref(ncnt), C.byref(nst)) == 0
         ref = man[name]
-        assert nt.value == len(ref) and nst.value == nstack
+        assert nt.value == len(ref) and nst.value == (nstack if kind == 1 else 1)
         key, kd, nd, off, un = C.c_char_p(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
         shape = (C.c_int64 * 4)()
         spans, n_float, n_unused = [], 0, 0
@@ -110,3 +111,4 @@ def test_network_level_layout_without_a_gpu(lib):
         assert L.lib.awr_net_destroy(h) == 0
     assert L.lib.awr_net_create(2, 1, 14, 2, C.byref(C.c_void_p())) == -1 and "kind" in L.last_error()
     assert L.lib.awr_net_create(0, 1, 14, 3, C.byref(C.c_void_p())) == -1
+    assert L.lib.awr_net_create(0, 34, 14, 2, C.byref(C.c_void_p())) == -1 and "depth" in L.last_error()      # resnet_deconv.py:9-13 builds 18/50/101/152

@@ -33,7 +33,7 @@ def amd():
 
 
 def make_net(amd, net, J, sd):
-    m = amd.get_deconv_net(18, J, 2) if net.startswith("resnet") else amd.PoseNet(net, J)
+    m = amd.get_deconv_net(int(net.split("_")[1]), J, 2) if net.startswith("resnet") else amd.PoseNet(net, J)
     m.load_state_dict(sd, strict=True)
     return m.cuda()
 
@@ -84,7 +84,7 @@ def smp_index(n, i):
     return int(np.minimum(((O._hash_uniform(1, 1000 + 40 + i, 7).astype(np.float64) + 0.5) * n).astype(np.int64), n - 1)[0])
 
 
-@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1", "hourglass_2"])
+@pytest.mark.parametrize("net", ["resnet_18", "resnet_50", "hourglass_1", "hourglass_2"])
 def test_backbone_forward_golden(amd, dev, golden_dir, net):
     g = np.load(os.path.join(golden_dir, "%s_fwd.npz" % net))
     img = torch.from_numpy(g["img"])
@@ -115,6 +115,7 @@ def test_backbone_forward_golden(amd, dev, golden_dir, net):
             for i, k in enumerate(g["bn_keys"]):
                 np.testing.assert_allclose(got_sd[str(k)].cpu().numpy(), g["bn_%d" % i], rtol=2e-4, atol=2e-5)
             assert int(got_sd["pre.1.num_batches_tracked" if net.startswith("resnet") else "pre.0.bn.num_batches_tracked"]) == 1
+            assert len(got_sd) == len(man)
 
 
 def check_grad_norms(m, pkeys, ref_l2, ref_smp=None):
@@ -144,7 +145,7 @@ def check_grad_norms(m, pkeys, ref_l2, ref_smp=None):
     return worst
 
 
-@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1", "hourglass_2"])
+@pytest.mark.parametrize("net", ["resnet_18", "resnet_50", "hourglass_1", "hourglass_2"])
 @pytest.mark.parametrize("tag,cw", [("c0", 0.0), ("c1", 1.0)])
 def test_fused_train_step_golden(amd, dev, golden_dir, net, tag, cw):
     from awr_amd.trainer import TrainEngine

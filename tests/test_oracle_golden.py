@@ -21,7 +21,8 @@ def _hashed(shape, stream, scale):
 
 def test_manifest_matches_reference_checkpoint_layout(golden_dir):
     man = json.load(open(os.path.join(golden_dir, "statedict_manifest.json")))
-    for name, (net, J) in {"resnet_18_J14": ("resnet_18", 14), "hourglass_1_J14": ("hourglass_1", 14),
+    for name, (net, J) in {"resnet_18_J14": ("resnet_18", 14), "resnet_50_J14": ("resnet_50", 14), "resnet_101_J14": ("resnet_101", 14),
+                           "hourglass_1_J14": ("hourglass_1", 14),
                            "hourglass_2_J21": ("hourglass_2", 21)}.items():
         ours = O.manifest_for(net, J)
         assert [k for k, _, _ in ours] == [e[0] for e in man[name]]
@@ -77,7 +78,7 @@ def test_huber(golden_dir):
     np.testing.assert_allclose(gx.numpy(), (z.clamp(-0.01, 0.01) / z.numel()).numpy(), rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1", "hourglass_2"])
+@pytest.mark.parametrize("net", ["resnet_18", "resnet_50", "hourglass_1", "hourglass_2"])
 def test_backbone_forward(golden_dir, net):
     g = _load(golden_dir, "%s_fwd.npz" % net)
     img = torch.from_numpy(g["img"])

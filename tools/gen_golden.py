@@ -68,7 +68,7 @@ def hashed(shape, stream, scale):
 
 
 def build_ref_net(net, J, get_deconv_net, PoseNet):
-    return get_deconv_net(18, J, 2) if net.startswith("resnet") else PoseNet(net, J)
+    return get_deconv_net(int(net.split("_")[1]), J, 2) if net.startswith("resnet") else PoseNet(net, J)
 
 
 def main():
@@ -82,7 +82,7 @@ def main():
     # ---- (b) checkpoint layout --------------------------------------------------------------
     print("[manifest]")
     man = {}
-    for net, J in [("resnet_18", 14), ("hourglass_1", 14), ("hourglass_2", 21)]:
+    for net, J in [("resnet_18", 14), ("resnet_50", 14), ("resnet_101", 14), ("hourglass_1", 14), ("hourglass_2", 21)]:
         ref_sd = build_ref_net(net, J, get_deconv_net, PoseNet).state_dict()
         ours = O.manifest_for(net, J)
         assert [k for k, _, _ in ours] == list(ref_sd.keys()), net
@@ -144,7 +144,7 @@ def main():
 
     # ---- a1-a3 backbones (procedural weights) --------------------------------------------------
     print("[backbones a1-a3]")
-    for net, J, H, B in [("resnet_18", 14, 128, 2), ("hourglass_1", 14, 128, 2), ("hourglass_2", 21, 128, 1)]:
+    for net, J, H, B in [("resnet_18", 14, 128, 2), ("resnet_50", 14, 128, 2), ("hourglass_1", 14, 128, 2), ("hourglass_2", 21, 128, 1)]:
         man_ = O.manifest_for(net, J)
         img, _ = O.synth_batch(B, H, J, seed=13)
         ks = 1.0 if net.startswith("resnet") else 0.4
@@ -179,7 +179,7 @@ def main():
 
     # ---- a8/a9 full train step ------------------------------------------------------------------
     print("[train step a8/a9]")
-    for net, J, B in [("resnet_18", 14, 2), ("hourglass_1", 14, 2), ("hourglass_2", 14, 1)]:
+    for net, J, B in [("resnet_18", 14, 2), ("resnet_50", 14, 2), ("hourglass_1", 14, 2), ("hourglass_2", 14, 1)]:
         man_ = O.manifest_for(net, J)
         pkeys = O.params_of(None, man_)
         img, jt_gt = O.synth_batch(B, 128, J, seed=14)
