@@ -61,7 +61,7 @@ def oracle_fp64_joint_gap(net, sd, img, ks, training, stages=None):
     gaps = []
     for a, b in zip(j32, j64):
         d = (a.double() - b).norm(dim=-1) * 150.0
-        gaps.append((float(d.mean()), float(d.max())))
+        gaps.append((float(d.mean()), float(d.max()), b))          # [2] = the float64 joints (assert_joints reports HIP's own distance from them)
     return gaps
 
 
@@ -75,6 +75,8 @@ def assert_joints(name, got, ref, gap):
     report(name + "/joint_err_mm_mean", mean)
     report(name + "/joint_err_mm", mx)
     report(name + "/oracle_fp32_vs_fp64_gap_mm_mean", gap[0])
+    if len(gap) > 2 and tuple(gap[2].shape) == tuple(np.asarray(got).shape):      # how far the HIP joints themselves sit from float64
+        report(name + "/hip_vs_fp64_mm_mean", float(np.linalg.norm(np.asarray(got, np.float64) - gap[2].numpy(), axis=-1).mean() * 150.0))
     bar_mean, bar_max = max(NORTH_STAR_MEAN_MM, 3.0 * gap[0]), max(5e-3, 6.0 * gap[1])
     assert mean <= bar_mean and mx <= bar_max, (name, mean, mx, "bars", bar_mean, bar_max, "fp64 gap", gap)
     return mean, mx
