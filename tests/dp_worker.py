@@ -25,7 +25,8 @@ def main():
     for mode, steps in (("same", 2), ("split", 1)):
         torch.manual_seed(1234 + rank)                   # different initial weights per rank: the broadcast must fix that
         net = awr_amd.get_deconv_net(18, 14, 2).cuda()
-        eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, process_group=torch.distributed.group.WORLD, use_graph=False, autotune=False)
+        eng = TrainEngine(net, 2, 128, 1.0, coord_weight=1.0, lr=1e-3, process_group=torch.distributed.group.WORLD, use_graph=False, autotune=False,
+                          native_rccl=os.environ.get("AWR_TEST_NATIVE") == "1")      # 1: the library's own communicator (awr_dp_*) exchanges the buckets
         assert eng.dp and eng.world == world and len(eng.sync.buckets) > 1
         losses, per_step = [], []
         for s in range(steps):

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, backend="gloo"):
+def _run(tmp_path, backend="gloo", native=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -21,7 +21,7 @@ def _run(tmp_path, backend="gloo"):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AWR_TEST_BACKEND=backend,
-                   AWR_DETERMINISTIC="1")
+                   AWR_DETERMINISTIC="1", AWR_TEST_NATIVE="1" if native else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -90,3 +90,16 @@ def test_two_rank_data_parallel_engine_over_rccl(tmp_path):
             assert torch.equal(a, b), mode
     assert torch.equal(r0["same"]["buffers"], r1["same"]["buffers"])
     assert r0["split"]["losses"] != r1["split"]["losses"] and not torch.equal(r0["split"]["buffers"], r1["split"]["buffers"])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one RCCL rank per device)")
+def test_two_rank_data_parallel_engine_over_the_librarys_own_rccl_communicator(tmp_path):
+    """The same run with the bucket exchange issued natively (awr_dp_*: librccl.so through dlopen, awr_plan_set_dp): replicas bitwise
+    equal after every step, and bitwise equal to the torch.distributed transport (same buckets, same SUM, deterministic mode)."""
+    r0, r1 = _run(tmp_path, backend="nccl", native=True)
+    for mode in ("same", "split"):
+        for a, b in zip(r0[mode]["per_step"], r1[mode]["per_step"]):
+            assert torch.equal(a, b), mode
+    t0, _ = _run(tmp_path, backend="nccl", native=False)
+    assert torch.equal(r0["same"]["params"], t0["same"]["params"])

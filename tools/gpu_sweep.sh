@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-box sweep of the configurations quoted in profiles/rNN_summary.md (train batch sizes, deterministic / serial modes, Hourglass, low-batch inference, split-operand mode)
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-C="--no-cpu-baseline --no-parity --no-split-mode --no-extras"
+C="--no-cpu-baseline --no-parity --no-split-mode --no-extras --no-b256"
 run() { n=$1; shift; python bench.py $C "$@" > $OUT/b_sweep_$n.json 2>$OUT/b_sweep_$n.err; python - <<P
 import json
 try:
