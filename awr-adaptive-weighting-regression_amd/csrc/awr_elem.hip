@@ -202,8 +202,11 @@ template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2:
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ msc, const float* __restrict__ msh, int64_t npix,
-                                                         int C, int rows_per_block, int nslots, double* __restrict__ out64, float* __restrict__ out32) {
-    const int C4 = C >> 2;
+                                                         int C, int Cw, int rows_per_block, int nslots, double* __restrict__ out64, float* __restrict__ out32) {
+    // blockIdx.y walks chunks of Cw <= 1024 channels (the 2048-channel maps of the Bottleneck ResNets): the row pitch stays C
+    const int cb = blockIdx.y * Cw;
+    if (Cw > C - cb) Cw = C - cb;
+    const int C4 = Cw >> 2;
     const int rpp = 256 / C4;  // row groups per pass
     const int cg = threadIdx.x % C4, rg = threadIdx.x / C4;
     const bool active = rg < rpp;
@@ -214,18 +217,18 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
     float4 ks = make_float4(0, 0, 0, 0), kt = make_float4(0, 0, 0, 0);
     if (MODE == 1 && active) {
-        mu = ld4(mean + cg * 4);
-        is = ld4(invstd + cg * 4);
+        mu = ld4(mean + cb + cg * 4);
+        is = ld4(invstd + cb + cg * 4);
         if (msc) {
-            ks = ld4(msc + cg * 4);
-            kt = ld4(msh + cg * 4);
+            ks = ld4(msc + cb + cg * 4);
+            kt = ld4(msh + cb + cg * 4);
         }
     }
     // MODE 0: sums shifted by the thread's first row (nearly constant channels: csrc/awr_conv.hip, gemm_epilogue), converted back
     // to the plain sums in fp64 before the cross-thread combine
     float4 c0 = make_float4(0, 0, 0, 0);
     int nrows = 0;
-    if (MODE == 0 && active && r0 + rg < r1) c0 = ld4(x + (r0 + rg) * C + cg * 4);
+    if (MODE == 0 && active && r0 + rg < r1) c0 = ld4(x + (r0 + rg) * C + cb + cg * 4);
     // one row (all operands) -> partial sums
     auto accum = [&](float4 v, float4 aa, float4 yy) {
         if (MODE == 0) {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             float4 v[U], aa[U], yy[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t o = (r + (int64_t)u * rpp) * C + cg * 4;
+                const int64_t o = (r + (int64_t)u * rpp) * C + cb + cg * 4;
                 v[u] = ld4(x + o);
                 aa[u] = (MODE == 1 && act) ? ld4(act + o) : z4;
                 yy[u] = (MODE == 1) ? ld4(y + o) : z4;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             for (int u = 0; u < U; ++u) accum(v[u], aa[u], yy[u]);
         }
         for (; r < r1; r += rpp) {
-            const int64_t o = r * C + cg * 4;
+            const int64_t o = r * C + cb + cg * 4;
             accum(ld4(x + o), (MODE == 1 && act) ? ld4(act + o) : z4, (MODE == 1) ? ld4(y + o) : z4);
         }
     }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = threadIdx.x * 4 + k;
+            const int c = cb + threadIdx.x * 4 + k;
             if (MODE == 2) {
                 atomicAdd(out32 + c, (float)a[k]);
             } else {
@@ -551,20 +554,22 @@ static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 // workgroups: a caller that allocates that many copies gets one workgroup per copy (deterministic mode).
 static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd,
                              const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, int nslots, hipStream_t st) {
-    AWR_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "channel reduction: C=%d must be a multiple of 4 in [4,1024]", C);
+    AWR_REQUIRE(C % 4 == 0 && C >= 4 && (C <= 1024 || C % 1024 == 0), "channel reduction: C=%d must be a multiple of 4 up to 1024, or a multiple of 1024", C);
     AWR_REQUIRE(npix > 0 && nslots >= 0, "channel reduction: empty tensor");
     if (nslots == 0) nslots = AWR_STAT_SLOTS;
-    const int rpp = 256 / (C / 4);
+    const int Cw = C <= 1024 ? C : 1024;
+    const unsigned nchunk = (unsigned)(C / Cw);
+    const int rpp = 256 / (Cw / 4);
     int64_t rows = (npix + AWR_REDUCE_MAX_BLOCKS - 1) / AWR_REDUCE_MAX_BLOCKS;  // <= 1024 workgroups; their atomics are spread over the slot copies
     if (rows < 64) rows = 64;
     rows = (rows + rpp - 1) / rpp * rpp;
     const unsigned grid = (unsigned)((npix + rows - 1) / rows);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
     else if (mode == 1)
-        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, (int)rows, nslots, out64, out32);
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
     return check_launch("col_reduce_kernel");
 }
 

@@ -273,6 +273,14 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_spawn_ranks(args.gpus))          # plain `python bench.py --gpus N`: be our own launcher
+    # stdout carries exactly ONE line, the JSON record: libraries that print banners on file descriptor 1 (RCCL's version block at
+    # communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("AWR_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))     # AWR_FORCE_DEVICE: test hook (several ranks on one GPU)
@@ -306,10 +314,10 @@ def main():
     if args.mode == "infer":
         res = measure_inference(awr_amd, O, args.net, args.batch, dev, rank, args.steps, max(args.warmup, 3), args.graph, peak_tf, flop_mult,
                                 per_layer=args.per_layer, net=net)
-        print(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": res["value"], "unit": "images/s",
+        emit(json.dumps({"metric": "depth-images/sec (inference, img -> joints)", "value": res["value"], "unit": "images/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                           "dtype": dtype, "data": "synthetic", "config": {"workload": res["workload"], "hipgraph": bool(args.graph), "gemm_products": nprod},
-                          "mfma_frac": res["mfma_frac"]}), flush=True)
+                          "mfma_frac": res["mfma_frac"]}))
         return
     def sync():
         torch.cuda.synchronize()
@@ -513,7 +521,7 @@ def main():
                 sm["joint_err_mm_vs_oracle"] = {"mean": round(mean6, 6), "max": round(max6, 6)}
             awr_amd.set_gemm_products(1)
             out["split_mode"] = sm
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if pg is not None:
         torch.distributed.destroy_process_group()
 

@@ -51,6 +51,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.lib.awr_debug_force_tile(0, 0) == 0
 
 
+def test_data_parallel_entry_points_without_gpu(lib):
+    """awr_dp_* open librccl.so with dlopen at first use: the probe needs no GPU (the ROCm image ships the library), argument checks run
+    before any RCCL call, and nothing here creates a communicator."""
+    import ctypes as C
+    v, p = C.c_int(), C.c_char_p()
+    rc = lib.lib.awr_dp_available(C.byref(v), C.byref(p))
+    assert rc in (0, -3)
+    if rc == 0:
+        assert v.value > 0 and b"rccl" in p.value
+    assert lib.lib.awr_dp_init(2, 2, C.create_string_buffer(128), C.byref(C.c_void_p())) == -1 and "rank" in lib.last_error()
+    assert lib.lib.awr_dp_unique_id(None) == -1
+    assert lib.lib.awr_dp_destroy(None) == 0
+    assert lib.lib.awr_plan_set_dp(None, None) == -1
+
+
 def test_struct_layout_matches_header(lib):
     import ctypes as C
     # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 12 pointers + 17 ints + 4 phases + pad + w_split

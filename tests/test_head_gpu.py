@@ -160,6 +160,52 @@ def test_roundtrip_property_full_size(amd, dev):
     assert float((back - jt)[fg].abs().max()) < 0.05
 
 
+def test_nhwc_roundtrip_and_loss_properties_full_size(amd, dev):
+    """Size-independent properties of the NHWC forms at BASELINE's full batch (256 / GPU, config 4): (i) the GT map of joints lying on
+    the hand surface, fed back as the prediction, decodes to those joints (round trip) and has ZERO dense loss and zero gradient;
+    (ii) the dense-loss gradient of a perturbed map is clamp(z, +-0.01) / N element for element (so its absolute sum is bounded by
+    0.01 per element and the loss is non-negative); (iii) scaling dense_weight scales loss and gradient linearly."""
+    from awr_amd import _lib as L
+    B, J, H, ks = 256, 14, 128, 0.4
+    F, cp = H // 2, 64
+    img, _ = O.synth_batch(B, H, J, seed=6)
+    d = img[:, 0, ::2, ::2]
+    g = torch.Generator().manual_seed(1)
+    ys, xs = torch.randint(20, 44, (B, J), generator=g), torch.randint(20, 44, (B, J), generator=g)
+    a = 2.0 * (torch.arange(F).float() + 0.5) / F - 1.0
+    dep = d[torch.arange(B).view(B, 1), ys, xs]
+    jt_gt = torch.stack([a[xs], a[ys], dep], -1).contiguous()
+    imd, jgd = img.to(dev), jt_gt.to(dev)
+    gt = amd.FeatureModule().joint2offset(jgd, imd, ks, F)                 # (B, 4J, F, F), bit-exact IEEE GT map
+    pred = _to_nhwc(gt, cp)
+    n = int(L.lib.awr_head_nhwc_scratch(B, J, F))
+    scratch, jt, stat = torch.zeros(n, device=dev), torch.zeros(B, J, 3, device=dev), torch.zeros(B, J, 2, device=dev)
+    g_jt, acc, losses = torch.zeros(B, J, 3, device=dev), torch.zeros(2, device=dev, dtype=torch.float64), torch.zeros(3, device=dev)
+    grad = torch.full((B, F * F, cp), float("nan"), device=dev)
+    s = L.stream()
+
+    def step(p, dw):
+        acc.zero_()
+        L.call("awr_head_loss_step_nhwc", L.ptr(p), cp, L.ptr(imd), L.ptr(jgd), B, J, F, H, ks, 0.01, 0.0, dw, L.ptr(scratch), L.ptr(jt), L.ptr(stat),
+               L.ptr(g_jt), L.ptr(acc), L.ptr(grad), s)
+        L.call("awr_loss_finalize_reset", L.ptr(acc), 2, L.ptr(losses), s)
+        torch.cuda.synchronize()
+        return float(losses[1]), grad.clone(), jt.clone()
+    l0, g0, j0 = step(pred, 1.0)
+    assert l0 == 0.0 and float(g0.abs().max()) == 0.0 and float(acc.abs().max()) == 0.0           # (i) exact: the fused GT map IS the prediction
+    fg = (dep < 0.99).to(dev)
+    assert float((j0 - jgd)[fg].abs().max()) < 0.05
+    noise = torch.from_numpy((O._hash_uniform(pred.numel(), 11, 3) * np.float32(0.1)).reshape(pred.shape).copy()).to(dev)
+    noise[:, :, 4 * J:] = 0
+    l1, g1, _ = step(pred + noise, 1.0)
+    N = B * 4 * J * F * F
+    z = noise[:, :, :4 * J]
+    assert torch.allclose(g1[:, :, :4 * J] * N, z.clamp(-0.01, 0.01), rtol=1e-5, atol=3e-7) and l1 > 0                        # (ii)
+    assert bool((g1[:, :, 4 * J:] == 0).all())
+    l2, g2, _ = step(pred + noise, 2.0)
+    assert abs(l2 - 2.0 * l1) <= 1e-6 * l2 and torch.allclose(g2, 2.0 * g1, rtol=1e-6, atol=0)                              # (iii)
+
+
 def test_huber_and_dense_loss(amd, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "huber.npz"))
     x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)

@@ -203,7 +203,7 @@ def test_batch_statistics_of_nearly_constant_channels(ops, L, dev):
     assert float(((var3 - ys.var((0, 2, 3), unbiased=False)).abs() / ys.var((0, 2, 3), unbiased=False)).max()) < 1e-4
 
 
-@pytest.mark.parametrize("B,H,C", [(2, 16, 64), (3, 10, 96), (2, 8, 512), (4, 32, 128)])
+@pytest.mark.parametrize("B,H,C", [(2, 16, 64), (3, 10, 96), (2, 8, 512), (4, 32, 128), (2, 4, 2048)])      # 2048: the Bottleneck ResNets' layer4 (channel chunks)
 def test_batchnorm_train_forward_backward(L, dev, B, H, C):
     x = rnd(B, C, H, H, seed=1) * 2 + 0.3
     gamma, beta = rnd(C, seed=2) + 1.5, rnd(C, seed=3)

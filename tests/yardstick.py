@@ -166,8 +166,8 @@ def decisions_from_plan(ref64, plan_tensors):
     per-channel (scale, shift) the loaders apply.  ReLUs the plan never materialises in any form (the fused ResNet stem) keep the
     float64 decisions.  Max-pools: the plan's argmax is re-derived from ITS pooled tensor ("<block>.conv3.conv.out" /
     "<block>.conv3+skip_layer.out", first maximum wins like awr_maxpool_fwd and ATen).  Returns (flips, pools, report) with report =
-    [(tag, n decisions that differ from float64's, max |float64 pre-activation| among them -- for pools: the largest gap between the two
-    window elements relative to the tensor's magnitude)]."""
+    [(tag, n decisions that differ from float64's, max |float64 pre-activation| among them relative to 1 + the tensor's largest magnitude
+    -- for pools: the largest gap between the two window elements relative to the tensor's magnitude)]."""
     flips, pools, report = {}, {}, []
     for tag, (x64, idx64) in ref64["pools"].items():
         if not tag.endswith(".resout"):
@@ -200,8 +200,8 @@ def decisions_from_plan(ref64, plan_tensors):
         on = on.permute(0, 3, 1, 2).cpu()
         m = on != (x64 > 0)
         flips[tag] = m
-        if bool(m.any()):
-            report.append((tag, int(m.sum()), float(x64[m].abs().max())))
+        if bool(m.any()):      # relative to the tensor's scale: residual sums grow with depth, and so does the absolute rounding error
+            report.append((tag, int(m.sum()), float(x64[m].abs().max() / (1.0 + x64.abs().max()))))
     return flips, pools, report
 
 
