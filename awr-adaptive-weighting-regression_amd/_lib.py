@@ -49,7 +49,8 @@ class ConvArgs(C.Structure):
                 ("so", C.c_int), ("si", C.c_int), ("T", C.c_int),
                 ("relu_in", C.c_int), ("relu_out", C.c_int), ("nphase", C.c_int), ("tile_m", C.c_int), ("tile_n", C.c_int),
                 ("ph", Phase * 4), ("w_split", C.c_void_p), ("stat_slots", C.c_int), ("stat_slot_base", C.c_int), ("in2", C.c_void_p), ("Cin1", C.c_int),
-                ("partial", C.c_void_p), ("split_k", C.c_int), ("split_max", C.c_int), ("bnr_act", C.c_void_p)]
+                ("partial", C.c_void_p), ("split_k", C.c_int), ("split_max", C.c_int), ("bnr_act", C.c_void_p),
+                ("bnr2_y", C.c_void_p), ("bnr2_coef", C.c_void_p), ("stats2", C.c_void_p)]
 
 
 class PackJob(C.Structure):

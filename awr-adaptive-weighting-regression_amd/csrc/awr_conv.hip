@@ -167,7 +167,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     // that into the normalised activations and the gradients.  x - c is exact for nearly equal values; the sums return to the
     // unshifted form in fp64 once per wave: sum x = s1 + n c, sum x^2 = s2 + 2 c s1 + n c^2.
     const bool shifted = a.stats && !a.bnr_y;
-    float4 cs1[TN], cs2[TN], csh[TN];
+    float4 cs1[TN], cs2[TN], cs3[TN], csh[TN];      // cs3: sum g * xhat of a second BatchNorm sharing the masked gradient (a.bnr2_y)
     int ccnt[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -178,11 +178,13 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         const float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
         const float4 osh = (a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
         float4 ksc = o4, ksh = z4, kmu = z4, kis = o4;       // fused BatchNorm-backward reduction coefficients
+        float4 kmu2 = z4, kis2 = o4;
         if (a.bnr_y && nok) {
             ksc = ld4(a.bnr_coef + n0); ksh = ld4(a.bnr_coef + a.N + n0);
             kmu = ld4(a.bnr_coef + 2 * a.N + n0); kis = ld4(a.bnr_coef + 3 * a.N + n0);
+            if (a.bnr2_y) { kmu2 = ld4(a.bnr2_coef + 2 * a.N + n0); kis2 = ld4(a.bnr2_coef + 3 * a.N + n0); }
         }
-        float4 s1 = z4, s2 = z4, cshift = z4;
+        float4 s1 = z4, s2 = z4, s3 = z4, cshift = z4;
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -228,6 +230,11 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                         s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                         s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
+                        if (a.bnr2_y) {
+                            const float4 y2 = ld4(a.bnr2_y + o);
+                            s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
+                            s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
+                        }
                     } else {
                         const float4 d = make_float4(v.x - cshift.x, v.y - cshift.y, v.z - cshift.z, v.w - cshift.w);
                         s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
@@ -242,6 +249,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         }
         cs1[j] = s1;
         cs2[j] = s2;
+        cs3[j] = s3;
         csh[j] = cshift;
         ccnt[j] = cnt;
     }
@@ -251,11 +259,12 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         // workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands
         // of workgroups hit the same C channels; without the slots the atomics serialise in L2 and cost more than the GEMM
         // epilogue itself).  (The BatchNorm-backward sums -- sum g, sum g*xhat -- have no such cancellation: plain sums.)
-        double d1[TN][4], d2[TN][4];
+        double d1[TN][4], d2[TN][4], d3[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float* p1 = &cs1[j].x;
             float* p2 = &cs2[j].x;
+            float* p3 = &cs3[j].x;
             int cnt = ccnt[j];
 #pragma unroll
             for (int o = 8; o <= 32; o <<= 1) {
@@ -263,6 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 for (int e = 0; e < 4; ++e) {
                     p1[e] += __shfl_xor(p1[e], o, 64);
                     p2[e] += __shfl_xor(p2[e], o, 64);
+                    if (a.stats2) p3[e] += __shfl_xor(p3[e], o, 64);
                 }
                 cnt += __shfl_xor(cnt, o, 64);
             }
@@ -272,10 +282,12 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 const double c = shifted ? (double)pc[e] : 0.0, n = (double)cnt;
                 d1[j][e] = (double)p1[e] + n * c;
                 d2[j][e] = (double)p2[e] + 2.0 * c * (double)p1[e] + n * c * c;
+                d3[j][e] = (double)p3[e];
             }
         }
         __syncthreads();                 // all transpose tiles are dead: reuse the LDS for the cross-wave combine
-        double* red = reinterpret_cast<double*>(smem);      // [wn * TN + j][stat][lane 0..7][4]
+        double* red = reinterpret_cast<double*>(smem);      // [wn * TN + j][stat][lane 0..7][4]; third statistic behind the first two
+        double* red3 = red + 2 * TN * 2 * 8 * 4;
         if (wm == 1 && lane < 8) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -283,6 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 for (int e = 0; e < 4; ++e) {
                     red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e] = d1[j][e];
                     red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e] = d2[j][e];
+                    if (a.stats2) red3[((wn * TN + j) * 8 + lane) * 4 + e] = d3[j][e];
                 }
         }
         __syncthreads();
@@ -290,15 +303,22 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
             // slot copies: AWR_STAT_SLOTS by default; with a.stat_slots >= the launch's workgroup count every workgroup owns its
             // slot (one add onto zero is exact: the deterministic mode)
             const unsigned nslots = a.stat_slots > 0 ? (unsigned)a.stat_slots : (unsigned)AWR_STAT_SLOTS;
-            double* st = a.stats + (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
+            const size_t slot = (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
+            double* st = a.stats + slot;
+            double* st2 = a.stats2 ? a.stats2 + slot : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
                 if (n0 < a.N) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        atomicAdd(st + n0 + e, d1[j][e] + red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e]);
+                        const double t1 = d1[j][e] + red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e];
+                        atomicAdd(st + n0 + e, t1);
                         atomicAdd(st + a.N + n0 + e, d2[j][e] + red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e]);
+                        if (st2) {      // the second BatchNorm sees the same masked gradient: same sum g, its own sum g * xhat
+                            atomicAdd(st2 + n0 + e, t1);
+                            atomicAdd(st2 + a.N + n0 + e, d3[j][e] + red3[((wn * TN + j) * 8 + lane) * 4 + e]);
+                        }
                     }
                 }
             }
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
         }
         awr_conv_args b = a;      // raw partial sums: the epilogue proper runs in splitk_reduce_kernel
         b.out = a.partial + (size_t)blockIdx.z * ((size_t)a.B * a.Hout * a.Wout * a.N);
-        b.bias = nullptr; b.out_scale = nullptr; b.out_shift = nullptr; b.res = nullptr; b.stats = nullptr; b.bnr_y = nullptr; b.relu_out = 0;
+        b.bias = nullptr; b.out_scale = nullptr; b.out_shift = nullptr; b.res = nullptr; b.stats = nullptr; b.bnr_y = nullptr; b.bnr2_y = nullptr; b.stats2 = nullptr; b.relu_out = 0;
         gemm_epilogue<TM, TN>(b, ph, acc, smem, M, tile_m, tile_n);
         return;
     }
@@ -1287,6 +1307,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
         if (a->bnr_act) b.bnr_act = a->bnr_act + out_img * b.B * c;
+        if (a->bnr2_y) b.bnr2_y = a->bnr2_y + out_img * b.B * c;
         if (a->in2) {
             b.in = a->in + (int64_t)a->Hin * a->Win * a->Cin1 * b.B * c;
             b.in2 = a->in2 + (int64_t)a->Hin * a->Win * (a->Cin - a->Cin1) * b.B * c;
@@ -1306,6 +1327,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && (!a->res || (a->bnr_act && a->res == a->out))),
                 "conv_gemm: fused BN-backward reduction needs coef + stats; accumulating (res) only in place and with bnr_act");
     AWR_REQUIRE(!a->bnr_act || a->bnr_y, "conv_gemm: bnr_act without bnr_y");
+    AWR_REQUIRE(!a->bnr2_y || (a->bnr_y && a->bnr2_coef && a->stats2), "conv_gemm: a second fused reduction (bnr2_y) needs bnr_y, bnr2_coef and stats2");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
     AWR_REQUIRE(!a->in2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),

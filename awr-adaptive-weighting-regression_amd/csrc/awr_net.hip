@@ -598,6 +598,10 @@ struct Tn {
     // HBM; its consumers (conv / wgrad / maxpool loaders) apply the affine on the fly
     bool lazy = false, lz_relu = false;
     const float *lz_scale = nullptr, *lz_shift = nullptr;
+    // a materialised BatchNorm output WITHOUT ReLU or residual (the ResNet downsample projection's): what a consumer that adds it to
+    // another BatchNorm's output before a ReLU needs to reduce this BatchNorm's backward sums together with its own
+    const float *bn_y = nullptr, *bn_coef4 = nullptr;
+    StatBuf pre_sums;      // set by that consumer's backward: sum g / sum g*xhat of THIS BatchNorm are already in here
     std::string name;
     int64_t npix() const { return (int64_t)B * H * W; }
     int64_t numel() const { return npix() * C; }
@@ -673,11 +677,12 @@ struct awr_plan {
     struct Bucket { int64_t lo, hi; int ready; };
     std::vector<Bucket> buckets;
     bool built_bwd = false;
-    // pack tables (device) for refresh_weights: [want_split]
-    void* pack_tab[2] = {nullptr, nullptr};
-    int pack_njobs[2] = {0, 0};
-    int64_t pack_rows[2] = {0, 0};
+    // pack tables (device) for refresh_weights: [want_split][0 = forward layouts (+ dual layers), 1 = data-gradient layouts]
+    void* pack_tab[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int pack_njobs[2][2] = {{0, 0}, {0, 0}};
+    int64_t pack_rows[2][2] = {{0, 0}, {0, 0}};
     bool pack_built[2] = {false, false};
+
     // streams
     std::vector<hipStream_t> side;
     std::vector<hipStream_t> branch;      // backward branches (an hourglass level's full-resolution skip residual)
@@ -1110,6 +1115,7 @@ struct Builder {
             const float* rb = res ? res->buf : nullptr;
             float* ob = a->buf;
             f("awr_bn_apply", [=](void* s) { return awr_bn_apply(xb, sc, sh, rb, relu ? 1 : 0, ob, npix, C, s); });
+            if (!relu && !res) { a->bn_y = y->buf; a->bn_coef4 = coef4; }
         }
         P.nodes.push_back([=]() { return bn_bwd(y, a, bn, relu, res, mean, invstd, sc, sh, coef4); });
         return a;
@@ -1143,6 +1149,17 @@ struct Builder {
             ga->bnr_act = res ? a->buf : nullptr;
             ga->stats = sums.p;
             ga->stat_slots = sums.nslots;
+            // the residual is itself a BatchNorm output (no ReLU of its own: the downsample projection): its backward needs sum g and
+            // sum g * xhat over the SAME masked gradient -- reduced here too, its stand-alone reduction pass disappears
+            static const bool no_bnr2 = getenv("AWR_NO_BNR2") != nullptr;      // same-box A/B hook
+            if (res && res->bn_y && res->needs_grad && res->C == C && !no_bnr2) {
+                res->pre_sums = stat_buf(sums.nslots, C);
+                ga->bnr2_y = res->bn_y;
+                ga->bnr2_coef = res->bn_coef4;
+                ga->stats2 = res->pre_sums.p;
+            }
+        } else if (a->pre_sums.p && !relu && !res) {
+            sums = a->pre_sums;
         } else {
             sums = stat_buf(reduce_slots(), C);
         }
@@ -1154,7 +1171,8 @@ struct Builder {
         const float* yb = y->buf;
         double* sp = sums.p;
         const int ns = sums.nslots;
-        if (!fused) b("awr_bn_bwd_reduce", [=](void* s) { return awr_bn_bwd_reduce(da, act, yb, mean, invstd, msc, msh, npix, C, sp, ns, s); });
+        const bool pre_reduced = !fused && a->pre_sums.p && !relu && !res;
+        if (!fused && !pre_reduced) b("awr_bn_bwd_reduce", [=](void* s) { return awr_bn_bwd_reduce(da, act, yb, mean, invstd, msc, msh, npix, C, sp, ns, s); });
         float* gy;
         bool acc = false;
         if (y->needs_grad) {
@@ -1494,10 +1512,13 @@ struct NetBuilder {
             for (int bi = 0; bi < nb[li - 1]; ++bi) {
                 const std::string p = fmt("layer%d.%d", li, bi);
                 Tn* r;
+                const size_t n0 = P.nodes.size();
+                size_t n1 = n0;
                 if (N.convs.count(p + ".downsample.0")) {   // 1x1 projection (+ stride) + its BatchNorm: independent of the main branch until the residual add
                     b.fork(0);
                     r = cbr(c, p + ".downsample.0", p + ".downsample.1", false);
                     b.end_fork(r);
+                    n1 = P.nodes.size();
                 } else {
                     r = c;
                 }
@@ -1505,12 +1526,47 @@ struct NetBuilder {
                 // cheaper than one write + read of the tensor -- the loader arithmetic costs 8-15 % of a GEMM whose K grows with the
                 // channel count, the tensor pass does not: beyond 128 channels the activation is written out
                 Tn* o = cbr(c, p + ".conv1", p + ".bn1", true, nullptr, C(p + ".conv1")->spec.cout <= 128);
+                const size_t n2 = P.nodes.size();
                 if (!bott) {
                     c = cbr(o, p + ".conv2", p + ".bn2", true, r);
                 } else {
                     o = cbr(o, p + ".conv2", p + ".bn2", true, nullptr, C(p + ".conv2")->spec.cout <= 128);
                     c = cbr(o, p + ".conv3", p + ".bn3", true, r);
                 }
+                // Backward of a block with a projection (the emitters run in reverse node order).  Two things are arranged here:
+                // (i) the projection's data gradient covers only one of the four stride phases of d(c) (zero fill + accumulate), conv1's
+                // covers all of it: with the projection's backward emitted FIRST, conv1's data gradient is the LAST producer of d(c) -- a
+                // full-coverage GEMM that adds in place and can host the fused BatchNorm-backward reduction of the previous block's
+                // output (with the projection's own BatchNorm reduced in this block's bn-output GEMM, bn_bwd: no stand-alone reduction
+                // pass is left in a ResNet step);  (ii) the projection's backward (BatchNorm apply, a small 1x1 weight and data gradient)
+                // only needs the masked d(out) and only meets the main chain again at conv1's data gradient: it runs on a branch stream
+                // beside the block's conv backward.  Emission: bn_last, FORK, projection, ENDFORK, ..., bn1, JOIN, conv1.
+                // The forward launch order is untouched.
+                static const bool no_reorder = getenv("AWR_NO_DS_REORDER") != nullptr;      // same-box A/B hooks
+                static const bool no_branch = getenv("AWR_NO_DS_BRANCH") != nullptr;
+                if (P.training && n1 > n0 && !no_reorder) {
+                    std::vector<std::function<int()>> ds(P.nodes.begin() + n0, P.nodes.begin() + n1), mn(P.nodes.begin() + n1, P.nodes.end());
+                    Builder* bp = &b;
+                    auto marker = [bp](int kind) {
+                        return std::function<int()>([bp, kind]() {
+                            Op& o = bp->b(kind == OP_FORK ? "__fork__" : kind == OP_ENDFORK ? "__endfork__" : "__join__", nullptr);
+                            o.kind = kind;
+                            o.sid = 0;
+                            return bp->err;
+                        });
+                    };
+                    std::vector<std::function<int()>> order;
+                    order.push_back(mn.front());                                   // conv1 (its data gradient: last producer of d(c))
+                    if (!no_branch) order.push_back(marker(OP_JOIN));
+                    for (size_t i = 1; i + 1 < mn.size(); ++i) order.push_back(mn[i]);
+                    if (!no_branch) order.push_back(marker(OP_ENDFORK));
+                    for (auto& f : ds) order.push_back(f);
+                    if (!no_branch) order.push_back(marker(OP_FORK));
+                    order.push_back(mn.back());                                    // the block output's BatchNorm
+                    P.nodes.erase(P.nodes.begin() + n0, P.nodes.end());
+                    for (auto& f : order) P.nodes.push_back(f);
+                }
+                (void)n2;
             }
         for (int i = 0; i < N.ndeconv; ++i)   // feeds the next transposed conv (K = 4 x 256 per phase: materialised) or the 1x1 head GEMM (lazy)
             c = cbr(c, fmt("deconv_layers.%d", 3 * i), fmt("deconv_layers.%d", 3 * i + 1), true, nullptr, i == N.ndeconv - 1);
@@ -1636,8 +1692,8 @@ namespace awrnet {
 static int refresh_weights(awr_plan& P, void* stream) {
     const int ws = awr_get_gemm_products() != 1 ? 1 : 0;      // split images are only written for the mode that reads them
     if (!P.pack_built[ws]) {
-        std::vector<awr_pack_job> jobs;
-        int64_t total = 0;
+        std::vector<awr_pack_job> jobs[2];
+        int64_t total[2] = {0, 0};
         for (auto* l : P.layers) {
             if (l->head) continue;
             const PackRecipe rc[2] = {fwd_pack(l->spec), dgrad_pack(l->spec)};
@@ -1648,9 +1704,9 @@ static int refresh_weights(awr_plan& P, void* stream) {
                 memset(&j, 0, sizeof j);
                 j.src = l->w; j.dst = dst[k]->p; j.split = ws ? dst[k]->split : nullptr;
                 j.d0 = rc[k].d0; j.d1 = rc[k].d1; j.T = rc[k].T; j.transpose = rc[k].transpose; j.rows = rc[k].rows; j.ld = rc[k].ld;
-                j.first = total;
-                total += rc[k].rows;
-                jobs.push_back(j);
+                j.first = total[k];
+                total[k] += rc[k].rows;
+                jobs[k].push_back(j);
             }
         }
         for (auto* d : P.dual_layers) {       // [W3 row | Wskip row] side by side in one K-contiguous buffer (FP32 mode only: no split image)
@@ -1662,17 +1718,24 @@ static int refresh_weights(awr_plan& P, void* stream) {
                 memset(&j, 0, sizeof j);
                 j.src = src[k]->w; j.dst = d->p.p + offs[k]; j.split = nullptr;
                 j.d0 = src[k]->spec.cout; j.d1 = src[k]->spec.cin; j.T = 1; j.transpose = 0; j.rows = d->p.rows; j.ld = d->p.ld; j.cols = colsv[k];
-                j.first = total;
-                total += d->p.rows;
-                jobs.push_back(j);
+                j.first = total[0];
+                total[0] += d->p.rows;
+                jobs[0].push_back(j);
             }
         }
-        if (!jobs.empty()) NET_CHECK(upload_table(P, jobs.data(), jobs.size() * sizeof(awr_pack_job), &P.pack_tab[ws]));
-        P.pack_njobs[ws] = (int)jobs.size();
-        P.pack_rows[ws] = total;
+        for (int k = 0; k < 2; ++k) {
+            if (!jobs[k].empty()) NET_CHECK(upload_table(P, jobs[k].data(), jobs[k].size() * sizeof(awr_pack_job), &P.pack_tab[ws][k]));
+            P.pack_njobs[ws][k] = (int)jobs[k].size();
+            P.pack_rows[ws][k] = total[k];
+        }
         P.pack_built[ws] = true;
     }
-    if (P.pack_njobs[ws]) NET_CHECK(awr_pack_weights_batched((const awr_pack_job*)P.pack_tab[ws], P.pack_njobs[ws], P.pack_rows[ws], stream));
+    if (P.pack_njobs[ws][0])
+        NET_CHECK(awr_pack_weights_batched((const awr_pack_job*)P.pack_tab[ws][0], P.pack_njobs[ws][0], P.pack_rows[ws][0], stream));
+    // (packing the data-gradient layouts on a side stream under the forward's GEMMs was measured in rounds 2 and 3: no gain, 14.04 vs
+    // 14.04 ms -- profiles/r03_summary.md -- so both tables go to the caller's stream)
+    if (P.pack_njobs[ws][1])
+        NET_CHECK(awr_pack_weights_batched((const awr_pack_job*)P.pack_tab[ws][1], P.pack_njobs[ws][1], P.pack_rows[ws][1], stream));
     hipStream_t st = awr::as_stream(stream);
     for (auto* l : P.layers) {
         if (!l->head) continue;
@@ -1715,7 +1778,9 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     hipStream_t main = awr::as_stream(stream);
     const bool use_side = !P.side.empty();
     const bool wside = is_bwd && use_side;
-    hipStream_t comm = (wside && P.bucket_cb && P.n_buckets > 1) ? P.comm : nullptr;
+    // (no callback needed: a single-GPU plan built with several buckets uses the hand-off just to scatter its weight gradients early,
+    // off the tail of the step)
+    hipStream_t comm = (wside && P.n_buckets > 1) ? P.comm : nullptr;
     bool pending = false, handed = false;
     size_t nside = 0;
     void* cur = stream;
@@ -1738,7 +1803,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         if (comm && op.kind == OP_BUCKET) {
             if (!handed) NET_CHECK(hand_off());
             handed = false;
-            P.bucket_cb(P.bucket_user, op.lo, op.hi, (void*)comm);
+            if (P.bucket_cb) P.bucket_cb(P.bucket_user, op.lo, op.hi, (void*)comm);
             continue;
         }
         if (wside && pending && (op.kind == OP_CALL || op.kind == OP_BUCKET)) {
@@ -1754,11 +1819,11 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
             }
         }
         switch (op.kind) {
-            case OP_ZERO:
-                HIP_TRY(hipMemsetAsync(op.p, 0, op.bytes, main));
+            case OP_ZERO:      // (on the issuing chain: a zero fill inside a branch belongs to the branch's data gradient)
+                HIP_TRY(hipMemsetAsync(op.p, 0, op.bytes, awr::as_stream(cur)));
                 continue;
             case OP_COPY:
-                HIP_TRY(hipMemcpyAsync(op.p, op.q, op.bytes, hipMemcpyDeviceToDevice, main));
+                HIP_TRY(hipMemcpyAsync(op.p, op.q, op.bytes, hipMemcpyDeviceToDevice, awr::as_stream(cur)));
                 continue;
             case OP_BUCKET:
                 if (P.bucket_cb) P.bucket_cb(P.bucket_user, op.lo, op.hi, stream);

@@ -77,6 +77,8 @@ class TrainEngine:
         world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         import os
         self.dp = world > 1 or (process_group is not None and os.environ.get("AWR_FORCE_DP") == "1")   # test hook: 1-rank group
+        # (single GPU: scattering the packed weight gradients bucket by bucket during the backward, like the data-parallel plans do, instead
+        # of in one launch at the tail of the step was measured slower: 14.28-14.32 vs 14.00-14.05 ms, profiles/r03_summary.md)
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
                                  n_buckets=n_buckets if self.dp else 1)
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data

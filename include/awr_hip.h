@@ -223,6 +223,9 @@ typedef struct awr_conv_args {
                                BatchNorm whose output had a residual added before the ReLU (resnet_deconv.py:74-78).  `res` may then be
                                set as well: the launch is the LAST producer of the gradient, adds its tile onto the earlier
                                contributions, masks, reduces and stores the masked gradient in place */
+    const float* bnr2_y;    /* with bnr_y: a SECOND BatchNorm whose output was added to the first one's before the ReLU (the ResNet downsample */
+    const float* bnr2_coef; /* projection: a = relu(bn2(y) + bn_ds(y2))) shares the masked gradient g: also accumulate sum g, */
+    double* stats2;         /* sum g*(y2-mean2)*invstd2 into stats2 (same slot geometry as `stats`); coef2 = [scale|shift|mean|invstd][N] */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
