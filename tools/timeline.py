@@ -24,12 +24,22 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
+    # only the optimiser launches that close a real step: bench.py's serial event passes at the end replay the plan op by op (one long
+    # single-queue segment) and launch the optimiser on its own; a real step has the modal launch count of the segments
+    from collections import Counter
+    counts = [ends[k] - ends[k - 1] for k in range(1, len(ends))]
+    modal = Counter(c for c in counts if c > 50).most_common(1)
+    if modal:
+        keep = [k for k in range(1, len(ends)) if counts[k - 1] == modal[0][0]]
+        segs = [(ends[k - 1], ends[k]) for k in keep]
+    else:
+        segs = []
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    if len(ends) < nsteps + 1:
-        print("not enough steps in trace (%d adam launches)" % len(ends))
+    if len(segs) < nsteps:
+        print("not enough steps in trace (%d adam launches, %d full steps)" % (len(ends), len(segs)))
         return
-    for s in range(len(ends) - nsteps, len(ends)):
-        seg = rows[ends[s - 1] + 1: ends[s] + 1]
+    for s in range(len(segs) - nsteps, len(segs)):
+        seg = rows[segs[s][0] + 1: segs[s][1] + 1]
         t0, t1 = seg[0][0], max(r[1] for r in seg)
         # sweep
         ev = []
@@ -52,7 +62,7 @@ def main():
         for a, b, _, q in seg:
             perq[q] = perq.get(q, 0) + b - a
         print("   busy per queue: " + ", ".join("q%s %.3f ms" % (q, v / 1e6) for q, v in sorted(perq.items())))
-        if s == len(ends) - 1:
+        if s == len(segs) - 1:
             # idle gaps: times with depth 0
             gaps = []
             cur_end, prev = seg[0][1], seg[0]
