@@ -1883,15 +1883,12 @@ static int run_timed(awr_plan& P, std::vector<Op>& ops, void* stream, float* ms)
         if (op.kind == OP_ZERO) { if (hipMemsetAsync(op.p, 0, op.bytes, main) != hipSuccess) rc = AWR_ERR_HIP; continue; }
         if (op.kind == OP_COPY) { if (hipMemcpyAsync(op.p, op.q, op.bytes, hipMemcpyDeviceToDevice, main) != hipSuccess) rc = AWR_ERR_HIP; continue; }
         if (op.kind != OP_CALL || (op.boundary && P.nhwc_boundary)) continue;
-        if (op.gemm) {
-            (void)hipEventCreate(&ev[i].first);
-            (void)hipEventCreate(&ev[i].second);
-            (void)hipEventRecord(ev[i].first, main);
-            rc = op.fn(stream);
-            (void)hipEventRecord(ev[i].second, main);
-        } else {
-            rc = op.fn(stream);
-        }
+        // (every launch gets its event pair; callers that only want the GEMM family filter by the op flags)
+        (void)hipEventCreate(&ev[i].first);
+        (void)hipEventCreate(&ev[i].second);
+        (void)hipEventRecord(ev[i].first, main);
+        rc = op.fn(stream);
+        (void)hipEventRecord(ev[i].second, main);
     }
     if (hipStreamSynchronize(main) != hipSuccess && rc == AWR_OK) {
         set_error("run_timed: hipStreamSynchronize failed");

@@ -289,12 +289,13 @@ class Plan:
     def backward(self):
         self.run_backward()
 
-    def timed(self, which):
-        """Serial replay of one launch list with a HIP-event pair around every conv / stem launch -> {name: seconds}."""
+    def timed(self, which, every=False):
+        """Serial replay of one launch list with a HIP-event pair around every launch -> {name: seconds} of the conv / stem launches
+        (`every`: of all launches, BatchNorm / pooling / element-wise ones included)."""
         lst = 0 if which in (0, "fwd", "forward") else 1
         ms = (C.c_float * self.n_ops[lst])()
         L.call("awr_plan_run_timed", self.h, lst, L.stream(), ms)
-        return {n: ms[i] * 1e-3 for i, (n, g) in enumerate(self._ops[lst]) if g}
+        return {n: ms[i] * 1e-3 for i, (n, g) in enumerate(self._ops[lst]) if (g or (every and ms[i] > 0))}
 
     # ---- autotune --------------------------------------------------------------------------------------------
     def _gemm(self, i):

@@ -197,12 +197,12 @@ class TrainEngine:
         """(B, 4J, F, F) dense map of the last step in the reference's layout."""
         return self.plan.dense_map(self.stage if stage is None else stage)
 
-    def timed_core(self):
-        """The captured part once more, serially, with a HIP-event pair around every conv / stem launch (bench.py's roofline):
-        -> {launch name: seconds}.  Not an optimisation step (no optimiser update)."""
+    def timed_core(self, every=False):
+        """The captured part once more, serially, with a HIP-event pair around every launch (bench.py's roofline):
+        -> {launch name: seconds} of the conv / stem launches (`every`: of all launches).  Not an optimisation step (no optimiser update)."""
         self.plan.refresh_weights()
-        per = self.plan.timed("fwd")
-        per.update(self.plan.timed("bwd"))
+        per = self.plan.timed("fwd", every)
+        per.update(self.plan.timed("bwd", every))
         return per
 
     def timed_hbm(self, reps=5):

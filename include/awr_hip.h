@@ -411,7 +411,7 @@ int awr_plan_info(const awr_plan* plan, int64_t* bytes, int* deterministic, int*
                   int* n_buckets, int* n_gemm, int* n_bn);
 int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* ready_op);
 /* op i of the forward (list 0) / backward (list 1) launch list: name, algorithmic MACs (GEMM-family launches),
- * flags bit 0 = weight gradient that may run on a side stream, bit 1 = conv / stem family (timed by awr_plan_run_timed) */
+ * flags bit 0 = weight gradient that may run on a side stream, bit 1 = conv / stem family (the launches a roofline is quoted for) */
 int awr_plan_op(const awr_plan* plan, int list, int i, const char** name, double* macs, int* flags);
 /* parity / debugging introspection: activation tensor i of the plan in build order (i past the end returns AWR_ERR_ARG): name
  * ("<layer>.out" = a conv's raw output, "<bn>.act" = a materialised BatchNorm(+ReLU) output, "<bn>.act(lazy)" = one that is never
@@ -442,7 +442,7 @@ int awr_stream_pool_info(int* n_streams, int* n_independent);
 int awr_plan_refresh_weights(awr_plan* plan, void* stream);
 int awr_plan_forward(awr_plan* plan, void* stream);
 int awr_plan_backward(awr_plan* plan, void* stream);
-/* serial replay with a HIP-event pair around every conv / stem launch: ms[i] per op (synchronises the stream) */
+/* serial replay with a HIP-event pair around every launch: ms[i] per op, 0 for fills / copies / markers (synchronises the stream) */
 int awr_plan_run_timed(awr_plan* plan, int list, void* stream, float* ms);
 /* time the tile / split-K candidates of every GEMM launch in place (no-op in deterministic mode); read / preset choices
  * (target_blocks: weight gradients = workgroup target of the split over pixels; conv launches with `partial` scratch = split-K depth) */
