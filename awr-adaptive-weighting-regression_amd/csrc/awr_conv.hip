@@ -337,21 +337,29 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // the hourglass residual's conv3 + skip_layer (hourglass.py:44-59) without writing and re-reading the skip branch's output.
 // SPLIT (fp32 mode): blockIdx.z owns a contiguous range of the K slices and stores its raw partial tile to a.partial (copy
 // blockIdx.z); splitk_reduce_kernel finishes the job.
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false>
+// FUSE2 (fp32 mode, 64x128 tile, a.w2 set): TWO convolutions back to back.  The conv described by (in, w, taps) has exactly 128 output
+// channels, so the workgroup's 64x128 tile holds ALL channels of its 64 pixels: instead of storing it, bias / folded BatchNorm / ReLU are
+// applied in registers, the tile goes to LDS as the A operand of a second, 1x1 GEMM (w2: [N][128]) whose result gets the ordinary epilogue
+// (bias2, residual) -- the hourglass residual's conv2 (3x3) -> bn3 -> ReLU -> conv3 (1x1) + skip (hourglass.py:44-59) in one launch at
+// inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
+constexpr int F2P = 132;      // pitch (floats) of the intermediate tile in LDS: rows 4 banks apart like LDK
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
+    static_assert(!FUSE2 || (TM == 1 && TN == 2 && NP == 0 && !DUAL && !SPLIT), "FUSE2: 64x128 tile, FP32-MFMA mode");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
     constexpr int ROWB = NP ? LDR : LDK * 4;    // LDS row pitch in bytes
     // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
-    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 fp32 configuration)
-    __shared__ __attribute__((aligned(16))) char smem_raw[(BM + BN) * ROWB];
+    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 fp32 configuration).
+    // FUSE2: [intermediate tile 64 x 132 (over the dead phase-1 slices)][w2 K-slices 128 x 36, then the transpose tiles]
+    __shared__ __attribute__((aligned(16))) char smem_raw[FUSE2 ? 64 * F2P * 4 + 128 * LDK * 4 : (BM + BN) * ROWB];
     float* const smem = reinterpret_cast<float*>(smem_raw);
     char* const As = smem_raw;
     char* const Bs = smem_raw + BM * ROWB;
 
     const awr_phase& ph = a.ph[blockIdx.y];
     const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = (a.N + BN - 1) / BN;
+    const int tilesN = FUSE2 ? 1 : (a.N + BN - 1) / BN;      // (FUSE2: a.N is the second conv's channel count; the first has BN)
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -709,6 +717,64 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
             load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
             mfma_split16<TM, TN, NP>(fa, fb, acc);
         }
+    }
+    if constexpr (FUSE2) {
+        float* const A2 = smem;                                  // [64][F2P]: relu(bn(conv + bias)), all 128 channels of the tile's pixels
+        char* const B2 = smem_raw + 64 * F2P * 4;                // [128][LDK]: one K-slice of w2; afterwards the epilogue's transpose tiles
+        __syncthreads();                                         // the phase-1 slices are dead
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * 64 + j * 32 + l31;
+            const float b1 = a.bias ? a.bias[col] : 0.f, sc = a.out_scale ? a.out_scale[col] : 1.f, sh = a.out_shift ? a.out_shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[0][j][r] + b1) * sc + sh;
+                if (a.relu_out) v = fmaxf(v, 0.f);
+                A2[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * F2P + col] = v;
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, OOB);
+        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 + l31) * F2P) * 4 + 16 * half;
+        const char* b2_frag = B2 + (wn * 64 + l31) * ROWB + 16 * half;
+        awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
+        e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
+        // 128 output channels at a time (two passes: N == 256), four K-slices of the 128 intermediate ones each; the passes are unrolled
+        // so that each epilogue is straight-line code with its own register allocation (inside a run-time loop it cost 47 VGPRs)
+        float4 rb2[4];
+        auto load_b2 = [&](int hf, int s2) {
+            const unsigned row0 = (unsigned)(hf * 128 + r0), k0 = (unsigned)(32 * s2 + kc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * 128u + k0) * 4u);
+        };
+        load_b2(0, 0);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+            for (int s2 = 0; s2 < 4; ++s2) {
+                __syncthreads();             // first slice: the intermediate tile is complete / the transpose tiles are dead; later: the previous slice is
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st4(reinterpret_cast<float*>(B2 + (r0 + 32 * i) * ROWB) + kc, rb2[i]);
+                __syncthreads();
+                if (s2 < 3) load_b2(hf, s2 + 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float4 fa = ld4(reinterpret_cast<const float*>(a2_frag) + 32 * s2 + 8 * s);
+                    float4 fb[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_frag + j * 32 * ROWB) + 8 * s);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa.x)[k], (&fb[j].x)[k], acc[0][j], 0, 0, 0);
+                }
+            }
+            if (hf == 0) load_b2(1, 0);      // (in flight under the first pass's epilogue)
+            gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
+        }
+        return;
     }
     gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
 }
@@ -1338,6 +1404,16 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     }
     const int64_t M = (int64_t)a->B * a->Hq * a->Wq;
     AWR_REQUIRE(M < (1LL << 31), "conv_gemm: too many output pixels");
+    if (a->w2) {      // two convolutions back to back (FUSE2)
+        AWR_REQUIRE(g_products == 1 && a->N1 == 128 && a->N == 256 && a->so == 1 && a->nphase == 1 && !a->stats && !a->bnr_y && !a->in2 &&
+                        !a->partial && a->split_k <= 1,
+                    "conv_gemm: the fused pair (w2) needs the FP32-MFMA mode, 128 intermediate channels, N == 256, a stride-1 output "
+                    "and no stats / bnr_y / in2 / split-K (N1=%d, N=%d)", a->N1, a->N);
+        AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32),
+                    "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
+        hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, false, true>), dim3((unsigned)((M + 63) / 64), 1), dim3(256), 0, as_stream(stream), *a);
+        return check_launch("conv_gemm_kernel<fused pair>");
+    }
     AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31),
                 "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
     // Tile choice (measured, tools/microbench_gemm.py): 64-row tiles win on every ResNet18/Hourglass layer shape --

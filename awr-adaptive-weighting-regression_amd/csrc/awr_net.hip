@@ -702,6 +702,11 @@ namespace awrnet {
 
 // ---- plan building -------------------------------------------------------------------------------------------
 struct Tn;
+static int env_or(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 struct ConvOpt {
     const float *in_scale = nullptr, *in_shift = nullptr;
     bool relu_in = false;
@@ -896,6 +901,45 @@ struct Builder {
             const bool has_bias = bias != nullptr;
             P.nodes.push_back([=]() { return conv_bwd(x, y, layer, res, has_bias); });
         }
+        return y;
+    }
+
+    // Inference: y = conv3(relu(bn3(conv2(x)))) + res as ONE launch (awr_conv_args.w2): conv2 has 128 output channels, so a 64x128 tile holds
+    // every channel of its pixels and feeds the 1x1 conv3 from LDS -- the intermediate never goes to HBM.  o = conv2's epilogue (folded bn3, ReLU).
+    // nullptr when the pair does not qualify (shape, product mode, too few workgroups to fill the chip without split-K).
+    Tn* conv_pair(Tn* x, ConvLayer* c2, const ConvOpt& o, ConvLayer* c3, Tn* res) {
+        const bool off = getenv("AWR_NO_FUSE2") != nullptr;                    // same-box A/B hook (read per plan)
+        const int min_wgs = env_or("AWR_FUSE2_MIN_WGS", 1024);                 // (tests force the fused form on small batches)
+        const Spec &s2 = c2->spec, &s3 = c3->spec;
+        const int64_t wgs = ((int64_t)x->B * x->H * x->W + 63) / 64;
+        if (off || P.training || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
+            s2.cout != 128 || s3.cin != 128 || s3.cout != 256 || wgs < min_wgs || x->lazy)
+            return nullptr;
+        use_layer(c2);
+        use_layer(c3);
+        const int B = x->B;
+        const Prob prob = fwd_problem(s2, x->H, x->W);
+        if (prob.so != 1 || prob.phases.size() != 1 || prob.N != 128) return nullptr;
+        Tn* y = new_t(B, prob.Hout, prob.Wout, 256, true, c3->name + ".out");
+        join_if(res);
+        P.cargs.emplace_back();
+        awr_conv_args* a = &P.cargs.back();
+        fill_conv_args(*a, prob, B, x->buf, c2->p_fwd.p, c2->p_fwd.split, y->buf, s2.T());
+        a->N1 = prob.N;
+        a->N = 256;
+        a->w2 = c3->p_fwd.p;
+        a->bias = c2->bias_ptr();
+        a->bias2 = c3->bias_ptr();
+        a->in_scale = o.in_scale; a->in_shift = o.in_shift; a->relu_in = o.relu_in;
+        a->out_scale = o.out_scale; a->out_shift = o.out_shift; a->relu_out = o.relu_out;
+        a->res = res ? res->buf : nullptr;
+        const std::string name = "awr_conv_gemm:" + c2->name + "+" + c3->name.substr(c3->name.rfind('.', c3->name.rfind('.') - 1) + 1);
+        Op& op = f(name, [a](void* s) { return awr_conv_gemm(a, s); });
+        op.gemm = true;
+        op.macs = gemm_macs(prob, B, s2) + gemm_macs(fwd_problem(s3, prob.Hout, prob.Wout), B, s3);
+        GemmRef g{a, nullptr, name};
+        g.tm = 1; g.tn = 2; g.tuned = true;      // one geometry: nothing for the tuner to choose
+        P.gemms.push_back(g);
         return y;
     }
 
@@ -1610,6 +1654,8 @@ struct NetBuilder {
         Tn* y = b.conv(x, C(p + ".conv1"), o);
         ConvOpt o2;
         o2.out_scale = s3.first; o2.out_shift = s3.second; o2.relu_out = true;
+        if (!dual && !skip)      // identity skip, 256 -> 128 -> 128 -> 256: conv2 and conv3 in one launch when the batch fills the chip
+            if (Tn* fused = b.conv_pair(y, C(p + ".conv2"), o2, C(p + ".conv3"), x)) return fused;
         y = b.conv(y, C(p + ".conv2"), o2);
         if (dual) return b.conv_dual(y, x, dual, false);
         Tn* r = skip ? b.conv(x, skip) : x;
@@ -1919,6 +1965,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
     int rc = AWR_OK;
     for (auto& g : P.gemms) {
         if (g.wa && g.wa->algo == 2) continue;      // the wave-per-tap kernel has one geometry
+        if (g.ca && g.ca->w2) continue;             // ... and so has the fused conv pair
         struct Cand { int tm, tn, tb; };
         std::vector<Cand> cands;
         if (g.ca) {

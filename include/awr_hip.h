@@ -226,6 +226,10 @@ typedef struct awr_conv_args {
     const float* bnr2_y;    /* with bnr_y: a SECOND BatchNorm whose output was added to the first one's before the ReLU (the ResNet downsample */
     const float* bnr2_coef; /* projection: a = relu(bn2(y) + bn_ds(y2))) shares the masked gradient g: also accumulate sum g, */
     double* stats2;         /* sum g*(y2-mean2)*invstd2 into stats2 (same slot geometry as `stats`); coef2 = [scale|shift|mean|invstd][N] */
+    const float* w2;        /* optional: TWO convolutions in one launch (inference; FP32-MFMA mode).  The conv described above has N1 = 128 */
+    const float* bias2;     /* output channels: bias / out_scale / out_shift / relu_out apply to THAT intermediate, which never leaves the */
+    int N1;                 /* chip; a 1x1 conv with the packed weights w2 [N][1][N1] follows, its epilogue takes bias2 and `res`; `out` */
+    int reserved0;          /* and N describe the second conv's output (N == 256).  hourglass.py:44-59: conv2 -> bn3 -> ReLU -> conv3 + skip */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).

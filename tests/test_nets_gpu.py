@@ -851,3 +851,37 @@ def test_deterministic_mode_is_bitwise_reproducible(amd, dev, golden_dir, net, B
     for it in range(3):
         eng.step(img.to(dev), jt_gt.to(dev))
     report("%s/deterministic/default_mode_param_max_abs_diff" % net, float((m.flat_params() - runs[0][3]).abs().max()))
+
+
+@pytest.mark.parametrize("net", ["hourglass_1", "hourglass_2"])
+def test_inference_fused_conv_pairs(amd, dev, golden_dir, net, monkeypatch):
+    """Inference plans run conv2 -> bn3 -> ReLU -> conv3 + skip of every 256 -> 128 -> 128 -> 256 residual (hourglass.py:44-59) as ONE launch
+    once the launch fills the chip (awr_conv_args.w2); forced here for every such residual of a batch-2 plan (down to 4x4 maps: 32-pixel
+    launches, ragged tiles) and held to the golden joints, the oracle's dense map and the two-launch plan."""
+    from awr_amd.trainer import InferEngine
+    g = np.load(os.path.join(golden_dir, "%s_fwd.npz" % net))
+    img = torch.from_numpy(g["img"])
+    J, ks = int(g["J"]), float(g["ks"])
+    man = O.manifest_for(net, J)
+    outs = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv("AWR_FUSE2_MIN_WGS", "1")
+            monkeypatch.delenv("AWR_NO_FUSE2", raising=False)
+        else:
+            monkeypatch.setenv("AWR_NO_FUSE2", "1")
+        m = make_net(amd, net, J, O.procedural_state(man, seed=0))
+        m.eval()
+        inf = InferEngine(m, img.shape[0], 128, ks, autotune=False)
+        names = inf.plan.op_names("fwd")
+        npair = sum(1 for n in names if "+conv3" in n)
+        assert (npair >= 10) if fused else (npair == 0), names
+        jt = inf(img.to(dev)).cpu()
+        outs[fused] = (jt, inf.plan.dense_map(m.nstage - 1).cpu())
+    oracle = O.backbone_forward(net, O.procedural_state(man, seed=0), img, training=False)
+    gaps = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=0), img, ks, False)
+    s = len(oracle) - 1
+    scale = max(1.0, float(oracle[s].abs().max()))
+    assert float((outs[True][1] - oracle[s]).abs().max()) / scale <= 2e-4
+    assert float((outs[True][1] - outs[False][1]).abs().max()) / scale <= 2e-5
+    assert_joints("%s/eval_fused_pairs/stage%d" % (net, s), outs[True][0].numpy(), g["eval_s%d_jt" % s], gaps[s])
