@@ -344,7 +344,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
 constexpr int F2P = 132;      // pitch (floats) of the intermediate tile in LDS: rows 4 banks apart like LDK
 template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const awr_conv_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
     static_assert(!FUSE2 || (TM == 1 && TN == 2 && NP == 0 && !DUAL && !SPLIT), "FUSE2: 64x128 tile, FP32-MFMA mode");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // R[cd][t][cg] += sum_{m in K-chunk} D[m][cd] * G[gather(m,t)][cg]      (split-K over pixels)
 // ------------------------------------------------------------------------------------------
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int BK = WBK;        // pixels per K-slice (shadows the channel-slice constant of the forward kernel)
     constexpr int LDM = BM + 4, LDN = BN + 4;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(64 * KS * 4) void conv_wgrad_taps_kernel(const awr_
 // (128 B per pixel) and the LDS stores (64 contiguous bytes per 8 lanes, the other 8 lanes 16 banks away) conflict-free.
 // LDS image, fragment reads and MFMA schedule are the ones of the forward kernel (rows = channels).
 template <int TM, int TN, int NP>
-__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_split_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int UD = 2 * BM, UG = 2 * BN;            // 4x4 units per 32-pixel slice of the D / G tile
     constexpr int NU = (UD + UG + 255) / 256;          // unit slots per thread

@@ -98,7 +98,7 @@ __device__ __forceinline__ void stem_load_patch16(float* patch, const float* __r
 // grid (groups of tiles_per_wg tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels x 32
 // channels.  A workgroup walks several tiles: the filter bank is loaded once and the next tile's patch is requested before the
 // current tile's MFMAs (a one-tile workgroup spends most of its life waiting for its 13 + 2 loads).
-__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_stats_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                                          int H, int W, int tiles_per_wg, int nslots, double* __restrict__ stats) {
     __shared__ float patch[ST_PH * ST_PW];
     __shared__ double red[4][2][32];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
 // conv (+ bias) -> affine (BatchNorm) -> [ReLU]: writes the full-resolution NHWC map (Hourglass stem)
 // ------------------------------------------------------------------------------------------
 // grid (tiles of 16x16 pixels, channel half, image).  A store instruction covers two pixels x 32 channels = two full 128-byte lines.
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu, int H, int W,
                                                         float* __restrict__ out) {
     __shared__ float patch[ST_PH * ST_PW];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
 // gradient of its accumulator elements directly (two pixels x 32 channels = two 128-byte lines per load instruction).
 // grid (groups of tiles_per_wg tiles of 16x16 pixels, channel half, image); 256 threads = 4 waves x 2 tiles of 32 pixels
 template <int WGRAD, bool DENSE>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ coef4, const float* __restrict__ bcoef,
                                                        const float* __restrict__ dpool, const uint8_t* __restrict__ argmax, int H, int W,
                                                        int tiles_per_wg, int nslots, double* __restrict__ sums, float* __restrict__ dw) {
