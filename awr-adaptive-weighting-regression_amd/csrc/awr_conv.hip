@@ -342,17 +342,17 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // applied in registers, the tile goes to LDS as the A operand of a second, 1x1 GEMM (w2: [N][128]) whose result gets the ordinary epilogue
 // (bias2, residual) -- the hourglass residual's conv2 (3x3) -> bn3 -> ReLU -> conv3 (1x1) + skip (hourglass.py:44-59) in one launch at
 // inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
-constexpr int F2P = 132;      // pitch (floats) of the intermediate tile in LDS: rows 4 banks apart like LDK
 template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
-    static_assert(!FUSE2 || (TM == 1 && TN == 2 && NP == 0 && !DUAL && !SPLIT), "FUSE2: 64x128 tile, FP32-MFMA mode");
+    static_assert(!FUSE2 || (NP == 0 && !DUAL && !SPLIT), "FUSE2: FP32-MFMA mode");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
     constexpr int ROWB = NP ? LDR : LDK * 4;    // LDS row pitch in bytes
     // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
     // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 fp32 configuration).
-    // FUSE2: [intermediate tile 64 x 132 (over the dead phase-1 slices)][w2 K-slices 128 x 36, then the transpose tiles]
-    __shared__ __attribute__((aligned(16))) char smem_raw[FUSE2 ? 64 * F2P * 4 + 128 * LDK * 4 : (BM + BN) * ROWB];
+    // FUSE2: [intermediate tile BM x (BN + 4) (over the dead phase-1 slices)][w2 K-slices BN x 36, then the transpose tiles]
+    __shared__ __attribute__((aligned(16))) char smem_raw[FUSE2 ? BM * (BN + 4) * 4 + (BN * LDK * 4 > 4 * 32 * LDK * 4 ? BN * LDK * 4 : 4 * 32 * LDK * 4)
+                                                                : (BM + BN) * ROWB];
     float* const smem = reinterpret_cast<float*>(smem_raw);
     char* const As = smem_raw;
     char* const Bs = smem_raw + BM * ROWB;
@@ -719,56 +719,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
     }
     if constexpr (FUSE2) {
-        float* const A2 = smem;                                  // [64][F2P]: relu(bn(conv + bias)), all 128 channels of the tile's pixels
-        char* const B2 = smem_raw + 64 * F2P * 4;                // [128][LDK]: one K-slice of w2; afterwards the epilogue's transpose tiles
+        constexpr int P2 = BN + 4;                               // pitch of the intermediate tile (floats): rows 4 banks apart like LDK
+        float* const A2 = smem;                                  // [BM][P2]: relu(bn(conv + bias)), ALL BN channels of the tile's pixels
+        char* const B2 = smem_raw + BM * P2 * 4;                 // [BN][LDK]: one K-slice of w2; afterwards the epilogue's transpose tiles
         __syncthreads();                                         // the phase-1 slices are dead
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = wn * 64 + j * 32 + l31;
+            const int col = wn * 32 * TN + j * 32 + l31;
             const float b1 = a.bias ? a.bias[col] : 0.f, sc = a.out_scale ? a.out_scale[col] : 1.f, sh = a.out_shift ? a.out_shift[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (acc[0][j][r] + b1) * sc + sh;
-                if (a.relu_out) v = fmaxf(v, 0.f);
-                A2[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * F2P + col] = v;
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[i][j][r] + b1) * sc + sh;
+                    if (a.relu_out) v = fmaxf(v, 0.f);
+                    A2[(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * P2 + col] = v;
+                }
         }
+        // second GEMM: K = the BN intermediate channels (A from LDS) followed by a.N1x channels of a second tensor at the same pixel
+        // (`in2`: the block input of a residual with a skip conv -- w2 rows are [W3 | Wskip]; A fragments straight from global memory, a
+        // lane's 16 bytes per 8-k sub-step: no staging buffer, the 52 KB of LDS and three workgroups per CU stay)
+        const int K2 = BN + a.N1x, nsl = K2 / BK, nsl_lds = BN / BK;
         const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, OOB);
-        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 + l31) * F2P) * 4 + 16 * half;
-        const char* b2_frag = B2 + (wn * 64 + l31) * ROWB + 16 * half;
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.N1x ? a.in2 : a.in, a.N1x ? (unsigned)M * (unsigned)a.N1x * 4u : 0u);
+        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 * TM + l31) * P2) * 4 + 16 * half;
+        const char* b2_frag = B2 + (wn * 32 * TN + l31) * ROWB + 16 * half;
+        unsigned x_off[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
+            x_off[i] = m < M ? ((unsigned)m * (unsigned)a.N1x + 4u * half) * 4u : OOB;
+        }
         awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
         e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
-        // 128 output channels at a time (two passes: N == 256), four K-slices of the 128 intermediate ones each; the passes are unrolled
-        // so that each epilogue is straight-line code with its own register allocation (inside a run-time loop it cost 47 VGPRs)
-        float4 rb2[4];
+        // BN output channels at a time: exactly two passes (N == 2 BN), unrolled so that each epilogue is straight-line code with its own
+        // register allocation (inside a run-time loop the inlined epilogue cost 47 VGPRs and a wave of occupancy)
+        float4 rb2[RB], xa[TM][4];
         auto load_b2 = [&](int hf, int s2) {
-            const unsigned row0 = (unsigned)(hf * 128 + r0), k0 = (unsigned)(32 * s2 + kc);
+            const unsigned row0 = (unsigned)(hf * BN + r0), k0 = (unsigned)(BK * s2 + kc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * 128u + k0) * 4u);
+            for (int i = 0; i < RB; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * (unsigned)K2 + k0) * 4u);
+        };
+        auto load_x = [&](int s2) {       // the four 8-k sub-steps of slice s2 (>= nsl_lds) of this lane's rows
+            const unsigned kb = (unsigned)(BK * (s2 - nsl_lds)) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xa[i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
         };
         load_b2(0, 0);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-            for (int s2 = 0; s2 < 4; ++s2) {
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int s2 = 0; s2 < nsl; ++s2) {
+                if (s2 >= nsl_lds) load_x(s2);      // (in flight across the barriers and the slice's LDS stores)
                 __syncthreads();             // first slice: the intermediate tile is complete / the transpose tiles are dead; later: the previous slice is
 #pragma unroll
-                for (int i = 0; i < 4; ++i) st4(reinterpret_cast<float*>(B2 + (r0 + 32 * i) * ROWB) + kc, rb2[i]);
+                for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(B2 + (r0 + 32 * i) * ROWB) + kc, rb2[i]);
                 __syncthreads();
-                if (s2 < 3) load_b2(hf, s2 + 1);
+                if (s2 + 1 < nsl) load_b2(hf, s2 + 1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float4 fa = ld4(reinterpret_cast<const float*>(a2_frag) + 32 * s2 + 8 * s);
-                    float4 fb[TN];
+                    float4 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = s2 < nsl_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + BK * s2 + 8 * s) : xa[i][s];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_frag + j * 32 * ROWB) + 8 * s);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa.x)[k], (&fb[j].x)[k], acc[0][j], 0, 0, 0);
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
                 }
             }
             if (hf == 0) load_b2(1, 0);      // (in flight under the first pass's epilogue)
@@ -1396,7 +1425,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(!a->bnr2_y || (a->bnr_y && a->bnr2_coef && a->stats2), "conv_gemm: a second fused reduction (bnr2_y) needs bnr_y, bnr2_coef and stats2");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
-    AWR_REQUIRE(!a->in2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),
+    AWR_REQUIRE(!a->in2 || a->w2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),
                 "conv_gemm: a second input tensor needs the FP32-MFMA mode, one tap and 0 < Cin1 < Cin, Cin1 %% 32 == 0");
     for (int p = 0; p < a->nphase; ++p) {
         AWR_REQUIRE(a->ph[p].ntaps >= 1 && a->ph[p].ntaps <= 16, "conv_gemm: phase %d has %d taps", p, a->ph[p].ntaps);
@@ -1404,14 +1433,17 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     }
     const int64_t M = (int64_t)a->B * a->Hq * a->Wq;
     AWR_REQUIRE(M < (1LL << 31), "conv_gemm: too many output pixels");
-    if (a->w2) {      // two convolutions back to back (FUSE2)
-        AWR_REQUIRE(g_products == 1 && a->N1 == 128 && a->N == 256 && a->so == 1 && a->nphase == 1 && !a->stats && !a->bnr_y && !a->in2 &&
-                        !a->partial && a->split_k <= 1,
-                    "conv_gemm: the fused pair (w2) needs the FP32-MFMA mode, 128 intermediate channels, N == 256, a stride-1 output "
-                    "and no stats / bnr_y / in2 / split-K (N1=%d, N=%d)", a->N1, a->N);
+    if (a->w2) {      // two convolutions back to back (FUSE2): the tile's N extent is the first conv's channel count
+        AWR_REQUIRE(g_products == 1 && (a->N1 == 128 || a->N1 == 64) && a->N == 2 * a->N1 && a->so == 1 && a->nphase == 1 && !a->stats && !a->bnr_y &&
+                        !a->partial && a->split_k <= 1 && a->N1x >= 0 && a->N1x % BK == 0 && (a->N1x == 0) == (a->in2 == nullptr) && !(a->N1x && a->res),
+                    "conv_gemm: the fused pair (w2) needs the FP32-MFMA mode, 64 or 128 intermediate channels, N == 2 N1, a stride-1 output, "
+                    "no stats / bnr_y / split-K, and either a residual or a second input (N1=%d, N=%d, N1x=%d)", a->N1, a->N, a->N1x);
         AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32),
                     "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
-        hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, false, true>), dim3((unsigned)((M + 63) / 64), 1), dim3(256), 0, as_stream(stream), *a);
+        const dim3 grid2((unsigned)((M + (a->N1 == 64 && a->tile_m == 2 ? 127 : 63)) / (a->N1 == 64 && a->tile_m == 2 ? 128 : 64)), 1);
+        if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
+        else if (a->tile_m == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
         return check_launch("conv_gemm_kernel<fused pair>");
     }
     AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31),

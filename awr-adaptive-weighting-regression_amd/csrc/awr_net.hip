@@ -907,45 +907,66 @@ struct Builder {
     // Inference: y = conv3(relu(bn3(conv2(x)))) + res as ONE launch (awr_conv_args.w2): conv2 has 128 output channels, so a 64x128 tile holds
     // every channel of its pixels and feeds the 1x1 conv3 from LDS -- the intermediate never goes to HBM.  o = conv2's epilogue (folded bn3, ReLU).
     // nullptr when the pair does not qualify (shape, product mode, too few workgroups to fill the chip without split-K).
-    Tn* conv_pair(Tn* x, ConvLayer* c2, const ConvOpt& o, ConvLayer* c3, Tn* res) {
+    Tn* conv_pair(Tn* x, ConvLayer* c2, const ConvOpt& o, ConvLayer* c3, Tn* res, DualLayer* dual = nullptr, Tn* xin = nullptr) {
         const bool off = getenv("AWR_NO_FUSE2") != nullptr;                    // same-box A/B hook (read per plan)
         const int min_wgs = env_or("AWR_FUSE2_MIN_WGS", 1024);                 // (tests force the fused form on small batches)
+        const bool no_dual = getenv("AWR_NO_FUSE2_DUAL") != nullptr;
+        if (dual) c3 = dual->c3;
         const Spec &s2 = c2->spec, &s3 = c3->spec;
         const int64_t wgs = ((int64_t)x->B * x->H * x->W + 63) / 64;
+        const int n1 = s2.cout;
         if (off || P.training || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
-            s2.cout != 128 || s3.cin != 128 || s3.cout != 256 || wgs < min_wgs || x->lazy)
+            (n1 != 128 && n1 != 64) || s3.cin != n1 || s3.cout != 2 * n1 || wgs < min_wgs || x->lazy || (dual && no_dual))
+            return nullptr;
+        if (dual && (dual->sk->spec.k != 1 || dual->sk->spec.stride != 1 || dual->sk->spec.cout != s3.cout || dual->sk->spec.cin_pad % 32 != 0 ||
+                     xin->lazy || xin->H != x->H || xin->W != x->W))
             return nullptr;
         use_layer(c2);
-        use_layer(c3);
         const int B = x->B;
         const Prob prob = fwd_problem(s2, x->H, x->W);
-        if (prob.so != 1 || prob.phases.size() != 1 || prob.N != 128) return nullptr;
-        Tn* y = new_t(B, prob.Hout, prob.Wout, 256, true, c3->name + ".out");
+        if (prob.so != 1 || prob.phases.size() != 1 || prob.N != n1) return nullptr;
+        const float *w2, *bias2;
+        int n1x = 0;
+        if (dual) {
+            (void)conv_dual_prepare(dual);      // [W3 | Wskip] side by side, biases summed (the packed buffer conv_dual launches with)
+            w2 = dual->p.p;
+            bias2 = dual->bias_sum;
+            n1x = dual->sk->spec.cin_pad;
+        } else {
+            use_layer(c3);
+            w2 = c3->p_fwd.p;
+            bias2 = c3->bias_ptr();
+        }
+        if (err) return nullptr;
+        Tn* y = new_t(B, prob.Hout, prob.Wout, 2 * n1, true, (dual ? dual->name : c3->name) + ".out");
         join_if(res);
         P.cargs.emplace_back();
         awr_conv_args* a = &P.cargs.back();
         fill_conv_args(*a, prob, B, x->buf, c2->p_fwd.p, c2->p_fwd.split, y->buf, s2.T());
-        a->N1 = prob.N;
-        a->N = 256;
-        a->w2 = c3->p_fwd.p;
+        a->N1 = n1;
+        a->N = 2 * n1;
+        a->w2 = w2;
         a->bias = c2->bias_ptr();
-        a->bias2 = c3->bias_ptr();
+        a->bias2 = bias2;
         a->in_scale = o.in_scale; a->in_shift = o.in_shift; a->relu_in = o.relu_in;
         a->out_scale = o.out_scale; a->out_shift = o.out_shift; a->relu_out = o.relu_out;
         a->res = res ? res->buf : nullptr;
-        const std::string name = "awr_conv_gemm:" + c2->name + "+" + c3->name.substr(c3->name.rfind('.', c3->name.rfind('.') - 1) + 1);
+        if (dual) { a->in2 = xin->buf; a->N1x = n1x; }
+        if (n1 == 64) a->tile_m = env_or("AWR_FUSE2_TM64", 2), a->tile_n = 1;      // 128x64 tile (what the tuner picks for this conv on its own)
+        const std::string tail = dual ? "conv3+skip_layer" : c3->name.substr(c3->name.rfind('.', c3->name.rfind('.') - 1) + 1);
+        const std::string name = "awr_conv_gemm:" + c2->name + "+" + tail;
         Op& op = f(name, [a](void* s) { return awr_conv_gemm(a, s); });
         op.gemm = true;
-        op.macs = gemm_macs(prob, B, s2) + gemm_macs(fwd_problem(s3, prob.Hout, prob.Wout), B, s3);
+        op.macs = gemm_macs(prob, B, s2) + gemm_macs(fwd_problem(s3, prob.Hout, prob.Wout), B, s3) +
+                  (dual ? gemm_macs(fwd_problem(dual->sk->spec, prob.Hout, prob.Wout), B, dual->sk->spec) : 0.0);
         GemmRef g{a, nullptr, name};
-        g.tm = 1; g.tn = 2; g.tuned = true;      // one geometry: nothing for the tuner to choose
+        g.tm = n1 == 64 ? a->tile_m : 1; g.tn = n1 == 64 ? 1 : 2; g.tuned = true;      // one geometry: nothing for the tuner to choose
         P.gemms.push_back(g);
         return y;
     }
 
-    // y = conv3(a) + skip(x) (+ both biases) as ONE launch (FP32-MFMA mode): the skip branch's output is never written or re-read.
-    // Backward: the two layers' own weight / data gradients, both reading d(y).
-    Tn* conv_dual(Tn* a, Tn* x, DualLayer* d, bool want_stats) {
+    // registers a dual layer with the plan (packed [W3 | Wskip] buffer + summed bias, refreshed with the weights); idempotent
+    int conv_dual_prepare(DualLayer* d) {
         use_layer(d->c3);
         use_layer(d->sk);
         bool seen = false;
@@ -961,6 +982,14 @@ struct Builder {
             }
             P.dual_layers.push_back(d);
         }
+        return err;
+    }
+
+    // y = conv3(a) + skip(x) (+ both biases) as ONE launch (FP32-MFMA mode): the skip branch's output is never written or re-read.
+    // Backward: the two layers' own weight / data gradients, both reading d(y).
+    Tn* conv_dual(Tn* a, Tn* x, DualLayer* d, bool want_stats) {
+        (void)conv_dual_prepare(d);
+        const int cin1 = d->c3->spec.cin_pad, cin2 = d->sk->spec.cin_pad, cout = d->c3->spec.cout;
         const int B = a->B;
         Spec spec = make_spec(false, cin1 + cin2, cout, 1, 1, 0);
         const Prob prob = fwd_problem(spec, a->H, a->W);
@@ -1654,8 +1683,12 @@ struct NetBuilder {
         Tn* y = b.conv(x, C(p + ".conv1"), o);
         ConvOpt o2;
         o2.out_scale = s3.first; o2.out_shift = s3.second; o2.relu_out = true;
-        if (!dual && !skip)      // identity skip, 256 -> 128 -> 128 -> 256: conv2 and conv3 in one launch when the batch fills the chip
+        // conv2 and conv3 (+ the skip conv, as extra K of the second GEMM) in one launch when the batch fills the chip
+        if (dual) {
+            if (Tn* fused = b.conv_pair(y, C(p + ".conv2"), o2, nullptr, nullptr, dual, x)) return fused;
+        } else if (!skip) {
             if (Tn* fused = b.conv_pair(y, C(p + ".conv2"), o2, C(p + ".conv3"), x)) return fused;
+        }
         y = b.conv(y, C(p + ".conv2"), o2);
         if (dual) return b.conv_dual(y, x, dual, false);
         Tn* r = skip ? b.conv(x, skip) : x;

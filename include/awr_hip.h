@@ -227,9 +227,11 @@ typedef struct awr_conv_args {
     const float* bnr2_coef; /* projection: a = relu(bn2(y) + bn_ds(y2))) shares the masked gradient g: also accumulate sum g, */
     double* stats2;         /* sum g*(y2-mean2)*invstd2 into stats2 (same slot geometry as `stats`); coef2 = [scale|shift|mean|invstd][N] */
     const float* w2;        /* optional: TWO convolutions in one launch (inference; FP32-MFMA mode).  The conv described above has N1 = 128 */
-    const float* bias2;     /* output channels: bias / out_scale / out_shift / relu_out apply to THAT intermediate, which never leaves the */
-    int N1;                 /* chip; a 1x1 conv with the packed weights w2 [N][1][N1] follows, its epilogue takes bias2 and `res`; `out` */
-    int reserved0;          /* and N describe the second conv's output (N == 256).  hourglass.py:44-59: conv2 -> bn3 -> ReLU -> conv3 + skip */
+    const float* bias2;     /* or 64 output channels: bias / out_scale / out_shift / relu_out apply to THAT intermediate, which never leaves */
+    int N1;                 /* the chip; a 1x1 conv with the packed weights w2 [N][1][N1 + N1x] follows, its epilogue takes bias2 and `res`; */
+    int N1x;                /* `out` and N = 2 N1 describe the second conv's output.  N1x > 0: the second conv's K extent continues with N1x */
+                            /* channels of `in2` at the same pixel (no `res` then).  hourglass.py:44-59: conv2 -> bn3 -> ReLU -> conv3 + skip */
+                            /* (identity skip = `res`; skip conv = [W3 | Wskip] over [intermediate | block input]) */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).

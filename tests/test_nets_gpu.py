@@ -875,7 +875,7 @@ def test_inference_fused_conv_pairs(amd, dev, golden_dir, net, monkeypatch):
         inf = InferEngine(m, img.shape[0], 128, ks, autotune=False)
         names = inf.plan.op_names("fwd")
         npair = sum(1 for n in names if "+conv3" in n)
-        assert (npair >= 10) if fused else (npair == 0), names
+        assert (npair >= 12 and sum(1 for n in names if "+conv3+skip_layer" in n) >= 2) if fused else (npair == 0), names
         jt = inf(img.to(dev)).cpu()
         outs[fused] = (jt, inf.plan.dense_map(m.nstage - 1).cpu())
     oracle = O.backbone_forward(net, O.procedural_state(man, seed=0), img, training=False)

@@ -615,42 +615,50 @@ def test_wgrad_one_wave_per_tap(ops, L, dev, kind, cin, cout, k, stride, B, H):
         assert rel_err(out.cpu(), gw_ref) < 1e-5, blocks
 
 
-@pytest.mark.parametrize("B,H,cin,k", [(2, 16, 128, 3), (3, 10, 128, 3), (1, 8, 64, 1)])      # ragged M (300 pixels), a 1x1 first conv
-def test_fused_conv_pair(ops, L, dev, B, H, cin, k):
-    """awr_conv_args.w2: conv (cin -> 128) -> bias -> folded BatchNorm -> ReLU -> conv 1x1 (128 -> 256) -> bias2 -> + residual in ONE launch
-    (the hourglass residual's conv2 / bn3 / conv3 / skip at inference, hourglass.py:44-59), against float64 and against the two-launch form."""
+@pytest.mark.parametrize("B,H,cin,k,n1,cx,tm", [(2, 16, 128, 3, 128, 0, 1), (3, 10, 128, 3, 128, 0, 1), (1, 8, 64, 1, 128, 0, 1),      # ragged M (300 pixels), a 1x1 first conv
+                                                (2, 16, 128, 3, 128, 128, 1), (3, 10, 64, 3, 64, 64, 2), (3, 10, 64, 3, 64, 64, 1), (2, 16, 64, 3, 64, 0, 2)])
+def test_fused_conv_pair(ops, L, dev, B, H, cin, k, n1, cx, tm):
+    """awr_conv_args.w2: conv (cin -> n1) -> bias -> folded BatchNorm -> ReLU -> conv 1x1 (n1 [+ cx channels of a second tensor] -> 2 n1) ->
+    bias2 [-> + residual] in ONE launch (the hourglass residual's conv2 / bn3 / conv3 / skip at inference, hourglass.py:44-59: identity skip =
+    residual, skip conv = extra K of the second GEMM), against float64 and against the two-launch form; 64x128, 128x64 and 64x64 tiles."""
     import ctypes as C
-    s1 = ops.ConvSpec("conv", cin, 128, k, 1, k // 2)
-    s2 = ops.ConvSpec("conv", 128, 256, 1, 1, 0)
+    n2 = 2 * n1
+    s1 = ops.ConvSpec("conv", cin, n1, k, 1, k // 2)
+    s2 = ops.ConvSpec("conv", n1 + cx, n2, 1, 1, 0)
     x = rnd(B, cin, H, H, seed=1)
-    w1, b1 = rnd(128, cin, k, k, seed=2, scale=0.05), rnd(128, seed=3)
-    w2, b2 = rnd(256, 128, 1, 1, seed=4, scale=0.1), rnd(256, seed=5)
+    w1, b1 = rnd(n1, cin, k, k, seed=2, scale=0.05), rnd(n1, seed=3)
+    w2, b2 = rnd(n2, n1 + cx, 1, 1, seed=4, scale=0.1), rnd(n2, seed=5)
     isc, ish = rnd(cin, seed=6) + 1.5, rnd(cin, seed=7)
-    sc, sh = rnd(128, seed=8) + 1.5, rnd(128, seed=9)
-    res = rnd(B, 256, H, H, seed=10)
+    sc, sh = rnd(n1, seed=8) + 1.5, rnd(n1, seed=9)
+    res = rnd(B, n2, H, H, seed=10) if not cx else None
+    x2 = rnd(B, cx, H, H, seed=11) if cx else None
     a0 = TF.relu(x.double() * isc.double().view(1, -1, 1, 1) + ish.double().view(1, -1, 1, 1))
     mid = TF.relu((TF.conv2d(a0, w1.double(), b1.double(), 1, k // 2)) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
-    ref = TF.conv2d(mid, w2.double(), b2.double()) + res.double()
+    ref = TF.conv2d(torch.cat([mid, x2.double()], 1) if cx else mid, w2.double(), b2.double()) + (res.double() if res is not None else 0.0)
     wp1, wp2 = ops.pack_weight(w1.to(dev), s1.fwd_pack()), ops.pack_weight(w2.to(dev), s2.fwd_pack())
-    xg, rg = ops.nhwc(x).to(dev), ops.nhwc(res).to(dev)
+    xg = ops.nhwc(x).to(dev)
+    rg = ops.nhwc(res).to(dev) if res is not None else None
+    x2g = ops.nhwc(x2).to(dev) if cx else None
     d = lambda t: t.to(dev)
     iscg, ishg, scg, shg, b1g, b2g = d(isc), d(ish), d(sc), d(sh), d(b1), d(b2)
     # two launches
     m2 = ops.conv_forward(s1, xg, wp1, in_scale=iscg, in_shift=ishg, relu_in=True, bias=b1g, out_scale=scg, out_shift=shg, relu_out=True)
-    y2 = ops.conv_forward(s2, m2, wp2, bias=b2g, res=rg)
+    y2 = ops.conv_forward(s2, torch.cat([m2, x2g], 3).contiguous() if cx else m2, wp2, bias=b2g, res=rg)
     # one launch
     prob = s1.fwd_problem(H, H)
-    y1 = torch.full((B, H, H, 256), float("nan"), device=dev)
+    y1 = torch.full((B, H, H, n2), float("nan"), device=dev)
     a = ops.make_conv_args(prob, B, xg, wp1, y1, in_scale=iscg, in_shift=ishg, relu_in=True, bias=b1g, out_scale=scg, out_shift=shg, relu_out=True, res=rg, T=s1.T)
-    a.w2, a.bias2, a.N1, a.N = L.ptr(wp2), L.ptr(b2g), 128, 256
+    a.w2, a.bias2, a.N1, a.N, a.tile_m, a.tile_n = L.ptr(wp2), L.ptr(b2g), n1, n2, tm, (2 if n1 == 128 else 1)
+    if cx:
+        a.in2, a.N1x = L.ptr(x2g), cx
     L.call("awr_conv_gemm", C.byref(a), L.stream())
     torch.cuda.synchronize()
     assert rel_err(ops.nchw(y1).cpu(), ref) < 3e-6 and rel_err(ops.nchw(y2).cpu(), ref) < 3e-6
     assert rel_err(y1.cpu(), y2.cpu()) < 2e-6
-    # refusals: statistics, a stride-2 output and other channel counts have no fused form
-    a.N1 = 64
+    # refusals: other channel counts have no fused form
+    a.N1 = 32
     with pytest.raises(Exception):
         L.call("awr_conv_gemm", C.byref(a), L.stream())
-    a.N1, a.N = 128, 128
+    a.N1, a.N = n1, n1
     with pytest.raises(Exception):
         L.call("awr_conv_gemm", C.byref(a), L.stream())
