@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-parity --no-split-mode --no-extras --no-b256"
 python bench.py --steps 20 --warmup 5 --no-split-mode > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; cut -c1-250 $OUT/bench_$TAG.json
 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --per-layer $OUT/per_layer_${TAG}_f32.txt > /dev/null 2>> $OUT/bench_$TAG.err
+python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_${TAG}_hg1_train.txt > /dev/null 2>> $OUT/bench_$TAG.err
+python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 $COMMON --per-layer $OUT/per_layer_${TAG}_hg1_infer_b128.txt > /dev/null 2>> $OUT/bench_$TAG.err
 prof() {  # name, command...
   local name=$1; shift
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$name -o trace -- "$@" > $OUT/prof_${TAG}_$name.log 2>&1 )
