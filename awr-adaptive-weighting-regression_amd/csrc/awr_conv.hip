@@ -343,7 +343,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // (bias2, residual) -- the hourglass residual's conv2 (3x3) -> bn3 -> ReLU -> conv3 (1x1) + skip (hourglass.py:44-59) in one launch at
 // inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
 template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
+__device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
     static_assert(!FUSE2 || (NP == 0 && !DUAL && !SPLIT), "FUSE2: FP32-MFMA mode");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
@@ -806,6 +806,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         return;
     }
     gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
+}
+
+// amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
+    conv_gemm_body<TM, TN, NP, AFF, DUAL, SPLIT, FUSE2>(a);
+}
+// The plain 64x64 tile at SIX waves per SIMD: 80 registers and two spilled dwords instead of 87 (five waves).  Same-box A/B: ResNet18 step
+// 13.83-13.86 vs 13.91-13.93 ms, Hourglass-1 train 25.20 vs 25.29 ms, config 3 13.32 vs 13.34 ms.  (The 64x128 tile at five waves -- 96
+// registers, twelve spilled dwords -- is no faster: 13.85-13.91 ms, Hourglass-1 slower.)  AWR_NO_OCC6=1 is the A/B hook.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void conv_gemm_kernel_11_occ6(const awr_conv_args a) {
+    conv_gemm_body<1, 1, 0, false>(a);
 }
 
 // out = epilogue(sum over the split-K copies, in order): bias, folded-BN affine, residual, ReLU
@@ -1500,7 +1512,9 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
         else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)
-    if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);
+    static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
+    if (TM == 1 && TN == 1 && occ6 && g_products == 1 && !a->in2) hipLaunchKernelGGL(conv_gemm_kernel_11_occ6, grid, dim3(256), 0, st, *a);
+    else if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);
     else if (TM == 2 && TN == 1) AWR_LAUNCH_GEMM(2, 1);
     else if (TM == 1 && TN == 2) AWR_LAUNCH_GEMM(1, 2);
     else AWR_LAUNCH_GEMM(1, 1);
