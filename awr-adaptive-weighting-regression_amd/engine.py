@@ -295,7 +295,14 @@ class Plan:
         lst = 0 if which in (0, "fwd", "forward") else 1
         ms = (C.c_float * self.n_ops[lst])()
         L.call("awr_plan_run_timed", self.h, lst, L.stream(), ms)
-        return {n: ms[i] * 1e-3 for i, (n, g) in enumerate(self._ops[lst]) if (g or (every and ms[i] > 0))}
+        out, self.timed_counts = {}, getattr(self, "timed_counts", {})
+        for i, (n, g) in enumerate(self._ops[lst]):
+            if g or (every and ms[i] > 0):      # (GEMM-family names are unique; the element-wise launches share theirs: summed, counted)
+                if n not in out:
+                    self.timed_counts[n] = 0
+                out[n] = out.get(n, 0.0) + ms[i] * 1e-3
+                self.timed_counts[n] += 1
+        return out
 
     # ---- autotune --------------------------------------------------------------------------------------------
     def _gemm(self, i):

@@ -180,7 +180,8 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
             f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
             for n, (sec, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
                 mc = inf.plan.macs.get(n, 0)
-                f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * mc, 2e-12 * mc * c / max(sec, 1e-12)))
+                cnt = inf.plan.timed_counts.get(n, 1)      # (element-wise launches share a name: total per forward, launches per forward)
+                f.write("%-52s %10.1f %10.2f %8.1f%s\n" % (n, 1e6 * sec / c, 2e-9 * mc, 2e-12 * mc * c / max(sec, 1e-12), "" if cnt == 1 else "   x%d" % cnt))
     return {"workload": "%s eval forward + head (img -> joints), batch %d" % (net_name, batch), "value": round(batch * steps / el, 2), "unit": "images/s",
             "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "hipgraph": bool(graph),
             "algorithmic_gflop_per_image": round(2e-9 * macs / batch, 3),
@@ -397,10 +398,13 @@ def main():
             f.write("%-52s %10s %10s %8s\n" % ("launch", "avg_us", "GFLOP", "TFLOP/s"))
             for n, (sec, c) in sorted(per.items(), key=lambda kv: -kv[1][0]):
                 f.write("%-52s %10.1f %10.2f %8.1f\n" % (n, 1e6 * sec / c, 2e-9 * macs[n], 2e-12 * macs[n] * c / sec))
-            f.write("\nall other launches of the plan (serial replay, same event pass)\n")
+            f.write("\nall other launches of the plan (serial replay, same event pass): total us per step, launches per step\n")
+            tot_other = 0.0
             for n, (sec, c) in sorted(per_all.items(), key=lambda kv: -kv[1][0]):
                 if n not in macs:
-                    f.write("%-52s %10.1f\n" % (n, 1e6 * sec / c))
+                    f.write("%-52s %10.1f %6d\n" % (n, 1e6 * sec / c, eng.plan.timed_counts.get(n, 1)))
+                    tot_other += 1e6 * sec / c
+            f.write("%-52s %10.1f\n" % ("sum", tot_other))
     dom = max(kern, key=lambda k: kern[k]["seconds"])
     tot_fl = sum(k["flops"] for k in kern.values())
     tot_sec = sum(k["seconds"] for k in kern.values())
