@@ -95,6 +95,14 @@ def test_resnet18_train_step_through_the_c_abi_only(golden_dir):
     ms = (C.c_float * nf.value)()
     ok(lib.awr_plan_run_timed(plan, 0, s, ms))
     assert sum(ms) > 0
+    # every launch carries an event pair (fills / copies / markers report 0): GEMM family AND the element-wise launches between them
+    name, macs, flags = C.c_char_p(), C.c_double(), C.c_int()
+    timed = {}
+    for i in range(nf.value):
+        ok(lib.awr_plan_op(plan, 0, i, C.byref(name), C.byref(macs), C.byref(flags)))
+        if ms[i] > 0:
+            timed.setdefault(name.value.decode().split(":")[0], []).append(ms[i])
+    assert len(timed["awr_conv_gemm"]) >= 20 and len(timed["awr_bn_finalize"]) >= 20 and len(timed["awr_bn_apply"]) >= 8 and "awr_stem_pool" in timed
     ok(lib.awr_plan_autotune(plan, 1, s))
     ok(lib.awr_plan_destroy(plan))
     ok(lib.awr_net_destroy(net))
