@@ -1450,7 +1450,8 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
                         !a->partial && a->split_k <= 1 && a->N1x >= 0 && a->N1x % BK == 0 && (a->N1x == 0) == (a->in2 == nullptr) && !(a->N1x && a->res),
                     "conv_gemm: the fused pair (w2) needs the FP32-MFMA mode, 64 or 128 intermediate channels, N == 2 N1, a stride-1 output, "
                     "no stats / bnr_y / split-K, and either a residual or a second input (N1=%d, N=%d, N1x=%d)", a->N1, a->N, a->N1x);
-        AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32),
+        AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) &&
+                        M * (int64_t)a->N1x * 4 < (1LL << 32),
                     "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
         const dim3 grid2((unsigned)((M + (a->N1 == 64 && a->tile_m == 2 ? 127 : 63)) / (a->N1 == 64 && a->tile_m == 2 ? 128 : 64)), 1);
         if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);

@@ -919,7 +919,7 @@ struct Builder {
             (n1 != 128 && n1 != 64) || s3.cin != n1 || s3.cout != 2 * n1 || wgs < min_wgs || x->lazy || (dual && no_dual))
             return nullptr;
         if (dual && (dual->sk->spec.k != 1 || dual->sk->spec.stride != 1 || dual->sk->spec.cout != s3.cout || dual->sk->spec.cin_pad % 32 != 0 ||
-                     xin->lazy || xin->H != x->H || xin->W != x->W))
+                     xin->lazy || xin->H != x->H || xin->W != x->W || xin->C != dual->sk->spec.cin_pad))
             return nullptr;
         use_layer(c2);
         const int B = x->B;
