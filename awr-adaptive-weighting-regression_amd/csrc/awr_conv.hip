@@ -150,9 +150,36 @@ __device__ __forceinline__ void mfma_split16(const bf16x8 (&fa)[TM][3], const bf
 // 32x36 LDS tile and leaves with float4 rows: 4 sixteen-byte stores per lane, every store instruction covering eight
 // full 128-byte lines; bias / folded-BN affine / residual (also loaded as float4) / statistics / ReLU are applied on
 // the way out.  (The single-K-slice layers -- im2col'd stem, 1x1 convs on the 128x128 maps -- are store-bound.)
+// The rows of the ONE operand tensor an epilogue reads (a residual, or the y of a fused BatchNorm-backward reduction) that this lane needs
+// for accumulator tile (i, j): four 16-byte requests through a buffer resource whose out-of-range offset (ragged rows, padded columns)
+// returns zeros.  EPRE launches issue tile (0, 0)'s BEFORE the K loop and every later tile's right after the previous tile has been consumed.
+struct epi_rows { float4 v[4]; };
 template <int TM, int TN>
+__device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const awr_phase& ph, int M, int tile_m, int tile_n, int i, int j, epi_rows& R) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, c4 = lane & 7, rbase = lane >> 3;
+    const float* const one = a.res ? a.res : a.bnr_y;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));      // < 4 GB (checked at launch)
+    const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = tile_m * BM + wm * 32 * TM + i * 32 + rbase + 8 * q;
+        unsigned off = OOB;
+        if (m < M && n0 < a.N) {
+            int opix = m;
+            if (a.so != 1) {
+                const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+                opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
+            }
+            off = ((unsigned)opix * (unsigned)a.N + (unsigned)n0) * 4u;
+        }
+        R.v[q] = buf_ld4(rs, off);
+    }
+}
+
+template <int TM, int TN, bool EPRE = false>
 __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
-                                              int tile_m, int tile_n) {
+                                              int tile_m, int tile_n, epi_rows* pre = nullptr) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -208,7 +235,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
                     if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                     if (a.res) {
-                        const float4 rr = ld4(a.res + o);
+                        const float4 rr = EPRE ? pre->v[q] : ld4(a.res + o);
                         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                     }
                 }
@@ -219,7 +246,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 if (valid) {
                     if (a.bnr_y) {
                         // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
-                        const float4 yy = ld4(a.bnr_y + o);
+                        const float4 yy = EPRE ? pre->v[q] : ld4(a.bnr_y + o);
                         if (a.bnr_act) {      // the activation had a residual added before the ReLU: mask from the stored tensor
                             const float4 aa = ld4(a.bnr_act + o);
                             v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
@@ -246,6 +273,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 }
             }
             __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
+            if constexpr (EPRE) {                  // the next tile's rows, in flight across its LDS bounce
+                if (i + 1 < TM) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, i + 1, j, *pre);
+                else if (j + 1 < TN) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, 0, j + 1, *pre);
+            }
         }
         cs1[j] = s1;
         cs2[j] = s2;
@@ -342,7 +373,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
 // applied in registers, the tile goes to LDS as the A operand of a second, 1x1 GEMM (w2: [N][128]) whose result gets the ordinary epilogue
 // (bias2, residual) -- the hourglass residual's conv2 (3x3) -> bn3 -> ReLU -> conv3 (1x1) + skip (hourglass.py:44-59) in one launch at
 // inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false, bool EPRE = false>
 __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
     static_assert(!FUSE2 || (NP == 0 && !DUAL && !SPLIT), "FUSE2: FP32-MFMA mode");
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -557,6 +588,8 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
         return;
     }
     set_tap(0);
+    epi_rows epre;
+    if constexpr (EPRE) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, 0, 0, epre);      // lands while the K loop runs
     if constexpr (NP == 0) {
         load_slice(0);
         store_slice();
@@ -805,13 +838,14 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
         }
         return;
     }
-    gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
+    if constexpr (EPRE) gemm_epilogue<TM, TN, true>(a, ph, acc, smem, M, tile_m, tile_n, &epre);
+    else gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
 }
 
 // amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false>
+template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false, bool EPRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
-    conv_gemm_body<TM, TN, NP, AFF, DUAL, SPLIT, FUSE2>(a);
+    conv_gemm_body<TM, TN, NP, AFF, DUAL, SPLIT, FUSE2, EPRE>(a);
 }
 // The plain 64x64 tile at SIX waves per SIMD: 80 registers and two spilled dwords instead of 87 (five waves).  Same-box A/B: ResNet18 step
 // 13.83-13.86 vs 13.91-13.93 ms, Hourglass-1 train 25.20 vs 25.29 ms, config 3 13.32 vs 13.34 ms.  (The 64x128 tile at five waves -- 96
@@ -1506,15 +1540,20 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     const bool aff = a->in_scale != nullptr || a->relu_in;
+    // short K loops (<= 8 slices) whose epilogue reads exactly one operand tensor: that tensor's rows are requested ahead (EPRE)
+    static const bool no_epre = getenv("AWR_NO_EPRE") != nullptr;      // same-box A/B hook
+    const bool epre = !no_epre && g_products == 1 && !a->in2 && a->nphase == 1 && a->ph[0].ntaps * (a->Cin / BK) <= 8 &&
+                      ((a->res != nullptr) != (a->bnr_y != nullptr)) && !a->bnr_act && !a->bnr2_y;
 #define AWR_LAUNCH_GEMM(tm, tn)                                                                          \
     do {                                                                                                 \
-        if (a->in2) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false, true>), grid, dim3(256), 0, st, *a);             \
+        if (epre) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false, false, false, false, true>), grid, dim3(256), 0, st, *a);  \
+        else if (a->in2) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false, true>), grid, dim3(256), 0, st, *a);             \
         else if (g_products == 6 && aff) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, true>), grid, dim3(256), 0, st, *a);   \
         else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
         else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)
     static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
-    if (TM == 1 && TN == 1 && occ6 && g_products == 1 && !a->in2) hipLaunchKernelGGL(conv_gemm_kernel_11_occ6, grid, dim3(256), 0, st, *a);
+    if (TM == 1 && TN == 1 && occ6 && g_products == 1 && !a->in2 && !epre) hipLaunchKernelGGL(conv_gemm_kernel_11_occ6, grid, dim3(256), 0, st, *a);
     else if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);
     else if (TM == 2 && TN == 1) AWR_LAUNCH_GEMM(2, 1);
     else if (TM == 1 && TN == 2) AWR_LAUNCH_GEMM(1, 2);
