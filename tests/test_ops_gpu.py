@@ -662,3 +662,49 @@ def test_fused_conv_pair(ops, L, dev, B, H, cin, k, n1, cx, tm):
     a.N1, a.N = n1, n1
     with pytest.raises(Exception):
         L.call("awr_conv_gemm", C.byref(a), L.stream())
+
+
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("cin,cout,B,H", [(128, 160, 3, 10), (256, 128, 2, 16), (64, 96, 2, 12)])      # ragged M and N; 4 / 8 / 2 K-slices
+def test_short_k_epilogue_operand_prefetch(ops, L, dev, tm, tn, cin, cout, B, H):
+    """1x1 convs with at most eight K-slices whose epilogue reads ONE operand tensor run the instantiation that requests that tensor's
+    rows ahead of their use (tile (0, 0) before the K loop): residual + statistics forward (hourglass.py:44-59 conv3 + identity skip), and
+    the data gradient with the fused BatchNorm-backward reduction (mask re-derived from y), every tile, against float64 and against the
+    plain instantiation (AWR_NO_EPRE is read once per process: the comparison is with the 3x3 / two-operand paths' arithmetic, i.e. float64)."""
+    import ctypes as C
+    spec = ops.ConvSpec("conv", cin, cout, 1, 1, 0)
+    x, w, bias = rnd(B, cin, H, H, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=0.1), rnd(cout, seed=3)
+    res = rnd(B, cout, H, H, seed=4)
+    pre = TF.conv2d(x.double(), w.double(), bias.double()) + res.double()
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    stats = torch.zeros(16, 2, cout, device=dev, dtype=torch.float64)
+    prob = spec.fwd_problem(H, H)
+    out = torch.full((B, H, H, prob["N"]), float("nan"), device=dev)
+    a = ops.make_conv_args(prob, B, ops.nhwc(x).to(dev), wp, out, bias=bias.to(dev), res=ops.nhwc(res).to(dev), stats=stats, T=spec.T)
+    a.tile_m, a.tile_n = tm, tn
+    L.call("awr_conv_gemm", C.byref(a), L.stream())
+    assert rel_err(ops.nchw(out)[:, :cout].cpu(), pre) < 2e-6
+    assert rel_err(stats.sum(0)[0][:cout].cpu(), pre.sum((0, 2, 3))) < 1e-5 and rel_err(stats.sum(0)[1][:cout].cpu(), (pre * pre).sum((0, 2, 3))) < 1e-5
+    # data gradient (cout -> cin channels) masked by relu(bn(y)) and reduced for the BatchNorm backward in the same launch
+    gy = rnd(B, cout, H, H, seed=5)
+    y = rnd(B, cin, H, H, seed=6)
+    coef4 = torch.stack([rnd(cin, seed=7) + 1.2, rnd(cin, seed=8) * 0.3, rnd(cin, seed=9) * 0.2, rnd(cin, seed=10) + 1.5])      # scale, shift, mean, invstd
+    v = TF.conv_transpose2d(gy.double(), w.double())
+    mask = (y.double() * coef4[0].double().view(1, -1, 1, 1) + coef4[1].double().view(1, -1, 1, 1)) > 0
+    g_ref = v * mask
+    xhat = (y.double() - coef4[2].double().view(1, -1, 1, 1)) * coef4[3].double().view(1, -1, 1, 1)
+    wd = ops.pack_weight(w.to(dev), spec.dgrad_pack())
+    dprob = spec.dgrad_problem(H, H)
+    g = torch.full((B, H, H, dprob["N"]), float("nan"), device=dev)
+    sums = torch.zeros(16, 2, dprob["N"], device=dev, dtype=torch.float64)
+    yg = torch.zeros(B, H, H, dprob["N"], device=dev)
+    yg[..., :cin] = ops.nhwc(y).to(dev)
+    c4 = torch.zeros(4, dprob["N"], device=dev)
+    c4[:, :cin] = coef4.to(dev)
+    d = ops.make_conv_args(dprob, B, ops.nhwc(gy).to(dev) if cout == dprob["Cin"] else torch.nn.functional.pad(ops.nhwc(gy), (0, dprob["Cin"] - cout)).to(dev),
+                           wd, g, stats=sums, T=spec.T)
+    d.bnr_y, d.bnr_coef, d.tile_m, d.tile_n = L.ptr(yg), L.ptr(c4), tm, tn
+    L.call("awr_conv_gemm", C.byref(d), L.stream())
+    torch.cuda.synchronize()
+    assert rel_err(ops.nchw(g)[:, :cin].cpu(), g_ref) < 3e-6
+    assert rel_err(sums.sum(0)[0][:cin].cpu(), g_ref.sum((0, 2, 3))) < 1e-5 and rel_err(sums.sum(0)[1][:cin].cpu(), (g_ref * xhat).sum((0, 2, 3))) < 2e-5
