@@ -885,3 +885,35 @@ def test_inference_fused_conv_pairs(amd, dev, golden_dir, net, monkeypatch):
     assert float((outs[True][1] - oracle[s]).abs().max()) / scale <= 2e-4
     assert float((outs[True][1] - outs[False][1]).abs().max()) / scale <= 2e-5
     assert_joints("%s/eval_fused_pairs/stage%d" % (net, s), outs[True][0].numpy(), g["eval_s%d_jt" % s], gaps[s])
+
+
+@pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
+def test_single_image_and_odd_batches(amd, dev, net):
+    """test.py:67-86 feeds whatever the loader's last batch holds; train.py keeps the ragged last batch (drop_last = False).  Batch 1 and
+    batch 3 plans (one / three 64-pixel tiles at the innermost Hourglass level, split-K inference launches) against the oracle: eval joints of
+    every image equal the joints of the same image evaluated alone, and one train step at batch 1 matches the oracle's loss and joints."""
+    from awr_amd.trainer import InferEngine, TrainEngine
+    J = 14
+    ks = 1.0 if net.startswith("resnet") else 0.4
+    man = O.manifest_for(net, J)
+    img, jt_gt = O.synth_batch(3, 128, J, seed=61)
+    sd = O.procedural_state(man, seed=6)
+    ref = O.offset2joint_softmax(O.backbone_forward(net, O.procedural_state(man, seed=6), img, training=False)[-1], img, ks)
+    gap = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=6), img, ks, False)[-1]
+    m = make_net(amd, net, J, sd)
+    jt3 = InferEngine(m, 3, 128, ks, autotune=False)(img.to(dev)).cpu()
+    assert_joints("%s/infer_b3" % net, jt3.numpy(), ref.numpy(), gap)
+    inf1 = InferEngine(m, 1, 128, ks, autotune=False)
+    for i in range(3):
+        jt1 = inf1(img[i:i + 1].to(dev)).cpu()
+        assert_joints("%s/infer_b1/img%d" % (net, i), jt1.numpy(), ref[i:i + 1].numpy(), gap)
+        d13 = (jt1 - jt3[i:i + 1]).norm(dim=-1) * 150.0      # tiles and split-K depths differ with the batch: the summation order does too
+        assert float(d13.mean()) <= 1e-3 and float(d13.max()) <= 5e-3
+    # one optimisation step on a single image
+    mt = make_net(amd, net, J, O.procedural_state(man, seed=6))
+    eng = TrainEngine(mt, 1, 128, ks, coord_weight=1.0, autotune=False)
+    losses, jt = eng.step(img[:1].to(dev), jt_gt[:1].to(dev))
+    sdo, ost = O.procedural_state(man, seed=6), {"step": 0, "m": {}, "v": {}}
+    out = O.train_step(net, sdo, ost, img[:1], jt_gt[:1], ks, 1.0, 1.0)
+    lo = float(out[0]) if isinstance(out, (tuple, list)) else float(out)
+    assert abs(float(losses[2]) - lo) <= 2e-4 * abs(lo)
