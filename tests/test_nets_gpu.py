@@ -917,3 +917,9 @@ def test_single_image_and_odd_batches(amd, dev, net):
     out = O.train_step(net, sdo, ost, img[:1], jt_gt[:1], ks, 1.0, 1.0)
     lo = float(out[0]) if isinstance(out, (tuple, list)) else float(out)
     assert abs(float(losses[2]) - lo) <= 2e-4 * abs(lo)
+    # an empty batch and a batch larger than the plan are refused, not padded
+    from awr_amd import _lib as L
+    with pytest.raises(L.AwrError):
+        eng.step(img[:0].to(dev), jt_gt[:0].to(dev))
+    with pytest.raises(L.AwrError):
+        eng.step(img[:2].to(dev), jt_gt[:2].to(dev))
