@@ -1448,14 +1448,25 @@ static std::vector<awr_plan::Bucket> plan_buckets(std::vector<GradWrite> ws, int
     std::stable_sort(ws.begin(), ws.end(), [](const GradWrite& a, const GradWrite& b) { return a.lo > b.lo; });
     int64_t total = 0;
     for (auto& w : ws) total += w.hi - w.lo;
-    const double target = (double)total / (double)(n_buckets > 1 ? n_buckets : 1);
-    int64_t acc = 0, hi_edge = n_active;
+    // The LAST bucket (the arena's first layers: final only when the backward ends) has nothing left to hide its exchange behind, so it is
+    // kept small -- the leading tensors up to 1 % of the parameters (ResNet18: the stem and layer1, 0.6 MB of 61.5 MB) -- and the others
+    // share the rest equally.  (Equal quarters left 15 MB = a quarter of the all-reduce exposed after the last data-gradient GEMM.)
+    int64_t tail = 0;
+    if (n_buckets > 2)
+        for (size_t i = ws.size(); i-- > 0;) {
+            if (tail + (ws[i].hi - ws[i].lo) > total / 100) break;
+            tail += ws[i].hi - ws[i].lo;
+        }
+    const double target = (double)(total - tail) / (double)(n_buckets > 1 ? n_buckets - (tail > 0 ? 1 : 0) : 1);
+    int64_t acc = 0, hi_edge = n_active, left = total;
     int ready = -1;
     for (size_t i = 0; i < ws.size(); ++i) {
         acc += ws[i].hi - ws[i].lo;
+        left -= ws[i].hi - ws[i].lo;
         if (ws[i].ready > ready) ready = ws[i].ready;
         const bool last = i + 1 == ws.size();
-        if (last || ((double)acc >= target && (int)out.size() < n_buckets - 1)) {
+        const bool cut_tail = tail > 0 && left == tail;      // everything below is the small last bucket
+        if (last || cut_tail || ((double)acc >= target && (int)out.size() < n_buckets - 1 - (tail > 0 ? 1 : 0))) {
             const int64_t edge = last ? 0 : ws[i].lo;
             out.push_back({edge, hi_edge, ready});
             hi_edge = edge;

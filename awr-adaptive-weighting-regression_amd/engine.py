@@ -29,13 +29,24 @@ def plan_buckets(writes, n_active, n_buckets):
         return []
     ws = sorted(writes, key=lambda w: -w[0])
     total = sum(hi - lo for lo, hi, _ in ws)
-    target = total / float(max(1, n_buckets))
-    out, acc, ready, hi_edge = [], 0, -1, n_active
+    # the LAST bucket (final only when the backward ends: nothing left to hide its exchange behind) is kept small -- the arena's leading
+    # tensors up to 1 % of the parameters -- and the others share the rest equally
+    tail = 0
+    if n_buckets > 2:
+        for lo, hi, _ in reversed(ws):
+            if tail + (hi - lo) > total // 100:
+                break
+            tail += hi - lo
+    nbig = n_buckets - (1 if tail > 0 else 0)
+    target = (total - tail) / float(max(1, nbig))
+    out, acc, ready, hi_edge, left = [], 0, -1, n_active, total
     for i, (lo, hi, r) in enumerate(ws):
         acc += hi - lo
+        left -= hi - lo
         ready = max(ready, r)
         last = i == len(ws) - 1
-        if last or (acc >= target and len(out) < n_buckets - 1):
+        cut_tail = tail > 0 and left == tail
+        if last or cut_tail or (acc >= target and len(out) < nbig - 1):
             edge = 0 if last else lo
             out.append([edge, hi_edge, ready])
             hi_edge, acc = edge, 0

@@ -158,6 +158,16 @@ def test_gradient_bucket_planner(amd):
         assert ready >= max(r for (wlo, whi, r) in writes if lo <= wlo < hi)    # nothing is reduced before it is final
     assert plan_buckets(writes, 1000, 1) == [(0, 1000, 50)]
     assert len(plan_buckets(writes, 1000, 16)) <= 6
+    # the last bucket -- final only when the backward ends -- is the small one: ResNet18-like sizes (stem + layer1 = 1 % of the arena)
+    sizes = [1728, 74000, 74000, 520000, 2100000, 8400000, 2100000, 1050000, 1050000, 14000]
+    w2, lo = [], 0
+    for i, n in enumerate(sizes):
+        w2.append((lo, lo + n, 100 - 10 * i))
+        lo += n
+    b4 = plan_buckets(w2, lo, 4)
+    assert 3 <= len(b4) <= 4 and b4[-1] == (0, 1728 + 74000 + 74000, 100) and b4[0][1] == lo
+    assert all(x[0] == y[1] for x, y in zip(b4, b4[1:])) and [r for _, _, r in b4] == sorted(r for _, _, r in b4)
+    assert (b4[-1][1] - b4[-1][0]) <= lo // 100
 
 
 def test_entry_point_overrides_and_dataset_lookup(tmp_path):
