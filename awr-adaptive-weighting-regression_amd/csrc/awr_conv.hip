@@ -154,40 +154,68 @@ __device__ __forceinline__ void mfma_split16(const bf16x8 (&fa)[TM][3], const bf
 // for accumulator tile (i, j): four 16-byte requests through a buffer resource whose out-of-range offset (ragged rows, padded columns)
 // returns zeros.  EPRE launches issue tile (0, 0)'s BEFORE the K loop and every later tile's right after the previous tile has been consumed.
 struct epi_rows { float4 v[4]; };
-template <int TM, int TN>
-__device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const awr_phase& ph, int M, int tile_m, int tile_n, int i, int j, epi_rows& R) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, c4 = lane & 7, rbase = lane >> 3;
-    const float* const one = a.res ? a.res : a.bnr_y;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));      // < 4 GB (checked at launch)
-    const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 u;
+    __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 0);      // buffer_store_dwordx4 ... offen: an out-of-range offset is dropped
+}
+// Byte offset of (row m of the GEMM, column 0) in the output tensor, OOB for rows beyond M.  Everything the epilogue reads or writes sits at
+// that offset + 4 n in tensors of the output's shape (< 4 GB): one 32-bit add per access instead of a 64-bit multiply-add, no branch
+// around ragged rows -- the epilogue's integer arithmetic was ~1 100 VALU instructions per wave (profiles/r03_pmc_1x1.txt), a third of a
+// four-slice launch's issue cycles.
+template <int TM>
+__device__ __forceinline__ void epi_row_offsets(const awr_conv_args& a, const awr_phase& ph, int M, int tile_m, unsigned (&orow)[TM][4]) {
+    constexpr int BM = 64 * TM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, rbase = lane >> 3;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int m = tile_m * BM + wm * 32 * TM + i * 32 + rbase + 8 * q;
-        unsigned off = OOB;
-        if (m < M && n0 < a.N) {
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = tile_m * BM + wm * 32 * TM + i * 32 + rbase + 8 * q;
             int opix = m;
             if (a.so != 1) {
                 const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
                 opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
             }
-            off = ((unsigned)opix * (unsigned)a.N + (unsigned)n0) * 4u;
+            orow[i][q] = m < M ? (unsigned)opix * (unsigned)a.N * 4u : OOB;
         }
-        R.v[q] = buf_ld4(rs, off);
-    }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const unsigned (&orow)[TM][4], int tile_n, int i, int j, epi_rows& R) {
+    constexpr int BN = 64 * TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave & 1, c4 = lane & 7;
+    const float* const one = a.res ? a.res : a.bnr_y;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));      // < 4 GB (checked at launch)
+    const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R.v[q] = buf_ld4(rs, (n0 < a.N && orow[i][q] != OOB) ? orow[i][q] + (unsigned)n0 * 4u : OOB);
 }
 
 template <int TM, int TN, bool EPRE = false>
 __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
-                                              int tile_m, int tile_n, epi_rows* pre = nullptr) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+                                              int tile_m, int tile_n, epi_rows* pre = nullptr, const unsigned (*orow_in)[4] = nullptr) {
+    constexpr int BN = 64 * TN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const bool direct = (a.so == 1);   // out pixel index == m
     __syncthreads();                    // every wave is done with the staged slices
     float* tbuf = smem + wave * (32 * LDK);
     const int c4 = lane & 7, rbase = lane >> 3;
+    unsigned orow[TM][4];
+    if (orow_in) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) orow[i][q] = orow_in[i][q];
+    } else {
+        epi_row_offsets<TM>(a, ph, M, tile_m, orow);
+    }
+    const unsigned obytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u);      // < 4 GB (checked at launch)
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out, obytes), rs_res = make_rsrc(a.res ? a.res : a.out, a.res ? obytes : 0u),
+                                 rs_y = make_rsrc(a.bnr_y ? a.bnr_y : a.out, a.bnr_y ? obytes : 0u),
+                                 rs_act = make_rsrc(a.bnr_act ? a.bnr_act : a.out, a.bnr_act ? obytes : 0u),
+                                 rs_y2 = make_rsrc(a.bnr2_y ? a.bnr2_y : a.out, a.bnr2_y ? obytes : 0u);
     // BatchNorm statistics (sum x, sum x^2) are accumulated SHIFTED by the first row of the wave's tile, c: a channel that is
     // almost constant (std << |mean|: dead or saturated channels, constant image background) would otherwise lose its variance to
     // the rounding of x^2 -- every term rounds the same way, the error does not average out -- and 1/sqrt(var + eps) amplifies
@@ -200,6 +228,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     for (int j = 0; j < TN; ++j) {
         const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
         const bool nok = n0 < a.N;                                        // N % 4 == 0: the whole float4 is in or out
+        const unsigned colb = (unsigned)n0 * 4u;
         const float4 z4 = make_float4(0, 0, 0, 0), o4 = make_float4(1, 1, 1, 1);
         const float4 bias = (a.bias && nok) ? ld4(a.bias + n0) : z4;
         const float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
@@ -222,60 +251,51 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
             for (int q = 0; q < 4; ++q) {
                 const int row = rbase + 8 * q;
                 float4 v = ld4(tbuf + row * LDK + 4 * c4);
-                const int m = tile_m * BM + wm * 32 * TM + i * 32 + row;
-                const bool valid = m < M && nok;
-                size_t o = 0;
-                if (valid) {
-                    int opix = m;
-                    if (!direct) {
-                        const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
-                        opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
-                    }
-                    o = (size_t)opix * a.N + n0;
-                    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-                    if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-                    if (a.res) {
-                        const float4 rr = EPRE ? pre->v[q] : ld4(a.res + o);
-                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                    }
+                const bool valid = nok && orow[i][q] != OOB;
+                const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
+                if (a.res) {
+                    const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (shifted && i == 0 && q == 0) {      // (wave-uniform) the shift: row 0 of the wave's tile, held by lanes 0..7
                     const float4 t = valid ? v : z4;
                     cshift.x = __shfl(t.x, c4, 64); cshift.y = __shfl(t.y, c4, 64); cshift.z = __shfl(t.z, c4, 64); cshift.w = __shfl(t.w, c4, 64);
                 }
-                if (valid) {
-                    if (a.bnr_y) {
-                        // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
-                        const float4 yy = EPRE ? pre->v[q] : ld4(a.bnr_y + o);
-                        if (a.bnr_act) {      // the activation had a residual added before the ReLU: mask from the stored tensor
-                            const float4 aa = ld4(a.bnr_act + o);
-                            v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
-                        } else {
-                            v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
-                            v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
-                        }
-                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                        s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
-                        s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
-                        if (a.bnr2_y) {
-                            const float4 y2 = ld4(a.bnr2_y + o);
-                            s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
-                            s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
-                        }
+                if (a.bnr_y) {
+                    // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
+                    const float4 yy = EPRE ? pre->v[q] : buf_ld4(rs_y, off);
+                    if (a.bnr_act) {      // the activation had a residual added before the ReLU: mask from the stored tensor
+                        const float4 aa = buf_ld4(rs_act, off);
+                        v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
                     } else {
-                        const float4 d = make_float4(v.x - cshift.x, v.y - cshift.y, v.z - cshift.z, v.w - cshift.w);
-                        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
-                        s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
-                        ++cnt;
+                        v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
+                        v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
                     }
-                    if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    st4(a.out + o, v);
+                    if (!valid) v = z4;      // ragged rows / padded columns contribute nothing to the sums
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
+                    s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
+                    if (a.bnr2_y) {
+                        const float4 y2 = buf_ld4(rs_y2, off);
+                        s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
+                        s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
+                    }
+                } else if (a.stats) {
+                    const float vm = valid ? 1.f : 0.f;
+                    const float4 d = make_float4((v.x - cshift.x) * vm, (v.y - cshift.y) * vm, (v.z - cshift.z) * vm, (v.w - cshift.w) * vm);
+                    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                    s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+                    cnt += valid ? 1 : 0;
                 }
+                if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                buf_st4(rs_out, off, v);
             }
             __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
             if constexpr (EPRE) {                  // the next tile's rows, in flight across its LDS bounce
-                if (i + 1 < TM) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, i + 1, j, *pre);
-                else if (j + 1 < TN) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, 0, j + 1, *pre);
+                if (i + 1 < TM) epi_fetch<TM, TN>(a, orow, tile_n, i + 1, j, *pre);
+                else if (j + 1 < TN) epi_fetch<TM, TN>(a, orow, tile_n, 0, j + 1, *pre);
             }
         }
         cs1[j] = s1;
@@ -589,7 +609,11 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
     }
     set_tap(0);
     epi_rows epre;
-    if constexpr (EPRE) epi_fetch<TM, TN>(a, ph, M, tile_m, tile_n, 0, 0, epre);      // lands while the K loop runs
+    unsigned eoff[EPRE ? TM : 1][4];
+    if constexpr (EPRE) {
+        epi_row_offsets<TM>(a, ph, M, tile_m, eoff);
+        epi_fetch<TM, TN>(a, eoff, tile_n, 0, 0, epre);      // lands while the K loop runs
+    }
     if constexpr (NP == 0) {
         load_slice(0);
         store_slice();
@@ -838,7 +862,7 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
         }
         return;
     }
-    if constexpr (EPRE) gemm_epilogue<TM, TN, true>(a, ph, acc, smem, M, tile_m, tile_n, &epre);
+    if constexpr (EPRE) gemm_epilogue<TM, TN, true>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
     else gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
 }
 
