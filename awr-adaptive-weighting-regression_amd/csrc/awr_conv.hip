@@ -153,6 +153,22 @@ __device__ __forceinline__ void mfma_split16(const bf16x8 (&fa)[TM][3], const bf
 // The rows of the ONE operand tensor an epilogue reads (a residual, or the y of a fused BatchNorm-backward reduction) that this lane needs
 // for accumulator tile (i, j): four 16-byte requests through a buffer resource whose out-of-range offset (ragged rows, padded columns)
 // returns zeros.  EPRE launches issue tile (0, 0)'s BEFORE the K loop and every later tile's right after the previous tile has been consumed.
+// GEMM row m -> (qx, qy, image): shifts and masks when both map sides are powers of two (every reference map is), else two integer
+// divisions -- ~25 VALU instructions each, per staged row in the prologue and per row in a strided epilogue
+__device__ __forceinline__ void decode_row(const awr_conv_args& a, int m, int& qx, int& qy, int& b) {
+    if (((a.Wq & (a.Wq - 1)) | (a.Hq & (a.Hq - 1))) == 0) {      // (uniform)
+        const int ws = __builtin_ctz(a.Wq), hs = __builtin_ctz(a.Hq);
+        qx = m & (a.Wq - 1);
+        const int t = m >> ws;
+        qy = t & (a.Hq - 1);
+        b = t >> hs;
+    } else {
+        qx = m % a.Wq;
+        const int t = m / a.Wq;
+        qy = t % a.Hq;
+        b = t / a.Hq;
+    }
+}
 struct epi_rows { float4 v[4]; };
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -175,7 +191,8 @@ __device__ __forceinline__ void epi_row_offsets(const awr_conv_args& a, const aw
             const int m = tile_m * BM + wm * 32 * TM + i * 32 + rbase + 8 * q;
             int opix = m;
             if (a.so != 1) {
-                const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+                int qx, qy, b;
+                decode_row(a, m, qx, qy, b);
                 opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
             }
             orow[i][q] = m < M ? (unsigned)opix * (unsigned)a.N * 4u : OOB;
@@ -253,7 +270,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 float4 v = ld4(tbuf + row * LDK + 4 * c4);
                 const bool valid = nok && orow[i][q] != OOB;
                 const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                if (a.bias) { v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w; }
                 if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                 if (a.res) {
                     const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off);
@@ -429,7 +446,8 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
     for (int i = 0; i < RA; ++i) {
         const int m = tile_m * BM + r0 + 32 * i;
         if (m < M) {
-            const int qx = m % a.Wq, t = m / a.Wq, qy = t % a.Hq, b = t / a.Hq;
+            int qx, qy, b;
+            decode_row(a, m, qx, qy, b);
             a_iy[i] = qy * a.si;
             a_ix[i] = qx * a.si;
             a_img[i] = (unsigned)b * a.Hin * a.Win;

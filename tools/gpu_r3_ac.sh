@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 PREV=$GRAFT_REPO_ROOT/awr-adaptive-weighting-regression_amd/lib/libawr_prev.so
 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -2
-python -m pytest tests/test_nets_gpu.py tests/test_full_size_gpu.py -m gpu -q --tb=short -x -k "yardstick or golden or config" 2>&1 | grep -v "^E        +" | tail -2
+python -m pytest tests/test_nets_gpu.py tests/test_full_size_gpu.py -m gpu -q --tb=short -x -k "golden" 2>&1 | grep -v "^E        +" | tail -2
 echo "== new"; python tools/microbench_1x1_epilogue.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
 echo "== prev"; AWR_LIB_PATH=$PREV python tools/microbench_1x1_epilogue.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
 C="--no-cpu-baseline --no-split-mode --no-extras --no-b256 --no-parity"
