@@ -968,24 +968,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
     const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
     unsigned d_ok = 0, g_ok = 0;     // staged rows that hold real data (a fused affine must not touch padding / tail rows)
+    // `fast` (uniform; hshift >= 64 encodes it): power-of-two D and G maps and fewer than 2^24 pixels in either tensor -- every reference
+    // layer.  The per-slice address arithmetic then has no 32-bit multiply (v_mul_lo_u32 is a quarter-rate instruction: the 14 of them per
+    // slice were half of the ~100 VALU instructions a wave issued per 16 MFMAs, profiles/r03_pmc_wgrad.txt): shifts for the map strides,
+    // 24-bit multiplies (full rate) by the channel pitches.
+    const bool fast = hshift >= 64;
+    const int hsh = hshift & 63, gws = (hshift >> 8) & 63, ghs = (hshift >> 16) & 63, sgs = a.sg - 1;      // log2(Hd), log2(Wg), log2(Hg); sg in {1, 2}
+    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
     auto load_slice = [&](int m0) {
         d_ok = g_ok = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = m0 + da_r + PM * i;
             const bool ok = m < m_end && d_cok;
-            rd[i] = buf_ld4(rs_d, ok ? (unsigned)m * a.Cd * 4u + d_col : OOB);
+            rd[i] = buf_ld4(rs_d, ok ? (fast ? __umul24((unsigned)m, dpitch) : (unsigned)m * dpitch) + d_col : OOB);
             d_ok |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int m = m0 + ga_r + PN * i;
+            if (fast) {
+                const int x = m & (a.Wd - 1), tt = m >> wshift, y = tt & (a.Hd - 1), b = tt >> hsh;
+                const int gy = (y << sgs) + dy, gx = (x << sgs) + dx;
+                const bool ok = m < m_end && g_cok && (unsigned)gy < (unsigned)a.Hg && (unsigned)gx < (unsigned)a.Wg;
+                const unsigned pix = (unsigned)((((b << ghs) + gy) << gws) + gx);
+                rg[i] = buf_ld4(rs_g, ok ? __umul24(pix, gpitch) + g_col : OOB);
+                g_ok |= ok ? (1u << i) : 0u;
+                continue;
+            }
             int x, y, b;
             if (wshift >= 0) {      // power-of-two feature maps (every layer of both backbones): no integer division per slice
                 x = m & (a.Wd - 1);
                 const int tt = m >> wshift;
                 y = tt & (a.Hd - 1);
-                b = tt >> hshift;
+                b = tt >> (hshift & 63);
             } else {
                 x = m % a.Wd;
                 const int tt = m / a.Wd;
@@ -1718,10 +1734,20 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     int wshift = log2i(a->Wd), hshift = log2i(a->Hd);
     if (wshift < 0 || hshift < 0) wshift = hshift = -1;
+    // FP32 kernel: multiply-free slice addressing when G's map sides are powers of two as well and both tensors hold < 2^24 pixels
+    // (packed into the hshift argument: bits 0-5 log2 Hd, bit 6 the flag, bits 8-13 log2 Wg, bits 16-21 log2 Hg)
+    int hshift_f32 = hshift;
+    {
+        const int gws = log2i(a->Wg), ghs = log2i(a->Hg);
+        static const bool no_fast = getenv("AWR_WGRAD_SLOW_ADDR") != nullptr;      // same-box A/B hook
+        if (!no_fast && wshift >= 0 && gws >= 0 && ghs >= 0 && (a->sg == 1 || a->sg == 2) && (int64_t)a->B * a->Hd * a->Wd < (1 << 24) &&
+            (int64_t)a->B * a->Hg * a->Wg < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24))
+            hshift_f32 = hshift | 64 | (gws << 8) | (ghs << 16);
+    }
 #define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
     do {                                                                                                                                  \
         if (g_products == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);                                \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32);                            \
     } while (0)
     if (TM == 2 && TN == 2) AWR_LAUNCH_WGRAD(2, 2);
     else if (TM == 2 && TN == 1) AWR_LAUNCH_WGRAD(2, 1);
