@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // R[cd][t][cg] += sum_{m in K-chunk} D[m][cd] * G[gather(m,t)][cg]      (split-K over pixels)
 // ------------------------------------------------------------------------------------------
-template <int TM, int TN>
+template <int TM, int TN, bool FAST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int BK = WBK;        // pixels per K-slice (shadows the channel-slice constant of the forward kernel)
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     // layer.  The per-slice address arithmetic then has no 32-bit multiply (v_mul_lo_u32 is a quarter-rate instruction: the 14 of them per
     // slice were half of the ~100 VALU instructions a wave issued per 16 MFMAs, profiles/r03_pmc_wgrad.txt): shifts for the map strides,
     // 24-bit multiplies (full rate) by the channel pitches.
-    const bool fast = hshift >= 64;
+    constexpr bool fast = FAST;      // (a compile-time variant: the general path's code and registers stay out of the loop)
     const int hsh = hshift & 63, gws = (hshift >> 8) & 63, ghs = (hshift >> 16) & 63, sgs = a.sg - 1;      // log2(Hd), log2(Wg), log2(Hg); sg in {1, 2}
     const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
     auto load_slice = [&](int m0) {
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int m = m0 + ga_r + PN * i;
-            if (fast) {
+            if constexpr (fast) {
                 const int x = m & (a.Wd - 1), tt = m >> wshift, y = tt & (a.Hd - 1), b = tt >> hsh;
                 const int gy = (y << sgs) + dy, gx = (x << sgs) + dx;
                 const bool ok = m < m_end && g_cok && (unsigned)gy < (unsigned)a.Hg && (unsigned)gx < (unsigned)a.Wg;
@@ -996,8 +996,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 g_ok |= ok ? (1u << i) : 0u;
                 continue;
             }
-            int x, y, b;
-            if (wshift >= 0) {      // power-of-two feature maps (every layer of both backbones): no integer division per slice
+            int x = 0, y = 0, b = 0;
+            if constexpr (fast) {
+            } else if (wshift >= 0) {      // power-of-two feature maps (every layer of both backbones): no integer division per slice
                 x = m & (a.Wd - 1);
                 const int tt = m >> wshift;
                 y = tt & (a.Hd - 1);
@@ -1747,6 +1748,7 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
 #define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
     do {                                                                                                                                  \
         if (g_products == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
+        else if (hshift_f32 >= 64) hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn, true>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32); \
         else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32);                            \
     } while (0)
     if (TM == 2 && TN == 2) AWR_LAUNCH_WGRAD(2, 2);
