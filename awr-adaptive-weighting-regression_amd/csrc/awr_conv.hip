@@ -212,7 +212,10 @@ __device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const unsigned
     for (int q = 0; q < 4; ++q) R.v[q] = buf_ld4(rs, (n0 < a.N && orow[i][q] != OOB) ? orow[i][q] + (unsigned)n0 * 4u : OOB);
 }
 
-template <int TM, int TN, bool EPRE = false>
+// EM (compile-time epilogue variant; run-time-uniform feature flags make the compiler keep every path's registers alive): 0 = every feature
+// behind its run-time flag, 1 = PLAIN (bias / affine / residual / ReLU only), 2 = STATS (the next BatchNorm's sum, sum of squares),
+// 3 = BNR (fused BatchNorm-backward reduction; bnr_act / bnr2_y stay run-time flags).  The launcher picks the variant from the same flags.
+template <int TM, int TN, bool EPRE = false, int EM = 0>
 __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
                                               int tile_m, int tile_n, epi_rows* pre = nullptr, const unsigned (*orow_in)[4] = nullptr) {
     constexpr int BN = 64 * TN;
@@ -220,6 +223,8 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
     __syncthreads();                    // every wave is done with the staged slices
+    const bool stats_on = (EM == 0 || EM == 2 || EM == 3) && a.stats != nullptr, bnr_on = (EM == 0 || EM == 3) && a.bnr_y != nullptr;
+    const bool act_on = bnr_on && a.bnr_act != nullptr, bnr2_on = bnr_on && a.bnr2_y != nullptr, stats2_on = bnr_on && a.stats2 != nullptr;
     float* tbuf = smem + wave * (32 * LDK);
     const int c4 = lane & 7, rbase = lane >> 3;
     unsigned orow[TM][4];
@@ -241,7 +246,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     // the rounding of x^2 -- every term rounds the same way, the error does not average out -- and 1/sqrt(var + eps) amplifies
     // that into the normalised activations and the gradients.  x - c is exact for nearly equal values; the sums return to the
     // unshifted form in fp64 once per wave: sum x = s1 + n c, sum x^2 = s2 + 2 c s1 + n c^2.
-    const bool shifted = a.stats && !a.bnr_y;
+    const bool shifted = stats_on && !bnr_on;
     float4 cs1[TN], cs2[TN], cs3[TN], csh[TN];      // cs3: sum g * xhat of a second BatchNorm sharing the masked gradient (a.bnr2_y)
     int ccnt[TN];
 #pragma unroll
@@ -261,10 +266,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         }
         float4 ksc = o4, ksh = z4, kmu = z4, kis = o4;       // fused BatchNorm-backward reduction coefficients
         float4 kmu2 = z4, kis2 = o4;
-        if (a.bnr_y && nok) {
+        if (bnr_on && nok) {
             ksc = ld4(a.bnr_coef + n0); ksh = ld4(a.bnr_coef + a.N + n0);
             kmu = ld4(a.bnr_coef + 2 * a.N + n0); kis = ld4(a.bnr_coef + 3 * a.N + n0);
-            if (a.bnr2_y) { kmu2 = ld4(a.bnr2_coef + 2 * a.N + n0); kis2 = ld4(a.bnr2_coef + 3 * a.N + n0); }
+            if (bnr2_on) { kmu2 = ld4(a.bnr2_coef + 2 * a.N + n0); kis2 = ld4(a.bnr2_coef + 3 * a.N + n0); }
         }
         float4 s1 = z4, s2 = z4, s3 = z4, cshift = z4;
         int cnt = 0;
@@ -288,10 +293,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     const float4 t = valid ? v : z4;
                     cshift.x = __shfl(t.x, c4, 64); cshift.y = __shfl(t.y, c4, 64); cshift.z = __shfl(t.z, c4, 64); cshift.w = __shfl(t.w, c4, 64);
                 }
-                if (a.bnr_y) {
+                if (bnr_on) {
                     // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
                     const float4 yy = EPRE ? pre->v[q] : buf_ld4(rs_y, off);
-                    if (a.bnr_act) {      // the activation had a residual added before the ReLU: mask from the stored tensor
+                    if (act_on) {      // the activation had a residual added before the ReLU: mask from the stored tensor
                         const float4 aa = buf_ld4(rs_act, off);
                         v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
                     } else {
@@ -302,12 +307,12 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                     s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                     s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
-                    if (a.bnr2_y) {
+                    if (bnr2_on) {
                         const float4 y2 = buf_ld4(rs_y2, off);
                         s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
                         s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
                     }
-                } else if (a.stats) {
+                } else if (stats_on) {
                     const float vm = valid ? 1.f : 0.f;
                     const float4 d = make_float4((v.x - cshift.x) * vm, (v.y - cshift.y) * vm, (v.z - cshift.z) * vm, (v.w - cshift.w) * vm);
                     s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
@@ -329,7 +334,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         csh[j] = cshift;
         ccnt[j] = cnt;
     }
-    if (a.stats) {
+    if (stats_on) {
         // Lanes with equal (lane & 7) hold partial sums of the same 4 columns: fold lane bits 3..5 (all lanes of a wave share the
         // shift, so the shifted fp32 sums combine in one basis), leave the shifted form in fp64, combine the two M-waves of the
         // workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands
@@ -348,7 +353,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 for (int e = 0; e < 4; ++e) {
                     p1[e] += __shfl_xor(p1[e], o, 64);
                     p2[e] += __shfl_xor(p2[e], o, 64);
-                    if (a.stats2) p3[e] += __shfl_xor(p3[e], o, 64);
+                    if (stats2_on) p3[e] += __shfl_xor(p3[e], o, 64);
                 }
                 cnt += __shfl_xor(cnt, o, 64);
             }
@@ -371,7 +376,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 for (int e = 0; e < 4; ++e) {
                     red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e] = d1[j][e];
                     red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e] = d2[j][e];
-                    if (a.stats2) red3[((wn * TN + j) * 8 + lane) * 4 + e] = d3[j][e];
+                    if (stats2_on) red3[((wn * TN + j) * 8 + lane) * 4 + e] = d3[j][e];
                 }
         }
         __syncthreads();
@@ -381,7 +386,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
             const unsigned nslots = a.stat_slots > 0 ? (unsigned)a.stat_slots : (unsigned)AWR_STAT_SLOTS;
             const size_t slot = (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
             double* st = a.stats + slot;
-            double* st2 = a.stats2 ? a.stats2 + slot : nullptr;
+            double* st2 = stats2_on ? a.stats2 + slot : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
@@ -890,6 +895,247 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
     }
     if constexpr (EPRE) gemm_epilogue<TM, TN, true>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
     else gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA operand staging (round 4): `buffer_load_dwordx4 ... offen lds`
+// ------------------------------------------------------------------------------------------
+// The kernel above moves every operand global -> VGPR -> ds_write -> LDS: RA + RB float4 staging registers per thread and a store phase
+// between two barriers per K-slice.  Operands that need no arithmetic on the way in -- the packed weights always, the activation rows
+// whenever there is no fused input affine / ReLU (every materialised input: block inputs, all data-gradient inputs, the deconvs) -- can go
+// global -> LDS directly.  What the instruction dictates (MI355X_MICROARCH.md, probed by tools/probes/lds_dma_probe.hip):
+//   * the destination is wave-uniform base (M0) + 16 * lane: a wave instruction fills 1 KB of CONSECUTIVE LDS, so rows are unpadded
+//     (KB * 4 bytes) and the bank-conflict-free fragment reads come from an XOR swizzle of the 16-byte chunk index instead of the 36-float
+//     pitch: chunk c of row r sits at chunk c ^ swz(r), swz(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows (the sixteen
+//     lanes of a ds_read_b128 group then hit sixteen distinct 16-byte slots).  The swizzle goes on the SOURCE address (lane (row, c)
+//     fetches chunk c ^ swz(row)) and on the fragment READ, never on the destination;
+//   * the source offset is per lane and out-of-range offsets WRITE ZEROS: the OOB trick of the register path (padding taps, ragged rows)
+//     carries over unchanged;
+//   * completion is the issuing wave's vmcnt, visibility to the other waves the barrier behind it.
+// Pipeline: NBUF = 2 stages of KB floats of K in LDS; stage k + 1 is requested before the MFMAs of stage k and awaited behind them, ONE
+// barrier per stage, no LDS store phase, no staging registers.  KB = 32 doubles the LDS of a workgroup (64x128: 48 KB, three workgroups
+// per CU); KB = 16 keeps it (24 KB) with 64-byte rows.  AREG: the activation rows still travel through registers (fused input affine /
+// ReLU of a never-materialised BatchNorm) and are stored into the same swizzled image; the weights go by DMA.
+// The instruction is issued from inline assembly: through the builtin, hipcc (ROCm 7.2) cannot tell which LDS bytes a DMA in flight will
+// overwrite and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- i.e. right behind the request, the load latency fully exposed
+// (seen in the ISA of the first version).  From assembly the compiler does not count the request at all: dma_wait() before the barrier is
+// ours to place; its own counted waits for ordinary loads can only over-wait (vmcnt retires in order).  M0 (the LDS base) is written in the
+// same statement that reads it and restored afterwards (cdna_hip_programming.md: M0 is compiler-reserved).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* p, unsigned bytes) {      // the same descriptor as make_rsrc, as four SGPR words
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    i32x4 r;
+    r.x = (int)(unsigned)u;
+    r.y = (int)((unsigned)(u >> 32) & 0xFFFFu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_uniform, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)reinterpret_cast<unsigned long long>(p);      // a generic pointer into LDS: aperture in the high word, LDS byte offset in the low one
+}
+template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0>
+__device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
+    static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
+    constexpr int LPR = KB / 4;                   // 16-byte chunks (= staging lanes) per row
+    constexpr int RPP = 256 / LPR;                // rows covered by one pass of the 256 threads (32 | 64); one pass = 4 KB of LDS
+    constexpr int RA = BM / RPP, RB = BN / RPP;   // DMA instructions (AREG: float4 registers) per thread and stage
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int EPI = 4 * 32 * LDK * 4;         // the epilogue's four 32x36 transpose tiles
+    static_assert(RA >= 1 && RB >= 1, "tile too small for the stage shape");
+    __shared__ __attribute__((aligned(16))) char smem_raw[NBUF * STAGE > EPI ? NBUF * STAGE : EPI];
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+
+    const awr_phase& ph = a.ph[blockIdx.y];
+    const int M = a.B * a.Hq * a.Wq;
+    const int tilesN = (a.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // staging role: row r0 (+ RPP per pass) of the tile, LDS chunk cl of that row, which holds SOURCE chunk cl ^ swz(row)
+    const int r0 = tid / LPR, cl = tid % LPR;
+    const int kc = (cl ^ (KB == 32 ? (r0 >> 1) & 7 : (r0 >> 2) & 3)) * 4;      // this thread's 4 consecutive k inside the stage
+
+    int a_iy[RA], a_ix[RA];
+    unsigned a_img[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = tile_m * BM + r0 + RPP * i;
+        if (m < M) {
+            int qx, qy, b;
+            decode_row(a, m, qx, qy, b);
+            a_iy[i] = qy * a.si;
+            a_ix[i] = qx * a.si;
+            a_img[i] = (unsigned)b * a.Hin * a.Win;
+        } else {
+            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
+            a_ix[i] = 0;
+            a_img[i] = 0;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
+    const i32x4 rw_in = make_rsrc_words(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), rw_w = make_rsrc_words(a.w, OOB);
+    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;      // this wave's 1 KB piece of every 4 KB pass
+    unsigned w_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + RPP * i) * a.T * a.Cin + kc) * 4u;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cslices = a.Cin / KB;
+    const int ksteps = ph.ntaps * cslices;
+    unsigned a_off[RA], tapmask = 0, wtap = 0;
+    auto set_tap = [&](int tap) {
+        const int tp = ph.tap[tap];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
+        tapmask = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
+            tapmask |= ok ? (1u << i) : 0u;
+        }
+        wtap = (unsigned)wt * a.Cin * 4u;
+    };
+    float4 ra[AREG ? RA : 1];
+    unsigned okmask = 0;
+    int c0_staged = 0;
+    // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
+    auto issue = [&](int c0, int buf) {
+        const unsigned cb = (unsigned)c0 * 4u;
+        const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(BM * ROWB);
+        if constexpr (AREG) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+            okmask = tapmask;
+            c0_staged = c0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) dma16(rw_w, Bs + i * 4096u, w_off[i] + (wtap + cb));
+    };
+    // AREG: registers -> LDS with the fused input affine + ReLU (the previous BatchNorm); padding stays zero
+    auto commit = [&](int buf) {
+        if constexpr (AREG) {
+            if (a.in_scale) {
+                const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
+            } else if (a.relu_in) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    ra[i].x = relu1(ra[i].x); ra[i].y = relu1(ra[i].y); ra[i].z = relu1(ra[i].z); ra[i].w = relu1(ra[i].w);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16), ra[i]);
+        }
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    // fragment reads: lane (l31, half) wants chunk 2 s + half of its rows for sub-step s; physically chunk (2 s + half) ^ swz(l31)
+    // (the wave / tile row offsets are multiples of 32: they do not change swz)
+    const int fswz = KB == 32 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+    const char* const a_row = smem_raw + (wm * 32 * TM + l31) * ROWB;
+    const char* const b_row = smem_raw + BM * ROWB + (wn * 32 * TN + l31) * ROWB;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < KB / 8; ++s) {
+            const int fo = buf * STAGE + (((2 * s + half) ^ fswz) << 4);
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_row + fo + i * 32 * ROWB));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_row + fo + j * 32 * ROWB));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+        }
+    };
+    int tap = 0, c0 = 0;
+    auto advance = [&]() {
+        c0 += KB;
+        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
+    };
+
+    set_tap(0);
+    epi_rows epre;
+    unsigned eoff[EPRE ? TM : 1][4];
+    if constexpr (EPRE) {
+        epi_row_offsets<TM>(a, ph, M, tile_m, eoff);
+        epi_fetch<TM, TN>(a, eoff, tile_n, 0, 0, epre);      // lands while the K loop runs
+    }
+    // stage_done: everything this wave asked for has landed (its own vmcnt), then the barrier: every wave's pieces are visible and every
+    // wave is done reading the stage that is requested next.  The scheduling fence keeps the MFMAs of the stage in front of the wait.
+    auto stage_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait();
+        __syncthreads();
+    };
+    issue(0, 0);
+    commit(0);
+    stage_done();
+    if constexpr (NBUF == 2) {
+        // unrolled by two: the stage buffer is a compile-time constant in every LDS address
+        int ks = 0;
+        for (; ks + 2 <= ksteps; ks += 2) {
+            advance(); issue(c0, 1);      // (ks + 1 < ksteps holds here)
+            compute(0);
+            commit(1);
+            stage_done();
+            const bool more = ks + 2 < ksteps;
+            if (more) { advance(); issue(c0, 0); }
+            compute(1);
+            if (more) {
+                commit(0);
+                stage_done();
+            }
+        }
+        if (ks < ksteps) compute(0);      // odd stage count: the last stage sits in buffer 0
+    } else {
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool more = ks + 1 < ksteps;
+            compute(0);
+            if (more) {
+                __syncthreads();
+                advance();
+                issue(c0, 0);
+                commit(0);
+                stage_done();
+            }
+        }
+    }
+    if constexpr (EPRE) gemm_epilogue<TM, TN, true, EM>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
+    else gemm_epilogue<TM, TN, false, EM>(a, ph, acc, smem, M, tile_m, tile_n);
+}
+template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
+    conv_gemm_dma_body<TM, TN, KB, NBUF, AREG, EPRE, EM>(a);
 }
 
 // amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
@@ -1505,7 +1751,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a && a->in && a->w && a->out, "conv_gemm: null pointer");
     const int64_t in_img = (int64_t)a->Hin * a->Win * a->Cin, out_img = (int64_t)a->Hout * a->Wout * a->N;
     int nchunk = 1;
-    while ((in_img * (a->B / nchunk) * 4 >= (1LL << 32) || out_img * (a->B / nchunk) >= (1LL << 31)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    while ((in_img * (a->B / nchunk) * 4 >= (1LL << 32) || out_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
     if (nchunk == 1) return conv_gemm_one(a, stream);
     for (int c = 0; c < nchunk; ++c) {
         awr_conv_args b = *a;
@@ -1551,7 +1797,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
                         !a->partial && a->split_k <= 1 && a->N1x >= 0 && a->N1x % BK == 0 && (a->N1x == 0) == (a->in2 == nullptr) && !(a->N1x && a->res),
                     "conv_gemm: the fused pair (w2) needs the FP32-MFMA mode, 64 or 128 intermediate channels, N == 2 N1, a stride-1 output, "
                     "no stats / bnr_y / split-K, and either a residual or a second input (N1=%d, N=%d, N1x=%d)", a->N1, a->N, a->N1x);
-        AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) &&
+        AWR_REQUIRE((int64_t)a->B * a->Hout * a->Wout * a->N * 4 < (1LL << 32) && (int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) &&
                         M * (int64_t)a->N1x * 4 < (1LL << 32),
                     "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
         const dim3 grid2((unsigned)((M + (a->N1 == 64 && a->tile_m == 2 ? 127 : 63)) / (a->N1 == 64 && a->tile_m == 2 ? 128 : 64)), 1);
@@ -1560,7 +1806,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
         return check_launch("conv_gemm_kernel<fused pair>");
     }
-    AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N < (1LL << 31),
+    AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 4 < (1LL << 32) && (int64_t)a->B * a->Hout * a->Wout * a->N * 4 < (1LL << 32),
                 "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
     // Tile choice (measured, tools/microbench_gemm.py): 64-row tiles win on every ResNet18/Hourglass layer shape --
     // 3-4 workgroups per CU de-synchronise prologue/epilogue bubbles that two lock-stepped 128x128 workgroups
@@ -1619,6 +1865,35 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
         else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)
+    // LDS-DMA staging (conv_gemm_dma_body): AWR_DMA = 0 off, 1 = 32-float stages x 2, 2 = 16-float stages x 2, 3 = 32-float stage x 1
+    static const int dma_mode = []() { const char* e = getenv("AWR_DMA"); return e ? atoi(e) : 0; }();
+    if (dma_mode && g_products == 1 && !a->in2 && !epre) {
+#define AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, em)                                                                                      \
+    do {                                                                                                                           \
+        if (aff) hipLaunchKernelGGL((conv_gemm_dma_kernel<tm, tn, kb, nbuf, true, false, em>), grid, dim3(256), 0, st, *a);        \
+        else hipLaunchKernelGGL((conv_gemm_dma_kernel<tm, tn, kb, nbuf, false, false, em>), grid, dim3(256), 0, st, *a);           \
+    } while (0)
+#define AWR_LAUNCH_DMA2(tm, tn, kb, nbuf)                                                                                          \
+    do {                                                                                                                           \
+        if (a->bnr_y) AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 3);                                                                        \
+        else if (a->stats) AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 2);                                                                   \
+        else AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 1);                                                                                 \
+    } while (0)
+#define AWR_LAUNCH_DMA(tm, tn)                                                                                                     \
+    do {                                                                                                                           \
+        if (dma_mode == 1) AWR_LAUNCH_DMA2(tm, tn, 32, 2);                                                                         \
+        else if (dma_mode == 2) AWR_LAUNCH_DMA2(tm, tn, 16, 2);                                                                    \
+        else AWR_LAUNCH_DMA2(tm, tn, 32, 1);                                                                                       \
+    } while (0)
+        if (TM == 2 && TN == 2) AWR_LAUNCH_DMA(2, 2);
+        else if (TM == 2 && TN == 1) AWR_LAUNCH_DMA(2, 1);
+        else if (TM == 1 && TN == 2) AWR_LAUNCH_DMA(1, 2);
+        else AWR_LAUNCH_DMA(1, 1);
+#undef AWR_LAUNCH_DMA
+#undef AWR_LAUNCH_DMA2
+#undef AWR_LAUNCH_DMA3
+        return check_launch("conv_gemm_dma_kernel");
+    }
     static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
     if (TM == 1 && TN == 1 && occ6 && g_products == 1 && !a->in2 && !epre) hipLaunchKernelGGL(conv_gemm_kernel_11_occ6, grid, dim3(256), 0, st, *a);
     else if (TM == 2 && TN == 2) AWR_LAUNCH_GEMM(2, 2);

@@ -188,6 +188,35 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
             "mfma_frac": round(flop_mult * 2 * macs / (el / steps) / 1e12 / peak_tf, 4)}
 
 
+def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, peak_tf, workload):
+    """Sub-record for one more single-GPU BASELINE training shape (same protocol as the headline: inputs resident in HBM, `warmup` untimed
+    steps, `steps` steps between two synchronisations, the FULL fused step -- GT map, forward, head, Huber, backward, Adam)."""
+    import time as _t
+    from awr_amd.trainer import TrainEngine
+    torch.manual_seed(0)
+    net = (awr_amd.get_deconv_net(18, J, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, J)).cuda()
+    eng = TrainEngine(net, batch, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False)
+    img, jt = O.synth_batch(batch, H, J, seed=977)
+    img, jt = img.to(dev), jt.to(dev)
+    eng.compile(img, jt)
+    for _ in range(warmup):
+        eng.step(img, jt)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        eng.step(img, jt)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / steps
+    macs = float(sum(eng.plan.macs.values()))
+    loss = float(eng.losses[2])
+    rec = {"workload": workload, "value": round(batch / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "plan_gb": round(eng.plan.bytes / 1e9, 1), "algorithmic_gflop_per_image": round(2e-9 * macs / batch, 3),
+           "step_mfma_frac": round(2.0 * macs / dt / 1e12 / peak_tf, 4), "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) < 1e30)}
+    del eng, net
+    torch.cuda.empty_cache()
+    return rec
+
+
 def _spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, exactly what torch.distributed.run would set), let rank 0 write the JSON line to our stdout, wait for all
@@ -268,6 +297,7 @@ def main():
     ap.add_argument("--per-layer", default="", help="write a per-GEMM-launch table (TFLOP/s per layer) to this file")
     ap.add_argument("--dp-selftest", action="store_true", help="data parallel: fail unless all replicas hold bitwise-identical parameters after the timed steps; "
                                                                "the per-bucket all-reduce timeline is reported either way when N > 1")
+    ap.add_argument("--no-hourglass-train", action="store_true", help="skip the Hourglass training sub-records 'hg1_train_b64' and 'config5'")
     ap.add_argument("--no-b256", action="store_true", help="skip the config-4 per-GPU shape (batch 256) sub-record")
     ap.add_argument("--deterministic", action="store_true", help="awr_amd.set_deterministic(True): bitwise-reproducible steps (no atomics on shared "
                                                                   "accumulators, no autotuning); reports what that costs")
@@ -506,6 +536,13 @@ def main():
             torch.cuda.empty_cache()
             out["forward"] = {"b%d" % b: measure_inference(awr_amd, O, "resnet_18", b, dev, rank, 30, 5, args.graph, peak_tf, flop_mult) for b in (64, 128)}
             out["config3"] = measure_inference(awr_amd, O, "hourglass_1", 128, dev, rank, 20, 5, args.graph, peak_tf, flop_mult)
+            if nprod == 1 and not args.no_hourglass_train:
+                # the two Hourglass TRAINING shapes: Hourglass-1 at the headline batch, and BASELINE configs[4]'s per-GPU
+                # shape (Hourglass-2, 256x256, 21 joints, 128 images: ~150 GB of plan buffers on one MI355X, ~0.3 s per step)
+                out["hg1_train_b64"] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
+                                                     "hourglass_1 NYU-shape 128x128 J=14 train step, batch 64")
+                out["config5"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 4, 2, peak_tf,
+                                               "hourglass_2 256x256 J=21 train step, batch 128/GPU = BASELINE configs[4] per-GPU shape")
         if world == 1 and nprod == 1 and not args.no_split_mode:
             # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)
             awr_amd.set_gemm_products(6)

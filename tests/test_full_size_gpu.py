@@ -107,3 +107,58 @@ def test_config1_resnet18_eval_batch4_split_k_path_vs_oracle(amd, dev):
     assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
     j64 = InferEngine(m, 64, 128, ks)(img.to(dev)).cpu()
     assert float((j64[:4] - j4).norm(dim=-1).max()) * 150.0 <= 1e-3
+
+
+def test_config5_hourglass2_256_j21_batch128(amd, dev):
+    """BASELINE configs[4] at its per-GPU size: Hourglass-2, 256x256 crops, 21 joints, 128 images -- the plan whose full-resolution maps
+    cross the 4 GB boundary of the kernels' 32-bit buffer offsets (`pre.1` writes 128 x 256 x 256 x 128 floats = exactly 2^32 bytes; the
+    conv launcher then walks the batch in chunks).  The oracle cannot run 128 such images in test time, so the batch is tied to it through
+    size-independent properties: (i) a TRAIN step on 16 copies of 8 images has the batch statistics of those 8 images, hence the loss, the
+    joints and the updated parameters of the 8-image step, whose loss the oracle's training-mode forward confirms; (ii) eval-mode images
+    are independent: the batch of 128 equals its 8-image slices."""
+    from awr_amd.trainer import InferEngine, TrainEngine
+    J, B, H, ks, small = 21, 128, 256, 0.4, 8
+    assert B * H * H * 128 * 4 >= 2 ** 32          # the 128-channel full-resolution map of `pre.1` (hourglass.py:111-113)
+    img8, jt8 = O.synth_batch(small, H, J, seed=305)
+    sd = O.reference_init_state("hourglass_2", J, seed=7)
+    # ---- the 8-image step, and the oracle's loss for it ----
+    m8 = _net(amd, "hourglass_2", J, sd)
+    e8 = TrainEngine(m8, small, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, autotune=False)
+    l8, j8 = e8.step(img8.to(dev), jt8.to(dev))
+    l8, j8 = float(l8[2]), j8.cpu()
+    with torch.no_grad():
+        pred = O.backbone_forward("hourglass_2", {k: v.clone() for k, v in sd.items()}, img8, training=True)[-1]
+        loss_ref = float(O.huber(pred, O.joint2offset(jt8, img8, ks, H // 2)))
+    assert abs(l8 - loss_ref) <= 2e-5 * abs(loss_ref), (l8, loss_ref)
+    sd8 = {k: v.cpu().clone() for k, v in m8.state_dict().items()}
+    del e8, m8
+    torch.cuda.empty_cache()
+    # ---- 128 images = 16 copies of the 8 ----
+    m = _net(amd, "hourglass_2", J, sd)
+    eng = TrainEngine(m, B, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, autotune=False)
+    assert eng.plan.bytes > 100e9 and eng.plan.bn_repeat == 2, eng.plan.bytes
+    losses, jt = eng.step(img8.repeat(B // small, 1, 1, 1).to(dev), jt8.repeat(B // small, 1, 1).to(dev))
+    lb, jt = float(losses[2]), jt.cpu()
+    assert np.isfinite(lb) and abs(lb - l8) <= 2e-5 * abs(l8), (lb, l8)
+    d = (jt.reshape(B // small, small, J, 3) - j8[None]).norm(dim=-1) * 150.0
+    assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
+    got = m.state_dict()
+    counters = [int(v) for k, v in got.items() if k.endswith("num_batches_tracked")]
+    assert len(counters) > 50 and all(c == 2 for c in counters)          # the fused two-stack step = two literal forwards (train.py:116-121)
+    for k in ("pre.0.bn.running_mean", "pre.1.bn2.running_var", "hgs.1.0.low1.bn3.running_var", "features.1.1.bn.running_mean"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), sd8[k].numpy(), rtol=2e-4, atol=2e-6)
+    # the mean gradient of 16 copies is the gradient of one copy: the bulk of the Adam-updated weights agrees tightly (elements whose gradient is
+    # rounding noise may land anywhere in +-lr)
+    diffs = torch.cat([(got[k].cpu() - sd8[k]).abs().reshape(-1) for k in ("pre.1.conv3.conv.weight", "hgs.0.0.up1.conv2.conv.weight", "outs_1.1.weight")])
+    assert float(torch.quantile(diffs[:2000000], 0.9)) <= 1e-4 and float(diffs.max()) <= 2.1e-3
+    del eng
+    torch.cuda.empty_cache()
+    # ---- eval: the batch of 128 against its slices ----
+    img, _ = O.synth_batch(B, H, J, seed=306)
+    m.eval()
+    jb = InferEngine(m, B, H, ks)(img.to(dev)).cpu()
+    assert bool(torch.isfinite(jb).all())
+    sm = InferEngine(m, small, H, ks)
+    for lo in (0, 56, 120):
+        js = sm(img[lo:lo + small].to(dev)).cpu()
+        assert float((js - jb[lo:lo + small]).norm(dim=-1).max()) * 150.0 <= 1e-3, lo

@@ -100,7 +100,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -114,6 +114,22 @@ def main():
             (n0, t0), (n1, t1) = pts[-2], pts[-1]
             b = (t1 - t0) / (n1 - n0)
             print("   -> per-slice %.2f us, fixed %.1f us  (= %.1f slices)" % (b * 1e6, (t1 - b * n1) * 1e6, (t1 - b * n1) / b))
+    elif args.mode == "fwdset":      # forward / data-gradient GEMM only, every tile, plain and with the BatchNorm statistics epilogue: the
+        B = args.batch                # same-box A/B of the staging variants (AWR_DMA=0..3, one process each; tools/gpu_r4_a.sh)
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8),
+                  ("deconv 512->256 @8", ops.ConvSpec("deconv", 512, 256, 4, 2, 1), 8), ("deconv 256->256 @16", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 16),
+                  ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32), ("head 1x1 256->64 @64", ops.ConvSpec("conv", 256, 64, 1, 1, 0), 64),
+                  ("hg 1x1 256->128 @64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 64), ("hg 1x1 128->256 @64", ops.ConvSpec("conv", 128, 256, 1, 1, 0), 64),
+                  ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64), ("hg 1x1 256->128 @16", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 16)]
+        print("AWR_DMA=%s batch %d: TF per tile, plain | with statistics epilogue" % (os.environ.get("AWR_DMA", "0"), B))
+        for name, spec, H in shapes:
+            res = []
+            for tile in ((1, 1), (2, 1), (1, 2), (2, 2)):
+                if spec.cout <= 64 and tile[1] == 2:
+                    continue
+                res.append("%s %5.1f|%5.1f" % (tile, run_fwd(spec, B, H, tile)[1], run_fwd(spec, B, H, tile, stats=True)[1]))
+            print("%-26s %s" % (name, "  ".join(res)), flush=True)
     elif args.mode == "tiles":       # forward only, every tile, a few representative layers (used by tools/probe_gemm.sh)
         B = args.batch
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16),
