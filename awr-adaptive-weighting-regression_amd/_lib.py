@@ -107,6 +107,8 @@ _SIGS = {
     "awr_set_gemm_products": ([_I], C.c_int),
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
     "awr_get_gemm_products": ([], C.c_int),
+    "awr_set_gemm_staging": ([_I], C.c_int),
+    "awr_get_gemm_staging": ([], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "awr_stem_stats": ([_P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
     "awr_stem_conv": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], C.c_int),

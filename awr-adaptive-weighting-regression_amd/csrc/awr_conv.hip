@@ -214,7 +214,8 @@ __device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const unsigned
 
 // EM (compile-time epilogue variant; run-time-uniform feature flags make the compiler keep every path's registers alive): 0 = every feature
 // behind its run-time flag, 1 = PLAIN (bias / affine / residual / ReLU only), 2 = STATS (the next BatchNorm's sum, sum of squares),
-// 3 = BNR (fused BatchNorm-backward reduction; bnr_act / bnr2_y stay run-time flags).  The launcher picks the variant from the same flags.
+// 3 = BNR (fused BatchNorm-backward reduction, nothing else), 4 = BNR with bnr_act / res / bnr2_y behind their run-time flags.  The launcher
+// picks the variant from the same flags.
 template <int TM, int TN, bool EPRE = false, int EM = 0>
 __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
                                               int tile_m, int tile_n, epi_rows* pre = nullptr, const unsigned (*orow_in)[4] = nullptr) {
@@ -223,8 +224,9 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
     __syncthreads();                    // every wave is done with the staged slices
-    const bool stats_on = (EM == 0 || EM == 2 || EM == 3) && a.stats != nullptr, bnr_on = (EM == 0 || EM == 3) && a.bnr_y != nullptr;
-    const bool act_on = bnr_on && a.bnr_act != nullptr, bnr2_on = bnr_on && a.bnr2_y != nullptr, stats2_on = bnr_on && a.stats2 != nullptr;
+    const bool stats_on = (EM == 0 || EM >= 2) && a.stats != nullptr, bnr_on = (EM == 0 || EM >= 3) && a.bnr_y != nullptr;
+    const bool act_on = EM != 3 && bnr_on && a.bnr_act != nullptr, bnr2_on = EM != 3 && bnr_on && a.bnr2_y != nullptr, stats2_on = EM != 3 && bnr_on && a.stats2 != nullptr;
+    const bool res_on = EM != 3 && a.res != nullptr;
     float* tbuf = smem + wave * (32 * LDK);
     const int c4 = lane & 7, rbase = lane >> 3;
     unsigned orow[TM][4];
@@ -285,7 +287,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 const bool valid = nok && orow[i][q] != OOB;
                 const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
                 v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w;
-                if (a.res) {
+                if (res_on) {
                     const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
@@ -942,7 +944,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)reinterpret_cast<unsigned long long>(p);      // a generic pointer into LDS: aperture in the high word, LDS byte offset in the low one
 }
-template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0>
+template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0, bool DUAL = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -984,8 +986,12 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
             a_img[i] = 0;
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u);
-    const i32x4 rw_in = make_rsrc_words(a.in, (unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), rw_w = make_rsrc_words(a.w, OOB);
+    // DUAL (single tap): channels [0, cin1) of the K extent come from `in` (with the fused input affine, if any), the rest from `in2` (plain,
+    // always by DMA): the hourglass residual's conv3 + skip_layer in one launch, as in conv_gemm_body
+    const int cin1 = DUAL ? a.Cin1 : a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u);
+    const i32x4 rw_in = make_rsrc_words(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u), rw_w = make_rsrc_words(a.w, OOB);
+    const i32x4 rw_in2 = make_rsrc_words(DUAL ? a.in2 : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
     const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;      // this wave's 1 KB piece of every 4 KB pass
     unsigned w_off[RB];
 #pragma unroll
@@ -1001,7 +1007,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 
     const int cslices = a.Cin / KB;
     const int ksteps = ph.ntaps * cslices;
-    unsigned a_off[RA], tapmask = 0, wtap = 0;
+    unsigned a_off[RA], a_off2[DUAL ? RA : 1], tapmask = 0, wtap = 0;
     auto set_tap = [&](int tap) {
         const int tp = ph.tap[tap];
         const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
@@ -1010,23 +1016,31 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         for (int i = 0; i < RA; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * a.Cin + kc) * 4u;
+            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * cin1 + kc) * 4u;
+            if constexpr (DUAL) a_off2[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * (a.Cin - cin1) + kc) * 4u;
             tapmask |= ok ? (1u << i) : 0u;
         }
         wtap = (unsigned)wt * a.Cin * 4u;
     };
     float4 ra[AREG ? RA : 1];
+    bool staged_regs = false;      // (AREG && DUAL: whether the stage in flight holds register rows -- its `in` part -- or came by DMA)
     unsigned okmask = 0;
     int c0_staged = 0;
     // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
     auto issue = [&](int c0, int buf) {
         const unsigned cb = (unsigned)c0 * 4u;
         const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(BM * ROWB);
-        if constexpr (AREG) {
+        if (DUAL && c0 >= cin1) {        // (wave-uniform) this stage comes from the second tensor
+            const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) dma16(rw_in2, As + i * 4096u, (tapmask & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
+            staged_regs = false;
+        } else if constexpr (AREG) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
             okmask = tapmask;
             c0_staged = c0;
+            staged_regs = true;
         } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
@@ -1037,6 +1051,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     // AREG: registers -> LDS with the fused input affine + ReLU (the previous BatchNorm); padding stays zero
     auto commit = [&](int buf) {
         if constexpr (AREG) {
+            if (DUAL && !staged_regs) return;
             if (a.in_scale) {
                 const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
 #pragma unroll
@@ -1133,9 +1148,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     if constexpr (EPRE) gemm_epilogue<TM, TN, true, EM>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
     else gemm_epilogue<TM, TN, false, EM>(a, ph, acc, smem, M, tile_m, tile_n);
 }
-template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0>
+template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0, bool DUAL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
-    conv_gemm_dma_body<TM, TN, KB, NBUF, AREG, EPRE, EM>(a);
+    conv_gemm_dma_body<TM, TN, KB, NBUF, AREG, EPRE, EM, DUAL>(a);
 }
 
 // amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
@@ -1338,6 +1353,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(Ds);
+        red[da_r * FM + (tid % FM)] = csum;
+        __syncthreads();
+        if (da_r == 0 && d_cok) {
+            float4 tsum = make_float4(0, 0, 0, 0);
+            for (int g = 0; g < PM; ++g) {
+                const float4 v = red[g * FM + tid];
+                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
+            }
+            if (a.split_stride) {
+                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + da_c, tsum);
+            } else {
+                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
+                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient with LDS-DMA staging (round 4)
+// ------------------------------------------------------------------------------------------
+// Same decomposition as conv_wgrad_kernel (workgroup = (tap, cd tile, cg tile, pixel chunk); K = pixels), same multiply-free slice
+// addressing (power-of-two maps: every reference layer), but an operand that needs no arithmetic on the way in goes global -> LDS directly
+// (`buffer_load_dwordx4 ... lds`, see conv_gemm_dma_body): the pixel rows of a slice are already what the instruction wants -- a pixel's BM
+// (BN) channels are contiguous in HBM and the slice image is [pixel][channel], so with UNPADDED rows thread t's 16-byte chunk lands at
+// 16 t of its 4 KB pass, lane-linear; the fragments are 4-byte reads of 32 consecutive floats per half-wave (conflict-free at any pitch), so
+// no swizzle is needed.  Stages of KP pixels are double-buffered: stage k + 1 is requested before the MFMAs of stage k, one barrier per
+// stage, no store phase, no staging registers.  DREG / GREG: that operand still travels through registers (fused BatchNorm + ReLU loader of
+// a never-materialised activation; the bias-gradient column sums need D in registers as well).
+template <int TM, int TN, int KP, bool DREG, bool GREG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? 5 : TM * TN == 2 ? 4 : 2))) void conv_wgrad_dma_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int FM = BM / 4, FN = BN / 4;          // 16-byte chunks per pixel row
+    constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows per 4 KB pass of the 256 threads
+    constexpr int RA = KP / PM, RB = KP / PN;        // passes (DMA instructions / float4 registers) per thread and stage
+    constexpr int DST = KP * BM * 4, STAGE = KP * (BM + BN) * 4;
+    static_assert(RA >= 1 && RB >= 1, "stage too small for the tile");
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * STAGE];
+
+    const int M = a.B * a.Hd * a.Wd;
+    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
+    int wg = blockIdx.x;
+    const int tcg = wg % tiles_cg; wg /= tiles_cg;
+    const int tcd = wg % tiles_cd; wg /= tiles_cd;
+    const int t = wg;                                 // tap
+    const int dy = a.dy[t], dx = a.dx[t];
+    const int m_begin = blockIdx.y * chunk;
+    int m_end = m_begin + chunk;
+    if (m_end > M) m_end = M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int da_c = (tid % FM) * 4, da_r = tid / FM;
+    const int ga_c = (tid % FN) * 4, ga_r = tid / FN;
+    const bool d_cok = tcd * BM + da_c < a.Cd, g_cok = tcg * BN + ga_c < a.Cg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rd[DREG ? RA : 1], rg[GREG ? RB : 1];
+    const unsigned dbytes = (unsigned)M * a.Cd * 4u, gbytes = (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u;
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, dbytes), rs_g = make_rsrc(a.G, gbytes);
+    const i32x4 rw_d = make_rsrc_words(a.D, dbytes), rw_g = make_rsrc_words(a.G, gbytes);
+    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
+    const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
+    unsigned d_ok = 0, g_ok = 0;
+    const int hsh = hshift & 63, gws = (hshift >> 8) & 63, ghs = (hshift >> 16) & 63, sgs = a.sg - 1;      // log2(Hd), log2(Wg), log2(Hg); sg in {1, 2}
+    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
+    auto issue = [&](int m0, int buf) {
+        const unsigned Dl = lds0 + (unsigned)(buf * STAGE), Gl = Dl + (unsigned)DST;
+        d_ok = g_ok = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + da_r + PM * i;
+            const bool ok = m < m_end && d_cok;
+            const unsigned off = ok ? __umul24((unsigned)m, dpitch) + d_col : OOB;
+            if constexpr (DREG) rd[i] = buf_ld4(rs_d, off);
+            else dma16(rw_d, Dl + i * 4096u, off);
+            d_ok |= ok ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int m = m0 + ga_r + PN * i;
+            const int x = m & (a.Wd - 1), tt = m >> wshift, y = tt & (a.Hd - 1), b = tt >> hsh;
+            const int gy = (y << sgs) + dy, gx = (x << sgs) + dx;
+            const bool ok = m < m_end && g_cok && (unsigned)gy < (unsigned)a.Hg && (unsigned)gx < (unsigned)a.Wg;
+            const unsigned pix = (unsigned)((((b << ghs) + gy) << gws) + gx);
+            const unsigned off = ok ? __umul24(pix, gpitch) + g_col : OOB;
+            if constexpr (GREG) rg[i] = buf_ld4(rs_g, off);
+            else dma16(rw_g, Gl + i * 4096u, off);
+            g_ok |= ok ? (1u << i) : 0u;
+        }
+    };
+    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
+    if (DREG && a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * BM + da_c); dsh = ld4(a.d_shift + tcd * BM + da_c); }
+    if (GREG && a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * BN + ga_c); gsh = ld4(a.g_shift + tcg * BN + ga_c); }
+    const bool do_colsum = DREG && a.d_colsum != nullptr && t == 0 && tcg == 0;
+    float4 csum = make_float4(0, 0, 0, 0);
+    auto commit = [&](int buf) {       // register-path operands: fused affine + ReLU (padding / tail rows stay zero), then into the stage image
+        if constexpr (DREG) {
+            if (a.d_scale) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    if (d_ok & (1u << i)) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
+            }
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16), rd[i]);
+        }
+        if constexpr (GREG) {
+            if (a.g_scale) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (g_ok & (1u << i)) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + DST + i * 4096 + tid * 16), rg[i]);
+        }
+    };
+    const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * BM + wm * 32 * TM + l31;            // A[i = cd][k = pixel]: Ds[k][i]
+    const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * BN + wn * 32 * TN + l31;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kp = 0; kp < KP / 2; ++kp) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = a_frag[buf * (STAGE / 4) + 2 * kp * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = b_frag[buf * (STAGE / 4) + 2 * kp * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto stage_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait();
+        __syncthreads();
+    };
+    issue(m_begin, 0);
+    commit(0);
+    stage_done();
+    for (int m0 = m_begin; m0 < m_end; m0 += 2 * KP) {
+        const bool more1 = m0 + KP < m_end;
+        if (more1) issue(m0 + KP, 1);
+        compute(0);
+        if (!more1) break;
+        commit(1);
+        stage_done();
+        const bool more2 = m0 + 2 * KP < m_end;
+        if (more2) issue(m0 + 2 * KP, 0);
+        compute(1);
+        if (more2) {
+            commit(0);
+            stage_done();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (cd < a.Cd && cg < a.Cg) {
+                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
+                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];     // deterministic mode: own copy per K-chunk
+                    else atomicAdd(o, acc[i][j][r]);
+                }
+            }
+    }
+    if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(smem_raw);
         red[da_r * FM + (tid % FM)] = csum;
         __syncthreads();
         if (da_r == 0 && d_cok) {
@@ -1723,7 +1924,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
 using namespace awr;
 
+// ---- dispatch of the LDS-DMA GEMM instantiations (run-time flags -> compile-time variants) ----
+template <int TM, int TN, int KB, int NBUF, bool AREG>
+static void launch_dma_em(const awr_conv_args* a, dim3 grid, hipStream_t st, bool epre, int em) {
+#define AWR_DMA_K(EPRE, EM, DUAL) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AREG, EPRE, EM, DUAL>), grid, dim3(256), 0, st, *a)
+    if (a->in2) {                      // conv3 + skip_layer: K = [in | in2]; no operand prefetch (the launcher excludes it), no BNR epilogue
+        if (em == 2) AWR_DMA_K(false, 2, true);
+        else AWR_DMA_K(false, 1, true);
+    } else if (epre) {                 // short K loops whose epilogue reads exactly one operand tensor
+        if (em == 3) AWR_DMA_K(true, 3, false);
+        else if (em == 2) AWR_DMA_K(true, 2, false);
+        else AWR_DMA_K(true, 1, false);
+    } else {
+        if (em == 4) AWR_DMA_K(false, 4, false);
+        else if (em == 3) AWR_DMA_K(false, 3, false);
+        else if (em == 2) AWR_DMA_K(false, 2, false);
+        else AWR_DMA_K(false, 1, false);
+    }
+#undef AWR_DMA_K
+}
+template <int TM, int TN>
+static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, int mode, bool aff, bool epre, int em) {
+#ifdef AWR_DMA_STUDY
+    if (mode == 1) { aff ? launch_dma_em<TM, TN, 32, 2, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 2, false>(a, grid, st, epre, em); return; }
+    if (mode == 3) { aff ? launch_dma_em<TM, TN, 32, 1, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, false>(a, grid, st, epre, em); return; }
+#endif
+    aff ? launch_dma_em<TM, TN, 16, 2, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 16, 2, false>(a, grid, st, epre, em);
+}
+static void launch_dma(const awr_conv_args* a, int TM, int TN, dim3 grid, hipStream_t st, int mode, bool aff, bool epre, int em) {
+    if (TM == 2 && TN == 2) launch_dma_tile<2, 2>(a, grid, st, mode, aff, epre, em);
+    else if (TM == 2 && TN == 1) launch_dma_tile<2, 1>(a, grid, st, mode, aff, epre, em);
+    else if (TM == 1 && TN == 2) launch_dma_tile<1, 2>(a, grid, st, mode, aff, epre, em);
+    else launch_dma_tile<1, 1>(a, grid, st, mode, aff, epre, em);
+}
+
+template <int TM, int TN, int KP>
+static void launch_wgrad_dma_t(const awr_wgrad_args* a, bool dreg, bool greg, dim3 grid, hipStream_t st, int chunk, int wshift, int hshift) {
+    if (dreg && greg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, true, true>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
+    else if (dreg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, true, false>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
+    else if (greg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, false, true>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, false, false>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
+}
+static void launch_wgrad_dma(const awr_wgrad_args* a, int TM, int TN, int kp, bool dreg, bool greg, dim3 grid, hipStream_t st, int chunk, int wshift, int hshift) {
+#define AWR_WD(tm, tn)                                                                                       \
+    do {                                                                                                     \
+        if (kp == 32) launch_wgrad_dma_t<tm, tn, 32>(a, dreg, greg, grid, st, chunk, wshift, hshift);        \
+        else launch_wgrad_dma_t<tm, tn, 16>(a, dreg, greg, grid, st, chunk, wshift, hshift);                 \
+    } while (0)
+    if (TM == 2 && TN == 2) AWR_WD(2, 2);
+    else if (TM == 2 && TN == 1) AWR_WD(2, 1);
+    else if (TM == 1 && TN == 2) AWR_WD(1, 2);
+    else AWR_WD(1, 1);
+#undef AWR_WD
+}
+
 static int g_force_tm = 0, g_force_tn = 0, g_products = []() { const char* e = getenv("AWR_GEMM_PRODUCTS"); return e ? atoi(e) : 1; }();
+static int g_staging = []() { const char* e = getenv("AWR_DMA"); return e ? atoi(e) : 2; }();
 
 extern "C" {
 
@@ -1741,6 +1997,18 @@ int awr_set_gemm_products(int n) {
 }
 
 int awr_get_gemm_products(void) { return g_products; }
+
+int awr_set_gemm_staging(int mode) {
+#ifdef AWR_DMA_STUDY
+    AWR_REQUIRE(mode >= 0 && mode <= 3, "gemm_staging: 0 (registers), 1 / 2 / 3 (LDS-DMA study variants)");
+#else
+    AWR_REQUIRE(mode == 0 || mode == 2, "gemm_staging: 0 (global -> registers -> LDS) or 2 (LDS-DMA, the default)");
+#endif
+    g_staging = mode;
+    return AWR_OK;
+}
+
+int awr_get_gemm_staging(void) { return g_staging; }
 
 static int conv_gemm_one(const awr_conv_args* a, void* stream);
 
@@ -1865,33 +2133,13 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         else if (g_products == 6) hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 6, false>), grid, dim3(256), 0, st, *a);    \
         else hipLaunchKernelGGL((conv_gemm_kernel<tm, tn, 0, false>), grid, dim3(256), 0, st, *a);                         \
     } while (0)
-    // LDS-DMA staging (conv_gemm_dma_body): AWR_DMA = 0 off, 1 = 32-float stages x 2, 2 = 16-float stages x 2, 3 = 32-float stage x 1
-    static const int dma_mode = []() { const char* e = getenv("AWR_DMA"); return e ? atoi(e) : 0; }();
-    if (dma_mode && g_products == 1 && !a->in2 && !epre) {
-#define AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, em)                                                                                      \
-    do {                                                                                                                           \
-        if (aff) hipLaunchKernelGGL((conv_gemm_dma_kernel<tm, tn, kb, nbuf, true, false, em>), grid, dim3(256), 0, st, *a);        \
-        else hipLaunchKernelGGL((conv_gemm_dma_kernel<tm, tn, kb, nbuf, false, false, em>), grid, dim3(256), 0, st, *a);           \
-    } while (0)
-#define AWR_LAUNCH_DMA2(tm, tn, kb, nbuf)                                                                                          \
-    do {                                                                                                                           \
-        if (a->bnr_y) AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 3);                                                                        \
-        else if (a->stats) AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 2);                                                                   \
-        else AWR_LAUNCH_DMA3(tm, tn, kb, nbuf, 1);                                                                                 \
-    } while (0)
-#define AWR_LAUNCH_DMA(tm, tn)                                                                                                     \
-    do {                                                                                                                           \
-        if (dma_mode == 1) AWR_LAUNCH_DMA2(tm, tn, 32, 2);                                                                         \
-        else if (dma_mode == 2) AWR_LAUNCH_DMA2(tm, tn, 16, 2);                                                                    \
-        else AWR_LAUNCH_DMA2(tm, tn, 32, 1);                                                                                       \
-    } while (0)
-        if (TM == 2 && TN == 2) AWR_LAUNCH_DMA(2, 2);
-        else if (TM == 2 && TN == 1) AWR_LAUNCH_DMA(2, 1);
-        else if (TM == 1 && TN == 2) AWR_LAUNCH_DMA(1, 2);
-        else AWR_LAUNCH_DMA(1, 1);
-#undef AWR_LAUNCH_DMA
-#undef AWR_LAUNCH_DMA2
-#undef AWR_LAUNCH_DMA3
+    // LDS-DMA staging (conv_gemm_dma_body) is the default of the FP32-MFMA mode: 16-float stages, double-buffered.  awr_set_gemm_staging(0) /
+    // AWR_DMA=0 is the same-box A/B hook back to the register-staged kernel; builds with -DAWR_DMA_STUDY also carry 1 = 32-float stages x 2 and
+    // 3 = 32-float stage x 1.
+    const int dma_mode = g_staging;
+    if (dma_mode && g_products == 1) {
+        const int em = a->bnr_y ? ((a->bnr_act || a->res || a->bnr2_y) ? 4 : 3) : a->stats ? 2 : 1;
+        launch_dma(a, TM, TN, grid, st, dma_mode, aff, epre, em);
         return check_launch("conv_gemm_dma_kernel");
     }
     static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
@@ -2022,6 +2270,16 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
         if (!no_fast && wshift >= 0 && gws >= 0 && ghs >= 0 && (a->sg == 1 || a->sg == 2) && (int64_t)a->B * a->Hd * a->Wd < (1 << 24) &&
             (int64_t)a->B * a->Hg * a->Wg < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24))
             hshift_f32 = hshift | 64 | (gws << 8) | (ghs << 16);
+    }
+    // LDS-DMA staging (conv_wgrad_dma_kernel) whenever the multiply-free addressing applies (every reference layer) in the FP32-MFMA mode;
+    // AWR_WGRAD_DMA=0 is the same-box A/B hook back to the register-staged kernel, AWR_WGRAD_KP the stage depth in pixels (16 | 32)
+    static const int wdma = []() { const char* e = getenv("AWR_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    static const int wkp = []() { const char* e = getenv("AWR_WGRAD_KP"); return e ? atoi(e) : 0; }();
+    if (wdma && g_staging && g_products == 1 && hshift_f32 >= 64) {
+        const bool dreg = a->d_scale != nullptr || a->d_colsum != nullptr, greg = a->g_scale != nullptr;
+        const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);
+        launch_wgrad_dma(a, TM, TN, kp, dreg, greg, grid, st, (int)chunk, wshift, hshift_f32);
+        return check_launch("conv_wgrad_dma_kernel");
     }
 #define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
     do {                                                                                                                                  \

@@ -331,7 +331,7 @@ class Plan:
             return
         cache_file = os.environ.get("AWR_TUNE_CACHE")
         if cache_key:
-            cache_key += "/x%d" % L.lib.awr_get_gemm_products()      # tile choices differ between the product modes
+            cache_key += "/x%d/s%d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging())      # tile choices differ between the modes
         names = [self._gemm(i)[0] for i in range(self.n_gemm)]
         if cache_file and cache_key and os.path.exists(cache_file):
             try:

@@ -249,6 +249,13 @@ int awr_debug_force_tile(int tm, int tn);
  * Replaces nothing in the reference (torch's conv precision is whatever cuDNN / oneDNN pick; cuDNN defaults to TF32). */
 int awr_set_gemm_products(int n);
 int awr_get_gemm_products(void);
+/* How the FP32-MFMA forward / data-gradient GEMM stages its operands (process-wide; default 2, or $AWR_DMA):
+ *   2 = LDS-DMA: `buffer_load_dwordx4 ... lds` straight into swizzled, unpadded LDS rows, 16-float stages, double-buffered
+ *       (weights always; activations whenever no fused input affine / ReLU has to touch them on the way in);
+ *   0 = global -> registers -> ds_write -> LDS (rounds 1-3; kept as the same-box A/B reference and for split-K / fused pairs).
+ * Results are bit-identical between the two (same k order).  Replaces nothing in the reference. */
+int awr_set_gemm_staging(int mode);
+int awr_get_gemm_staging(void);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).

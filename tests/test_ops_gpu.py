@@ -101,20 +101,130 @@ def test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, 
     assert rel_err(gw2.cpu(), 2 * gw_ref) < 1e-5
 
 
-@pytest.mark.parametrize("products", [1, 6])
+@pytest.mark.parametrize("products,staging", [(1, 2), (1, 0), (6, 2)])
 @pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
                                                               ("deconv", 64, 96, 4, 2, 1, 3, 10), ("conv", 32, 64, 1, 1, 0, 2, 12)])
-def test_conv_every_tile_shape(ops, L, dev, products, tm, tn, kind, cin, cout, k, stride, pad, B, H):
-    """All four workgroup tiles (64/128 x 64/128) in both product modes (f32 MFMA, 6-product bf16 split)
-    on ragged M and N (not multiples of any tile), incl. a single-K-slice problem."""
+def test_conv_every_tile_shape(ops, L, dev, products, staging, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """All four workgroup tiles (64/128 x 64/128) in both product modes (f32 MFMA, 6-product bf16 split) and, for the f32 mode, both
+    operand staging paths (2 = LDS-DMA, the default; 0 = through registers) on ragged M and N (not multiples of any tile), incl. a
+    single-K-slice problem."""
     L.call("awr_debug_force_tile", tm, tn)
     L.call("awr_set_gemm_products", products)
+    L.call("awr_set_gemm_staging", staging)
     try:
         test_conv_forward_dgrad_wgrad(ops, dev, kind, cin, cout, k, stride, pad, B, H)
     finally:
         L.call("awr_debug_force_tile", 0, 0)
         L.call("awr_set_gemm_products", 1)
+        L.call("awr_set_gemm_staging", 2)
+
+
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
+def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, tn):
+    """The LDS-DMA kernel (buffer_load ... lds into swizzled unpadded rows, 16-float stages) walks K in the same order as the register-staged
+    one, so every fused form must give the SAME BITS: 3x3 with the fused input affine + ReLU (activation rows through registers, weights by
+    DMA) + bias / affine / residual / ReLU / statistics epilogue; a strided 3x3 and a transposed conv (padding taps = out-of-range DMA
+    sources that must land zeros); the two-tensor K extent of conv3 + skip_layer (hourglass.py:44-59); the short-K operand-prefetch form;
+    a data gradient with the fused BatchNorm-backward reduction, plain and accumulating onto an earlier contribution with the mask from a
+    stored activation."""
+    import ctypes as C
+    outs, keep = {}, []
+
+    def D(t):      # device copy kept alive until the test ends (make_conv_args only stores raw pointers)
+        keep.append(t.to(dev).contiguous())
+        return keep[-1]
+    for staging in (0, 2):
+        L.call("awr_set_gemm_staging", staging)
+        try:
+            got = []
+            # (a) fused prologue + full epilogue, ragged N
+            B, H, cin, cout = 3, 18, 64, 96
+            spec = ops.ConvSpec("conv", cin, cout, 3, 1, 1)
+            x, w = rnd(B, cin, H, H, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+            s_, t_ = rnd(cin, seed=3) + 1.5, rnd(cin, seed=4)
+            so, to, bias, res = rnd(cout, seed=5) + 1.5, rnd(cout, seed=6), rnd(cout, seed=7), rnd(B, cout, H, H, seed=8)
+            wp = ops.pack_weight(D(w), spec.fwd_pack())
+            stats = torch.zeros(16, 2, cout, device=dev, dtype=torch.float64)
+            prob = spec.fwd_problem(H, H)
+            out = torch.full((B, H, H, prob["N"]), float("nan"), device=dev)
+            a = ops.make_conv_args(prob, B, D(ops.nhwc(x)), wp, out, in_scale=D(s_), in_shift=D(t_), relu_in=True, bias=D(bias),
+                                   out_scale=D(so), out_shift=D(to), res=D(ops.nhwc(res)), relu_out=True, stats=stats, T=spec.T)
+            a.tile_m, a.tile_n = tm, tn
+            L.call("awr_conv_gemm", C.byref(a), L.stream())
+            got += [out.clone(), stats.sum(0).float()]
+            # (b) strided conv, transposed conv, plain activations (both operands by DMA), ragged M
+            for kind, ci, co, k, st, p, hh in (("conv", 128, 160, 3, 2, 1, 20), ("deconv", 64, 96, 4, 2, 1, 10), ("conv", 96, 64, 1, 1, 0, 12)):
+                sp = ops.ConvSpec(kind, ci, co, k, st, p)
+                xx = rnd(2, ci, hh, hh, seed=11)
+                ww = rnd(*((co, ci, k, k) if kind == "conv" else (ci, co, k, k)), seed=12, scale=0.05)
+                pr = sp.fwd_problem(hh, hh)
+                xin = ops.nhwc(xx)
+                if pr["Cin"] != ci:
+                    xin = torch.nn.functional.pad(xin, (0, pr["Cin"] - ci))
+                oo = torch.full((2, pr["Hout"], pr["Wout"], pr["N"]), float("nan"), device=dev)
+                aa = ops.make_conv_args(pr, 2, D(xin), D(ops.pack_weight(D(ww), sp.fwd_pack())), oo, T=sp.T)
+                aa.tile_m, aa.tile_n = tm, tn
+                L.call("awr_conv_gemm", C.byref(aa), L.stream())
+                got.append(oo.clone())
+            # (c) two input tensors (K = [in | in2]) with the affine on the first
+            c1, c2, co = 64, 128, 160
+            xa, xb = rnd(2, c1, 12, 12, seed=21), rnd(2, c2, 12, 12, seed=22)
+            wab = rnd(co, c1 + c2, 1, 1, seed=23, scale=0.1)
+            sp = ops.ConvSpec("conv", c1 + c2, co, 1, 1, 0)
+            pr = sp.fwd_problem(12, 12)
+            oo = torch.full((2, 12, 12, pr["N"]), float("nan"), device=dev)
+            st2 = torch.zeros(16, 2, pr["N"], device=dev, dtype=torch.float64)
+            sa, ta = rnd(c1, seed=24) + 1.2, rnd(c1, seed=25)
+            aa = ops.make_conv_args(pr, 2, D(ops.nhwc(xa)), D(ops.pack_weight(D(wab), sp.fwd_pack())), oo, in_scale=D(sa), in_shift=D(ta),
+                                    relu_in=True, stats=st2, T=sp.T)
+            xb_d = D(ops.nhwc(xb))
+            aa.in2, aa.Cin1, aa.tile_m, aa.tile_n = L.ptr(xb_d), c1, tm, tn
+            L.call("awr_conv_gemm", C.byref(aa), L.stream())
+            got += [oo.clone(), st2.sum(0).float()]
+            ref_c = TF.conv2d(torch.cat([TF.relu(xa.double() * sa.double().view(1, -1, 1, 1) + ta.double().view(1, -1, 1, 1)), xb.double()], 1), wab.double())
+            assert rel_err(ops.nchw(oo)[:, :co].cpu(), ref_c) < 2e-6
+            # (d) short K + one epilogue operand (prefetch form) and (e) BatchNorm-backward reduction, plain and accumulating with a stored mask
+            cin, cout, B, H = 128, 160, 3, 10
+            sp = ops.ConvSpec("conv", cin, cout, 1, 1, 0)
+            x, w, res = rnd(B, cin, H, H, seed=31), rnd(cout, cin, 1, 1, seed=32, scale=0.1), rnd(B, cout, H, H, seed=33)
+            pr = sp.fwd_problem(H, H)
+            oo = torch.full((B, H, H, pr["N"]), float("nan"), device=dev)
+            aa = ops.make_conv_args(pr, B, D(ops.nhwc(x)), D(ops.pack_weight(D(w), sp.fwd_pack())), oo, res=D(ops.nhwc(res)), T=sp.T)
+            aa.tile_m, aa.tile_n = tm, tn
+            L.call("awr_conv_gemm", C.byref(aa), L.stream())
+            got.append(oo.clone())
+            sp3 = ops.ConvSpec("conv", 64, 96, 3, 1, 1)
+            gy, y, w3 = rnd(2, 96, 14, 14, seed=41), rnd(2, 64, 14, 14, seed=42), rnd(96, 64, 3, 3, seed=43, scale=0.05)
+            dp = sp3.dgrad_problem(14, 14)
+            coef4 = torch.zeros(4, dp["N"], device=dev)
+            coef4[:, :64] = torch.stack([rnd(64, seed=44) + 1.2, rnd(64, seed=45) * 0.3, rnd(64, seed=46) * 0.2, rnd(64, seed=47) + 1.5]).to(dev)
+            yg = torch.zeros(2, 14, 14, dp["N"], device=dev)
+            yg[..., :64] = D(ops.nhwc(y))
+            gin = ops.nhwc(gy)
+            if dp["Cin"] != 96:
+                gin = torch.nn.functional.pad(gin, (0, dp["Cin"] - 96))
+            for accumulate in (False, True):
+                g = torch.full((2, 14, 14, dp["N"]), float("nan"), device=dev)
+                sums = torch.zeros(16, 2, dp["N"], device=dev, dtype=torch.float64)
+                d = ops.make_conv_args(dp, 2, D(gin), D(ops.pack_weight(D(w3), sp3.dgrad_pack())), g, stats=sums, T=sp3.T)
+                d.bnr_y, d.bnr_coef, d.tile_m, d.tile_n = L.ptr(yg), L.ptr(coef4), tm, tn
+                if accumulate:
+                    act = D(ops.nhwc(rnd(2, dp["N"], 14, 14, seed=48)))
+                    g.copy_(ops.nhwc(rnd(2, dp["N"], 14, 14, seed=49)).to(dev))
+                    d.bnr_act, d.res = L.ptr(act), L.ptr(g)
+                L.call("awr_conv_gemm", C.byref(d), L.stream())
+                torch.cuda.synchronize()
+                got += [g.clone(), sums.sum(0).float()]
+            outs[staging] = got
+        finally:
+            L.call("awr_set_gemm_staging", 2)
+    assert len(outs[0]) == len(outs[2])
+    for i, (p, q) in enumerate(zip(outs[0], outs[2])):
+        if p.dtype == torch.float32 and p.dim() == 2:        # statistics: fp64 atomics in launch order, compared after rounding to fp32
+            assert rel_err(q.cpu(), p.cpu()) < 1e-6, i
+        else:
+            assert torch.equal(torch.nan_to_num(p, nan=-1234.0), torch.nan_to_num(q, nan=-1234.0)), i
 
 
 def test_conv_fused_prologue_epilogue_stats(ops, dev):
