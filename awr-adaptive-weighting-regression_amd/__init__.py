@@ -34,6 +34,19 @@ def get_deterministic():
     return bool(L.lib.awr_get_deterministic())
 
 
+def set_gemm_accum(mode):
+    """Process-wide accumulation order of the forward / data-gradient GEMMs of plans built afterwards (include/awr_hip.h:
+    awr_set_gemm_accum): "ordered" / 0 = one k-ordered chain per output element (fastest, the default), "blocked" / 1 = the chain restarts
+    every 128 k into a second accumulator set -- a convolution's rounding error falls to torch-CPU's (the parity mode)."""
+    from . import _lib as L
+    L.call("awr_set_gemm_accum", {"ordered": 0, "blocked": 1}.get(mode, mode))
+
+
+def get_gemm_accum():
+    from . import _lib as L
+    return ("ordered", "blocked")[int(L.lib.awr_get_gemm_accum())]
+
+
 def __getattr__(name):
     import importlib
     table = {

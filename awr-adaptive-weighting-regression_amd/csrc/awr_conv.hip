@@ -916,8 +916,8 @@ __device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
 //   * completion is the issuing wave's vmcnt, visibility to the other waves the barrier behind it.
 // Pipeline: NBUF = 2 stages of KB floats of K in LDS; stage k + 1 is requested before the MFMAs of stage k and awaited behind them, ONE
 // barrier per stage, no LDS store phase, no staging registers.  KB = 32 doubles the LDS of a workgroup (64x128: 48 KB, three workgroups
-// per CU); KB = 16 keeps it (24 KB) with 64-byte rows.  AREG: the activation rows still travel through registers (fused input affine /
-// ReLU of a never-materialised BatchNorm) and are stored into the same swizzled image; the weights go by DMA.
+// per CU); KB = 16 keeps it (24 KB) with 64-byte rows.  AFF: a fused input affine / ReLU (never-materialised BatchNorm) is applied to the A
+// fragments between LDS and the matrix pipe (see the body), so those launches move both operands by DMA as well.
 // The instruction is issued from inline assembly: through the builtin, hipcc (ROCm 7.2) cannot tell which LDS bytes a DMA in flight will
 // overwrite and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- i.e. right behind the request, the load latency fully exposed
 // (seen in the ISA of the first version).  From assembly the compiler does not count the request at all: dma_wait() before the barrier is
@@ -940,22 +940,26 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_uniform, unsigned
                  : "v"(voff), "s"(rsrc), "s"(lds_uniform)
                  : "memory");
 }
+constexpr int AFF_MAXC = 512;      // channels of a fused input affine the LDS-DMA kernel keeps in its LDS coefficient table
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)reinterpret_cast<unsigned long long>(p);      // a generic pointer into LDS: aperture in the high word, LDS byte offset in the low one
 }
-template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0, bool DUAL = false>
+template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
     constexpr int LPR = KB / 4;                   // 16-byte chunks (= staging lanes) per row
     constexpr int RPP = 256 / LPR;                // rows covered by one pass of the 256 threads (32 | 64); one pass = 4 KB of LDS
-    constexpr int RA = BM / RPP, RB = BN / RPP;   // DMA instructions (AREG: float4 registers) per thread and stage
-    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int RA = BM / RPP, RB = BN / RPP;   // DMA instructions per thread and stage
+    constexpr int AROWS = AFF == 2 ? 2 * BM : BM; // AFF == 2: the rows of TWO tensors (g, y) per A row
+    constexpr int STAGE = (AROWS + BN) * ROWB;
     constexpr int EPI = 4 * 32 * LDK * 4;         // the epilogue's four 32x36 transpose tiles
+    constexpr int BUFS = NBUF * STAGE > EPI ? NBUF * STAGE : EPI;
     static_assert(RA >= 1 && RB >= 1, "tile too small for the stage shape");
-    __shared__ __attribute__((aligned(16))) char smem_raw[NBUF * STAGE > EPI ? NBUF * STAGE : EPI];
+    // AFF: the coefficient vectors of the fused input arithmetic behind the stage buffers (<= AFF_MAXC channels; the launcher checks)
+    __shared__ __attribute__((aligned(16))) char smem_raw[BUFS + (AFF == 2 ? 4 : AFF ? 2 : 0) * AFF_MAXC * 4];
     float* const smem = reinterpret_cast<float*>(smem_raw);
 
     const awr_phase& ph = a.ph[blockIdx.y];
@@ -965,6 +969,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
     // staging role: row r0 (+ RPP per pass) of the tile, LDS chunk cl of that row, which holds SOURCE chunk cl ^ swz(row)
     const int r0 = tid / LPR, cl = tid % LPR;
     const int kc = (cl ^ (KB == 32 ? (r0 >> 1) & 7 : (r0 >> 2) & 3)) * 4;      // this thread's 4 consecutive k inside the stage
@@ -986,16 +991,65 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
             a_img[i] = 0;
         }
     }
-    // DUAL (single tap): channels [0, cin1) of the K extent come from `in` (with the fused input affine, if any), the rest from `in2` (plain,
-    // always by DMA): the hourglass residual's conv3 + skip_layer in one launch, as in conv_gemm_body
+    // DUAL (single tap): channels [0, cin1) of the K extent come from `in` (with the fused input affine, if any), the rest from `in2` (plain):
+    // the hourglass residual's conv3 + skip_layer in one launch, as in conv_gemm_body
     const int cin1 = DUAL ? a.Cin1 : a.Cin;
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u);
     const i32x4 rw_in = make_rsrc_words(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u), rw_w = make_rsrc_words(a.w, OOB);
-    const i32x4 rw_in2 = make_rsrc_words(DUAL ? a.in2 : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
+    const i32x4 rw_in2 = make_rsrc_words(DUAL ? a.in2 : AFF == 2 ? a.in_bnb_y : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
     const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;      // this wave's 1 KB piece of every 4 KB pass
     unsigned w_off[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + RPP * i) * a.T * a.Cin + kc) * 4u;
+
+    // AFF: the fused input affine + ReLU (a BatchNorm output that is never written to HBM) is applied to the A FRAGMENTS on their way from LDS
+    // to the matrix pipe, not to the rows on their way into LDS: both operands travel by DMA, and the arithmetic (a multiply-add and a clamp
+    // per element, every element twice -- once per N-wave) issues between the 64-cycle MFMAs, where the wave's VALU slots are idle anyway.
+    // Padding must stay zero THROUGH the affine: a lane knows whether its fragment rows are inside the image for the current tap.
+    // AFF == 2 (data gradients): the input IS a BatchNorm backward that is never materialised.  d(y) = a1 g + a2 (y - mean) + a3 per channel, g =
+    // the (masked) gradient w.r.t. the BatchNorm's output, y its input, (a1, a2, a3, mean) from awr_bn_bwd_finalize_lin: the rows of BOTH tensors
+    // are staged (same pixel, same channel chunk, same padding rule) and the two multiply-adds run on the fragments -- the
+    // awr_bn_bwd_apply pass between two dependent data-gradient GEMMs leaves the critical chain.
+    float* const aff_tab = reinterpret_cast<float*>(smem_raw + BUFS);
+    int f_iy[AFF ? TM : 1], f_ix[AFF ? TM : 1];
+    unsigned fmask = 0;
+    if constexpr (AFF) {
+        for (int c = tid * 4; c < cin1; c += 1024) {
+            if constexpr (AFF == 2) {
+                st4(aff_tab + c, ld4(a.in_bnb_coef + c));
+                st4(aff_tab + AFF_MAXC + c, ld4(a.in_bnb_coef + a.Cin + c));
+                st4(aff_tab + 2 * AFF_MAXC + c, ld4(a.in_bnb_coef + 2 * a.Cin + c));
+                st4(aff_tab + 3 * AFF_MAXC + c, ld4(a.in_bnb_coef + 3 * a.Cin + c));
+            } else {
+                st4(aff_tab + c, a.in_scale ? ld4(a.in_scale + c) : make_float4(1, 1, 1, 1));
+                st4(aff_tab + AFF_MAXC + c, a.in_shift ? ld4(a.in_shift + c) : make_float4(0, 0, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
+            f_iy[i] = -(1 << 20);
+            f_ix[i] = 0;
+            if (m < M) {
+                int qx, qy, b;
+                decode_row(a, m, qx, qy, b);
+                f_iy[i] = qy * a.si;
+                f_ix[i] = qx * a.si;
+            }
+        }
+    }
+    const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();
+    auto set_ftap = [&](int tap) {
+        if constexpr (AFF) {
+            const int tp = ph.tap[tap];
+            const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+            fmask = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int iy = f_iy[i] + dy, ix = f_ix[i] + dx;
+                fmask |= (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) ? (1u << i) : 0u;
+            }
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1004,6 +1058,34 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ACCB (awr_conv_args.accum = 1): blocked accumulation.  The matrix instruction adds onto its accumulator operand, so a K extent of 576 ...
+    // 4608 terms is ONE rounding chain; every ACC_BLOCK k the running sum moves into a second accumulator set and the chain restarts
+    // (chains of ACC_BLOCK + K / ACC_BLOCK terms): a conv's error against float64 falls to torch-CPU's.
+    constexpr int ACC_BLOCK = 128, ACC_STAGES = ACC_BLOCK / KB;
+    f32x16 tot[ACCB ? TM : 1][ACCB ? TN : 1];
+    int since = 0;
+    if constexpr (ACCB) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
+    auto fold = [&]() {
+        if constexpr (ACCB) {
+            if (++since == ACC_STAGES) {
+                since = 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+            }
+        }
+    };
 
     const int cslices = a.Cin / KB;
     const int ksteps = ph.ntaps * cslices;
@@ -1022,59 +1104,34 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         }
         wtap = (unsigned)wt * a.Cin * 4u;
     };
-    float4 ra[AREG ? RA : 1];
-    bool staged_regs = false;      // (AREG && DUAL: whether the stage in flight holds register rows -- its `in` part -- or came by DMA)
-    unsigned okmask = 0;
-    int c0_staged = 0;
     // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
     auto issue = [&](int c0, int buf) {
         const unsigned cb = (unsigned)c0 * 4u;
-        const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(BM * ROWB);
+        const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(AROWS * ROWB);
         if (DUAL && c0 >= cin1) {        // (wave-uniform) this stage comes from the second tensor
             const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
 #pragma unroll
             for (int i = 0; i < RA; ++i) dma16(rw_in2, As + i * 4096u, (tapmask & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
-            staged_regs = false;
-        } else if constexpr (AREG) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
-            okmask = tapmask;
-            c0_staged = c0;
-            staged_regs = true;
         } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+            if constexpr (AFF == 2) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) dma16(rw_in2, As + (unsigned)(BM * ROWB) + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+            }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) dma16(rw_w, Bs + i * 4096u, w_off[i] + (wtap + cb));
     };
-    // AREG: registers -> LDS with the fused input affine + ReLU (the previous BatchNorm); padding stays zero
-    auto commit = [&](int buf) {
-        if constexpr (AREG) {
-            if (DUAL && !staged_regs) return;
-            if (a.in_scale) {
-                const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
-#pragma unroll
-                for (int i = 0; i < RA; ++i)
-                    if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
-            } else if (a.relu_in) {
-#pragma unroll
-                for (int i = 0; i < RA; ++i) {
-                    ra[i].x = relu1(ra[i].x); ra[i].y = relu1(ra[i].y); ra[i].z = relu1(ra[i].z); ra[i].w = relu1(ra[i].w);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16), ra[i]);
-        }
-    };
 
-    const int half = lane >> 5, l31 = lane & 31;
     // fragment reads: lane (l31, half) wants chunk 2 s + half of its rows for sub-step s; physically chunk (2 s + half) ^ swz(l31)
     // (the wave / tile row offsets are multiples of 32: they do not change swz)
     const int fswz = KB == 32 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
     const char* const a_row = smem_raw + (wm * 32 * TM + l31) * ROWB;
-    const char* const b_row = smem_raw + BM * ROWB + (wn * 32 * TN + l31) * ROWB;
+    const char* const b_row = smem_raw + AROWS * ROWB + (wn * 32 * TN + l31) * ROWB;
+    int ctap = 0, cc0 = 0;      // the stage the MFMAs are at (the requests run one stage ahead)
     auto compute = [&](int buf) {
+        const bool aff_stage = AFF != 0 && (!DUAL || cc0 < cin1);       // (wave-uniform)
 #pragma unroll
         for (int s = 0; s < KB / 8; ++s) {
             const int fo = buf * STAGE + (((2 * s + half) ^ fswz) << 4);
@@ -1083,6 +1140,30 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
             for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_row + fo + i * 32 * ROWB));
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_row + fo + j * 32 * ROWB));
+            if constexpr (AFF == 2) {
+                const float4 k1 = ld4(aff_tab + cc0 + 8 * s + 4 * half), k2 = ld4(aff_tab + AFF_MAXC + cc0 + 8 * s + 4 * half),
+                             k3 = ld4(aff_tab + 2 * AFF_MAXC + cc0 + 8 * s + 4 * half), mu = ld4(aff_tab + 3 * AFF_MAXC + cc0 + 8 * s + 4 * half);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bool ok = fmask & (1u << i);
+                    const float4 g = fa[i], y = ld4(reinterpret_cast<const float*>(a_row + BM * ROWB + fo + i * 32 * ROWB));
+                    // (y - mean first, like the apply kernel: a nearly constant channel would cancel catastrophically in a2 y + a3')
+                    fa[i].x = ok ? g.x * k1.x + ((y.x - mu.x) * k2.x + k3.x) : 0.f; fa[i].y = ok ? g.y * k1.y + ((y.y - mu.y) * k2.y + k3.y) : 0.f;
+                    fa[i].z = ok ? g.z * k1.z + ((y.z - mu.z) * k2.z + k3.z) : 0.f; fa[i].w = ok ? g.w * k1.w + ((y.w - mu.w) * k2.w + k3.w) : 0.f;
+                }
+            } else if constexpr (AFF == 1) {
+                if (aff_stage) {
+                    const float4 sc = ld4(aff_tab + cc0 + 8 * s + 4 * half), sh = ld4(aff_tab + AFF_MAXC + cc0 + 8 * s + 4 * half);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const bool ok = fmask & (1u << i);
+                        float4 v = fa[i];
+                        v.x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, relu_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, relu_lo, __builtin_inff());
+                        v.z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, relu_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, relu_lo, __builtin_inff());
+                        fa[i].x = ok ? v.x : 0.f; fa[i].y = ok ? v.y : 0.f; fa[i].z = ok ? v.z : 0.f; fa[i].w = ok ? v.w : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1091,6 +1172,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
         }
+        if constexpr (AFF) {
+            cc0 += KB;
+            if (cc0 == a.Cin) { cc0 = 0; if (++ctap < ph.ntaps) set_ftap(ctap); }
+        }
+        fold();
     };
     int tap = 0, c0 = 0;
     auto advance = [&]() {
@@ -1099,6 +1185,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     };
 
     set_tap(0);
+    set_ftap(0);
     epi_rows epre;
     unsigned eoff[EPRE ? TM : 1][4];
     if constexpr (EPRE) {
@@ -1113,7 +1200,6 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         __syncthreads();
     };
     issue(0, 0);
-    commit(0);
     stage_done();
     if constexpr (NBUF == 2) {
         // unrolled by two: the stage buffer is a compile-time constant in every LDS address
@@ -1121,15 +1207,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         for (; ks + 2 <= ksteps; ks += 2) {
             advance(); issue(c0, 1);      // (ks + 1 < ksteps holds here)
             compute(0);
-            commit(1);
             stage_done();
             const bool more = ks + 2 < ksteps;
             if (more) { advance(); issue(c0, 0); }
             compute(1);
-            if (more) {
-                commit(0);
-                stage_done();
-            }
+            if (more) stage_done();
         }
         if (ks < ksteps) compute(0);      // odd stage count: the last stage sits in buffer 0
     } else {
@@ -1140,17 +1222,24 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 __syncthreads();
                 advance();
                 issue(c0, 0);
-                commit(0);
                 stage_done();
             }
         }
     }
+    if constexpr (ACCB) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
+    }
     if constexpr (EPRE) gemm_epilogue<TM, TN, true, EM>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
     else gemm_epilogue<TM, TN, false, EM>(a, ph, acc, smem, M, tile_m, tile_n);
 }
-template <int TM, int TN, int KB, int NBUF, bool AREG, bool EPRE = false, int EM = 0, bool DUAL = false>
+template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
-    conv_gemm_dma_body<TM, TN, KB, NBUF, AREG, EPRE, EM, DUAL>(a);
+    conv_gemm_dma_body<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB>(a);
 }
 
 // amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
@@ -1925,33 +2014,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 using namespace awr;
 
 // ---- dispatch of the LDS-DMA GEMM instantiations (run-time flags -> compile-time variants) ----
-template <int TM, int TN, int KB, int NBUF, bool AREG>
+template <int TM, int TN, int KB, int NBUF, int AFF>
 static void launch_dma_em(const awr_conv_args* a, dim3 grid, hipStream_t st, bool epre, int em) {
-#define AWR_DMA_K(EPRE, EM, DUAL) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AREG, EPRE, EM, DUAL>), grid, dim3(256), 0, st, *a)
-    if (a->in2) {                      // conv3 + skip_layer: K = [in | in2]; no operand prefetch (the launcher excludes it), no BNR epilogue
+#define AWR_DMA_K(EPRE, EM, DUAL) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL>), grid, dim3(256), 0, st, *a)
+#define AWR_DMA_KB(EM) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, false, EM, false, (KB == 16 && NBUF == 2)>), grid, dim3(256), 0, st, *a)
+    const bool blocked = KB == 16 && NBUF == 2 && a->accum == 1 && a->Cin * a->ph[0].ntaps > 256;      // (shorter K extents are one block anyway)
+    if constexpr (AFF == 2) {          // data gradients only: no statistics epilogue, no second tensor, no operand prefetch
+        if (blocked) {
+            if (em == 4) AWR_DMA_KB(4);
+            else if (em == 3) AWR_DMA_KB(3);
+            else AWR_DMA_KB(1);
+        } else {
+            if (em == 4) AWR_DMA_K(false, 4, false);
+            else if (em == 3) AWR_DMA_K(false, 3, false);
+            else AWR_DMA_K(false, 1, false);
+        }
+    } else if (a->in2) {               // conv3 + skip_layer: K = [in | in2]; no operand prefetch (the launcher excludes it), no BNR epilogue
         if (em == 2) AWR_DMA_K(false, 2, true);
         else AWR_DMA_K(false, 1, true);
     } else if (epre) {                 // short K loops whose epilogue reads exactly one operand tensor
         if (em == 3) AWR_DMA_K(true, 3, false);
         else if (em == 2) AWR_DMA_K(true, 2, false);
         else AWR_DMA_K(true, 1, false);
+    } else if (blocked) {
+        if (em == 4) AWR_DMA_KB(4);
+        else if (em == 3) AWR_DMA_KB(3);
+        else if (em == 2) AWR_DMA_KB(2);
+        else AWR_DMA_KB(1);
     } else {
         if (em == 4) AWR_DMA_K(false, 4, false);
         else if (em == 3) AWR_DMA_K(false, 3, false);
         else if (em == 2) AWR_DMA_K(false, 2, false);
         else AWR_DMA_K(false, 1, false);
     }
+#undef AWR_DMA_KB
 #undef AWR_DMA_K
 }
 template <int TM, int TN>
-static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, int mode, bool aff, bool epre, int em) {
+static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, int mode, int aff, bool epre, int em) {
 #ifdef AWR_DMA_STUDY
-    if (mode == 1) { aff ? launch_dma_em<TM, TN, 32, 2, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 2, false>(a, grid, st, epre, em); return; }
-    if (mode == 3) { aff ? launch_dma_em<TM, TN, 32, 1, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, false>(a, grid, st, epre, em); return; }
+    if (mode == 1 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 2, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 2, 0>(a, grid, st, epre, em); return; }
+    if (mode == 3 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 1, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, 0>(a, grid, st, epre, em); return; }
 #endif
-    aff ? launch_dma_em<TM, TN, 16, 2, true>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 16, 2, false>(a, grid, st, epre, em);
+    if (aff == 2) launch_dma_em<TM, TN, 16, 2, 2>(a, grid, st, epre, em);
+    else if (aff == 1) launch_dma_em<TM, TN, 16, 2, 1>(a, grid, st, epre, em);
+    else launch_dma_em<TM, TN, 16, 2, 0>(a, grid, st, epre, em);
 }
-static void launch_dma(const awr_conv_args* a, int TM, int TN, dim3 grid, hipStream_t st, int mode, bool aff, bool epre, int em) {
+static void launch_dma(const awr_conv_args* a, int TM, int TN, dim3 grid, hipStream_t st, int mode, int aff, bool epre, int em) {
     if (TM == 2 && TN == 2) launch_dma_tile<2, 2>(a, grid, st, mode, aff, epre, em);
     else if (TM == 2 && TN == 1) launch_dma_tile<2, 1>(a, grid, st, mode, aff, epre, em);
     else if (TM == 1 && TN == 2) launch_dma_tile<1, 2>(a, grid, st, mode, aff, epre, em);
@@ -1978,8 +2087,12 @@ static void launch_wgrad_dma(const awr_wgrad_args* a, int TM, int TN, int kp, bo
 #undef AWR_WD
 }
 
-static int g_force_tm = 0, g_force_tn = 0, g_products = []() { const char* e = getenv("AWR_GEMM_PRODUCTS"); return e ? atoi(e) : 1; }();
-static int g_staging = []() { const char* e = getenv("AWR_DMA"); return e ? atoi(e) : 2; }();
+// (plain functions, not lambdas, for the initialisers: hipcc 7.2 initialised a second namespace-scope `static int g = []() { ... }();` of one
+// translation unit with the FIRST lambda's body -- DESIGN.md 5, side finding of round 3)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int g_force_tm = 0, g_force_tn = 0, g_products = env_int("AWR_GEMM_PRODUCTS", 1);
+static int g_staging = env_int("AWR_DMA", 2);
+static int g_accum = env_int("AWR_ACCUM", 0);
 
 extern "C" {
 
@@ -2010,6 +2123,14 @@ int awr_set_gemm_staging(int mode) {
 
 int awr_get_gemm_staging(void) { return g_staging; }
 
+int awr_set_gemm_accum(int mode) {
+    AWR_REQUIRE(mode == 0 || mode == 1, "gemm_accum: 0 (ordered) or 1 (blocked: restart every 128 k)");
+    g_accum = mode;
+    return AWR_OK;
+}
+
+int awr_get_gemm_accum(void) { return g_accum; }
+
 static int conv_gemm_one(const awr_conv_args* a, void* stream);
 
 // Tensors above 4 GB (Hourglass stem-resolution maps at batch 128) exceed the 32-bit buffer offsets of the kernels: the
@@ -2030,10 +2151,13 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
         if (a->bnr_act) b.bnr_act = a->bnr_act + out_img * b.B * c;
         if (a->bnr2_y) b.bnr2_y = a->bnr2_y + out_img * b.B * c;
-        if (a->in2) {
+        if (a->in2 && a->w2) {       // fused pair: `in` holds Cin channels (advanced above), `in2` the N1x extra channels of the second GEMM
+            b.in2 = a->in2 + (int64_t)a->Hin * a->Win * a->N1x * b.B * c;
+        } else if (a->in2) {         // two-tensor K extent: Cin1 channels in `in`, the rest in `in2`
             b.in = a->in + (int64_t)a->Hin * a->Win * a->Cin1 * b.B * c;
             b.in2 = a->in2 + (int64_t)a->Hin * a->Win * (a->Cin - a->Cin1) * b.B * c;
         }
+        if (a->in_bnb_y) b.in_bnb_y = a->in_bnb_y + in_img * b.B * c;
         if (a->stat_slots > 0) b.stat_slot_base = a->stat_slot_base + c * (a->stat_slots / nchunk);
         if (int e = conv_gemm_one(&b, stream)) return e;
     }
@@ -2042,6 +2166,11 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
 
 static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
+    AWR_REQUIRE(a->accum == 0 || a->accum == 1, "conv_gemm: accum=%d", a->accum);
+    AWR_REQUIRE(!a->in_bnb_y || (a->in_bnb_coef && !a->in_scale && !a->relu_in && !a->in2 && !a->w2 && g_products == 1 && g_staging != 0 &&
+                                 a->Cin <= AFF_MAXC && !(a->partial && a->split_k > 1)),
+                "conv_gemm: an un-materialised BatchNorm-backward input (in_bnb_y) needs in_bnb_coef, the FP32-MFMA mode with LDS-DMA staging, Cin <= %d, "
+                "and no other input arithmetic / second tensor / fused pair / split-K", AFF_MAXC);
     AWR_REQUIRE(a->nphase >= 1 && a->nphase <= 4, "conv_gemm: nphase=%d", a->nphase);
     AWR_REQUIRE(g_products == 1 || a->w_split, "conv_gemm: the %d-product mode needs the split image of the weights (w_split)", g_products);
     AWR_REQUIRE(a->B > 0 && a->Hq > 0 && a->Wq > 0 && a->N > 0 && a->T > 0 && a->so >= 1 && a->si >= 1, "conv_gemm: bad geometry");
@@ -2137,9 +2266,9 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     // AWR_DMA=0 is the same-box A/B hook back to the register-staged kernel; builds with -DAWR_DMA_STUDY also carry 1 = 32-float stages x 2 and
     // 3 = 32-float stage x 1.
     const int dma_mode = g_staging;
-    if (dma_mode && g_products == 1) {
+    if (dma_mode && g_products == 1 && ((!aff && !a->in_bnb_y) || (a->in2 ? a->Cin1 : a->Cin) <= AFF_MAXC)) {
         const int em = a->bnr_y ? ((a->bnr_act || a->res || a->bnr2_y) ? 4 : 3) : a->stats ? 2 : 1;
-        launch_dma(a, TM, TN, grid, st, dma_mode, aff, epre, em);
+        launch_dma(a, TM, TN, grid, st, dma_mode, a->in_bnb_y ? 2 : aff ? 1 : 0, epre && !a->in_bnb_y, em);
         return check_launch("conv_gemm_dma_kernel");
     }
     static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
@@ -2271,10 +2400,12 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
             (int64_t)a->B * a->Hg * a->Wg < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24))
             hshift_f32 = hshift | 64 | (gws << 8) | (ghs << 16);
     }
-    // LDS-DMA staging (conv_wgrad_dma_kernel) whenever the multiply-free addressing applies (every reference layer) in the FP32-MFMA mode;
-    // AWR_WGRAD_DMA=0 is the same-box A/B hook back to the register-staged kernel, AWR_WGRAD_KP the stage depth in pixels (16 | 32)
-    static const int wdma = []() { const char* e = getenv("AWR_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-    static const int wkp = []() { const char* e = getenv("AWR_WGRAD_KP"); return e ? atoi(e) : 0; }();
+    // LDS-DMA staging (conv_wgrad_dma_kernel) is OPT-IN (AWR_WGRAD_DMA=1; AWR_WGRAD_KP = stage depth in pixels, 16 | 32): isolated launches of the
+    // 64x64 tile gain 4-7 % with both operands plain (profiles/r04_microbench_wgrad_dma.txt), the wider tiles nothing, an operand that still goes
+    // through registers (fused BatchNorm loader, bias-gradient column sums) loses 5-10 %, and the step does not move: the weight gradient is
+    // not limited by its staging (it co-runs with the data-gradient chain, re-reads D once per tap and ends in split-K atomics).
+    static const int wdma = env_int("AWR_WGRAD_DMA", 0);
+    static const int wkp = env_int("AWR_WGRAD_KP", 0);
     if (wdma && g_staging && g_products == 1 && hshift_f32 >= 64) {
         const bool dreg = a->d_scale != nullptr || a->d_colsum != nullptr, greg = a->g_scale != nullptr;
         const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);

@@ -4,6 +4,8 @@
 // (C % 4 == 0 everywhere), fp64 only for the cross-workgroup statistic accumulators.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "awr_common.h"
 
 namespace awr {
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // collapse the slot-spread backward sums into per-channel coefficients, emit dgamma/dbeta, re-arm the accumulator
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int nslots, double inv_count, const float* __restrict__ gamma,
                                        const float* __restrict__ invstd, float* __restrict__ coef, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
+                                       float* __restrict__ dbeta, int accumulate, const float* __restrict__ mean = nullptr, float* __restrict__ lin = nullptr) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < nslots; k += 64) {
@@ -343,6 +345,13 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(double* __restrict_
     coef[2 * C + c] = (gamma ? gamma[c] : 1.f) * invstd[c];   // gamma * invstd
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+    if (lin) {      // d(y) = gi (g - k1 - (y - mu) is k2) as a1 g + a2 (y - mu) + a3: what a consumer that never sees d(y) in memory evaluates
+        const float gi = coef[2 * C + c];
+        lin[c] = gi;
+        lin[C + c] = -(gi * invstd[c]) * coef[C + c];
+        lin[2 * C + c] = -gi * coef[c];
+        lin[3 * C + c] = mean[c];
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act, const float* __restrict__ y,
@@ -672,6 +681,9 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
                        invstd, coef, dgamma, dbeta, accumulate);
     if (int e = check_launch("bn_bwd_finalize_kernel")) return e;
     const int64_t n4 = npix * (C / 4);
+    // timing study only (results are WRONG): what the step would cost if the apply pass were free -- the upper bound of folding it into its consumers
+    static const bool exp_skip = getenv("AWR_EXP_NO_BN_BWD_APPLY") != nullptr;
+    if (exp_skip) return AWR_OK;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
                        coef, n4, C, dy, dy_add, g_out);
     return check_launch("bn_bwd_apply_kernel");
@@ -683,6 +695,24 @@ int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), sums, C, nslots ? nslots : AWR_STAT_SLOTS, 1.0 / (double)count, gamma,
                        invstd, coef, dgamma, dbeta, accumulate);
     return check_launch("bn_bwd_finalize_kernel");
+}
+
+int awr_bn_bwd_finalize_lin(double* sums, int C, int64_t count, const float* gamma, const float* mean, const float* invstd, float* coef, float* lin4,
+                            float* dgamma, float* dbeta, int accumulate, int nslots, void* stream) {
+    AWR_REQUIRE(sums && mean && invstd && coef && lin4 && C > 0 && count > 0 && nslots >= 0, "bn_bwd_finalize_lin: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), sums, C, nslots ? nslots : AWR_STAT_SLOTS, 1.0 / (double)count, gamma,
+                       invstd, coef, dgamma, dbeta, accumulate, mean, lin4);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+/* second half of awr_bn_bwd_apply on its own (coef from awr_bn_bwd_finalize / _lin) */
+int awr_bn_bwd_apply_only(const float* dout, const float* act, const float* y, const float* mean, const float* invstd, const float* mask_scale,
+                          const float* mask_shift, const float* coef, int64_t npix, int C, float* dy, const float* dy_add, float* g_out, void* stream) {
+    AWR_REQUIRE(dout && y && mean && invstd && coef && dy && npix > 0 && C % 4 == 0, "bn_bwd_apply_only: bad arguments");
+    const int64_t n4 = npix * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
+                       coef, n4, C, dy, dy_add, g_out);
+    return check_launch("bn_bwd_apply_kernel");
 }
 
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream) {

@@ -335,6 +335,7 @@ static void fill_conv_args(awr_conv_args& a, const Prob& p, int B, const float* 
     a.B = B; a.Hin = p.Hin; a.Win = p.Win; a.Cin = p.Cin;
     a.Hq = p.Hq; a.Wq = p.Wq; a.Hout = p.Hout; a.Wout = p.Wout; a.N = p.N;
     a.so = p.so; a.si = p.si; a.T = T;
+    a.accum = awr_get_gemm_accum();      // (the mode of the process when the plan is built, like the deterministic mode)
     a.nphase = (int)p.phases.size();
     for (int i = 0; i < a.nphase; ++i) {
         a.ph[i].py = p.phases[i].py;
@@ -602,6 +603,11 @@ struct Tn {
     // another BatchNorm's output before a ReLU needs to reduce this BatchNorm's backward sums together with its own
     const float *bn_y = nullptr, *bn_coef4 = nullptr;
     StatBuf pre_sums;      // set by that consumer's backward: sum g / sum g*xhat of THIS BatchNorm are already in here
+    // a conv output y whose BatchNorm's backward is NOT on the critical chain (set by bn_bwd, consumed by the conv's conv_bwd): the conv's data
+    // gradient reads g = d(loss)/d(bn(y)) (masked) and y itself and forms d(y) = a1 g + a2 (y - mean) + a3 on the fly (awr_conv_args.in_bnb_y);
+    // d(y) is still written -- by an apply launch that travels with the weight gradient on its side stream
+    bool conv_out = false;
+    const float *lz_g = nullptr, *lz_lin4 = nullptr, *lz_mean = nullptr, *lz_invstd = nullptr, *lz_coef = nullptr;
     std::string name;
     int64_t npix() const { return (int64_t)B * H * W; }
     int64_t numel() const { return npix() * C; }
@@ -619,6 +625,7 @@ struct Op {
     int64_t lo = 0, hi = 0;   // OP_BUCKET
     int sid = 0;              // fork / join stream id
     bool side_ok = false;     // weight-gradient launch that may run on a side stream
+    bool pair_next = false;   // side_ok launch that shares the side stream of the NEXT side_ok launch (its producer: awr_bn_bwd_apply -> awr_conv_wgrad)
     bool gemm = false;        // conv / stem family (timed by run_timed)
     bool boundary = false;    // NCHW <-> NHWC bridge at the reference boundary: skipped while the plan's NHWC boundary is on
     double macs = 0.0;
@@ -861,6 +868,7 @@ struct Builder {
         const int B = x->B;
         const Prob prob = fwd_problem(spec, x->H, x->W);
         Tn* y = new_t(B, prob.Hout, prob.Wout, prob.N, true, layer->name + ".out");
+        y->conv_out = o.res == nullptr;      // (its gradient has exactly one reader pair: this conv's weight and data gradient)
         if (o.want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, (int)prob.phases.size()), prob.N);
         const float* bias = o.use_bias ? layer->bias_ptr() : nullptr;
         join_if(o.res);
@@ -1074,6 +1082,14 @@ struct Builder {
         wa->d_colsum = bsum;
         const std::string wname = "awr_conv_wgrad:" + layer->name;
         const double layer_macs = gemm_macs(fwd_problem(spec, H, W), B, spec);      // forward, data gradient and weight gradient cost the same
+        if (y->lz_g) {      // d(y) for the weight gradient: written on ITS stream, right in front of it (the data gradient below does not wait for it)
+            const float *g = y->lz_g, *yb = y->buf, *mean = y->lz_mean, *invstd = y->lz_invstd, *coef = y->lz_coef;
+            const int64_t npix = y->npix();
+            const int C = y->C;
+            Op& aop = b("awr_bn_bwd_apply", [=](void* s) { return awr_bn_bwd_apply_only(g, nullptr, yb, mean, invstd, nullptr, nullptr, coef, npix, C, dy, nullptr, nullptr, s); });
+            aop.side_ok = (res == nullptr);
+            aop.pair_next = true;
+        }
         Op& wop = b(wname, [wa](void* s) { return awr_conv_wgrad(wa, s); });      // (reference into the op vector: do not use after the next push)
         wop.gemm = true;
         wop.macs = layer_macs;
@@ -1123,7 +1139,8 @@ struct Builder {
             }
             P.cargs.emplace_back();
             awr_conv_args* da = &P.cargs.back();
-            fill_conv_args(*da, dp, B, dy, layer->p_dgrad.p, layer->p_dgrad.split, gx, spec.T());
+            fill_conv_args(*da, dp, B, y->lz_g ? y->lz_g : dy, layer->p_dgrad.p, layer->p_dgrad.split, gx, spec.T());
+            if (y->lz_g) { da->in_bnb_y = y->buf; da->in_bnb_coef = y->lz_lin4; }
             da->res = acc ? gx : nullptr;
             // remember who wrote d(x), in order: a full-coverage dgrad that is the LAST producer can host the fused BN-backward reduction
             P.grad_writers[x].push_back(dp.full ? da : nullptr);
@@ -1266,13 +1283,26 @@ struct Builder {
                 post_add = g_out;
             }
         }
+        // Off the critical chain (round 4): when the masked gradient g is already in memory (fused reduction, no residual: nobody accumulates
+        // into that buffer later) and y is a plain conv output, the data gradient of that conv evaluates the BatchNorm backward itself from
+        // (g, y) and four coefficient vectors -- only the small finalize stays between the two dependent data-gradient GEMMs; the apply pass
+        // that writes d(y) for the weight gradient is emitted by conv_bwd on the weight gradient's side stream.  AWR_NO_LAZY_BNB=1 = A/B hook.
+        static const bool no_lazy_bnb = getenv("AWR_NO_LAZY_BNB") != nullptr;
+        const bool lazy_bnb = !no_lazy_bnb && fused && relu && !res && !acc && !g_out && y->conv_out && y->needs_grad && C <= 512 &&
+                              awr_get_gemm_products() == 1 && awr_get_gemm_staging() == 2;
         {
             const float* gam = bn->gamma;
             float *gg = bn->ggamma, *gb = bn->gbeta;
             const float* dy_add = acc ? gy : nullptr;
-            b("awr_bn_bwd_apply", [=](void* s) {
-                return awr_bn_bwd_apply(da, act, yb, mean, invstd, gam, msc, msh, sp, coef, npix, C, gy, dy_add, g_out, gg, gb, 0, ns, s);
-            });
+            if (lazy_bnb) {
+                float* lin4 = alloc<float>(4 * (int64_t)C);
+                b("awr_bn_bwd_finalize", [=](void* s) { return awr_bn_bwd_finalize_lin(sp, C, npix, gam, mean, invstd, coef, lin4, gg, gb, 0, ns, s); });
+                y->lz_g = da; y->lz_lin4 = lin4; y->lz_mean = mean; y->lz_invstd = invstd; y->lz_coef = coef;
+            } else {
+                b("awr_bn_bwd_apply", [=](void* s) {
+                    return awr_bn_bwd_apply(da, act, yb, mean, invstd, gam, msc, msh, sp, coef, npix, C, gy, dy_add, g_out, gg, gb, 0, ns, s);
+                });
+            }
         }
         note_grad(bn->ggamma, C);
         note_grad(bn->gbeta, C);
@@ -1937,7 +1967,8 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         }
         int rc;
         if (wside && op.side_ok) {
-            hipStream_t st = P.side[nside++ % P.side.size()];
+            hipStream_t st = P.side[nside % P.side.size()];
+            if (!op.pair_next) ++nside;
             NET_CHECK(stream_wait(P, st, awr::as_stream(cur)));      // its operands (dY, x) are final at this point of the issuing chain
             rc = op.fn((void*)st);
             pending = true;

@@ -142,13 +142,20 @@ class AwrBackbone(nn.Module):
             self._counters.zero_()
 
     # ---- execution ----------------------------------------------------------------------------------
-    def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1):
+    def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1, accum=None):
+        """accum: None = the process-wide mode (awr_amd.set_gemm_accum), "ordered" / "blocked" = this plan's own (awr_conv_args.accum)."""
         if not self._arena.is_cuda:
             raise L.AwrError("the AWR backbone runs on the MI355X only: call .cuda() first (there is no CPU path)")
-        key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets, L.lib.awr_get_deterministic())
+        acc = int(L.lib.awr_get_gemm_accum()) if accum is None else {"ordered": 0, "blocked": 1}[accum]
+        key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets, L.lib.awr_get_deterministic(), acc)
         plan = self._plans.get(key)
         if plan is None:
-            plan = Plan(self, B, H, H // getattr(self, "downsample", 2), self.J, training, supervised, bn_repeat, n_buckets)
+            was = int(L.lib.awr_get_gemm_accum())
+            L.call("awr_set_gemm_accum", acc)          # plans capture the mode when they are built
+            try:
+                plan = Plan(self, B, H, H // getattr(self, "downsample", 2), self.J, training, supervised, bn_repeat, n_buckets)
+            finally:
+                L.call("awr_set_gemm_accum", was)
             self._plans[key] = plan
         return plan
 

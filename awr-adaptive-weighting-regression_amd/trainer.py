@@ -63,7 +63,9 @@ class GradSync:
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
-                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, _share=None):
+                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, accum=None, _share=None):
+        """accum: None (process-wide mode) | "ordered" | "blocked" -- accumulation order of the forward / data-gradient GEMMs of this engine's
+        plan (awr_amd.set_gemm_accum): "blocked" is the parity mode (a conv's rounding error at torch-CPU's level, a few % slower)."""
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -80,7 +82,7 @@ class TrainEngine:
         # (single GPU: scattering the packed weight gradients bucket by bucket during the backward, like the data-parallel plans do, instead
         # of in one launch at the tail of the step was measured slower: 14.28-14.32 vs 14.00-14.05 ms, profiles/r03_summary.md)
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
-                                 n_buckets=n_buckets if self.dp else 1)
+                                 n_buckets=n_buckets if self.dp else 1, accum=accum)
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data
         # parallel: one more stream that finished gradient buckets (scatter + all-reduce) are handed to
         self.plan.set_streams(wgrad_streams, comm=(wgrad_streams > 0 and self.dp))
@@ -392,10 +394,12 @@ TrainEngine.load_optimizer_state_dict = lambda self, sd: _load_opt_into(self, sd
 class InferEngine:
     """test.py:67-86 without the per-sample host loop: img -> dense map -> joints, eval-mode BN."""
 
-    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=False, autotune=True):
+    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=False, autotune=True, parity=False):
+        """parity=True: blocked accumulation in the GEMMs of this engine's plan (awr_amd.set_gemm_accum) -- scoring passes (test.py:67-86) care
+        about the last digits of the joints, not about the last few per cent of throughput."""
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         net.eval()
-        self.plan = net.get_plan(batch_size, img_size, False)
+        self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if parity else None)
         if self.plan.n_side == 0:          # forward branches (ResNet downsample projections, Hourglass skip residuals) run beside the main chain
             self.plan.set_streams(4)
         self._autotune, self._compiled = bool(autotune), False

@@ -232,6 +232,13 @@ typedef struct awr_conv_args {
     int N1x;                /* `out` and N = 2 N1 describe the second conv's output.  N1x > 0: the second conv's K extent continues with N1x */
                             /* channels of `in2` at the same pixel (no `res` then).  hourglass.py:44-59: conv2 -> bn3 -> ReLU -> conv3 + skip */
                             /* (identity skip = `res`; skip conv = [W3 | Wskip] over [intermediate | block input]) */
+    const float* in_bnb_y;  /* optional (data gradients): `in` is g = d(loss)/d(bn(y)) (ReLU mask already applied) of a BatchNorm whose backward is NOT */
+    const float* in_bnb_coef; /* materialised; the GEMM input is d(y) = a1 g + a2 (y - mean) + a3 per channel with y = in_bnb_y (same shape as `in`) and */
+                            /* coef = [a1 | a2 | a3 | mean][Cin] (awr_bn_bwd_finalize_lin), formed while the operand is fed to the matrix pipe; padding */
+                            /* taps stay zero.  Replaces the awr_bn_bwd_apply pass between two dependent data-gradient GEMMs.  LDS-DMA staging only */
+    int accum;              /* 0 = one k-ordered accumulation chain over the whole K extent (v_mfma_f32_32x32x2_f32 after v_mfma ...); 1 = BLOCKED: every */
+                            /* 128 k the running sum is folded into a second accumulator set and restarted (chains of 128 + K / 128 terms, the */
+                            /* rounding behaviour of oneDNN's blocked kernels that the reference's CPU numbers come from).  LDS-DMA staging, K > 256 */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
@@ -256,6 +263,11 @@ int awr_get_gemm_products(void);
  * Results are bit-identical between the two (same k order).  Replaces nothing in the reference. */
 int awr_set_gemm_staging(int mode);
 int awr_get_gemm_staging(void);
+/* Accumulation order of the forward / data-gradient GEMMs of plans created from now on (process-wide; default 0, or $AWR_ACCUM):
+ * 0 = ordered, 1 = blocked (awr_conv_args.accum).  Blocked costs a second accumulator set (one resident wave per SIMD on the wider tiles)
+ * and brings a convolution's rounding error down to torch-CPU's: the parity mode (InferEngine(parity=True), TrainEngine(accum="blocked")). */
+int awr_set_gemm_accum(int mode);
+int awr_get_gemm_accum(void);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).
@@ -357,6 +369,14 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
  * gamma*invstd][C], emit dgamma / dbeta, zero the sums (for fused consumers such as awr_stem_bwd_wgrad) */
 int awr_bn_bwd_finalize(double* sums, int C, int64_t count, const float* gamma, const float* invstd, float* coef,
                         float* dgamma, float* dbeta, int accumulate, int nslots, void* stream);
+/* awr_bn_bwd_finalize that ALSO writes lin4 = [a1 | a2 | a3 | mean][C] with d(y) = a1 g + a2 (y - mean) + a3: the form a consumer GEMM evaluates
+ * on the fly (awr_conv_args.in_bnb_y / in_bnb_coef) when d(y) is not written to HBM on the critical chain.  Same reference lines as above. */
+int awr_bn_bwd_finalize_lin(double* sums, int C, int64_t count, const float* gamma, const float* mean, const float* invstd, float* coef,
+                            float* lin4, float* dgamma, float* dbeta, int accumulate, int nslots, void* stream);
+/* second half of awr_bn_bwd_apply on its own: d(y) from coef (awr_bn_bwd_finalize / _lin), no reduction, no parameter gradients */
+int awr_bn_bwd_apply_only(const float* dout, const float* act, const float* y, const float* mean, const float* invstd,
+                          const float* mask_scale, const float* mask_shift, const float* coef, int64_t npix, int C, float* dy,
+                          const float* dy_add, float* g_out, void* stream);
 /* plain ReLU backward / mask: g = dout * (act > 0) */
 int awr_relu_bwd(const float* dout, const float* act, float* g, int64_t n, void* stream);
 /* out = a + b (n elements); out may alias a */

@@ -227,6 +227,67 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, t
             assert torch.equal(torch.nan_to_num(p, nan=-1234.0), torch.nan_to_num(q, nan=-1234.0)), i
 
 
+@pytest.mark.parametrize("accum", [0, 1])
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
+                                                              ("deconv", 64, 96, 4, 2, 1, 3, 10), ("conv", 96, 64, 1, 1, 0, 2, 12)])
+def test_dgrad_with_unmaterialised_batchnorm_backward(ops, L, dev, accum, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """awr_conv_args.in_bnb_y / in_bnb_coef: the data gradient of a conv whose output y feeds a BatchNorm takes g = d(loss)/d(bn(y)) and y
+    and forms d(y) = a1 g + a2 (y - mean) + a3 per channel on the operand's way to the matrix pipe (padding taps stay zero), instead of
+    reading a d(y) that a separate pass wrote.  Against float64 (conv_transpose / conv of the float64 d(y)), and against the same GEMM fed
+    with d(y) materialised by awr_bn_bwd_apply_only from the coefficients awr_bn_bwd_finalize_lin derives from reduction sums.
+    accum = 1: the blocked-accumulation instantiation of the same launches."""
+    import ctypes as C
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    ho = spec.out_hw(H, H)[0]
+    w = rnd(*((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)), seed=2, scale=0.05)
+    g, y = rnd(B, cout, ho, ho, seed=3), rnd(B, cout, ho, ho, seed=4) * 2.0 + 0.7
+    gamma = rnd(cout, seed=5) + 1.5
+    # reduction sums as the fused epilogue leaves them: sum g and sum g * xhat per channel (one slot)
+    mean = y.double().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.double().var((0, 2, 3), unbiased=False) + 1e-5)
+    xhat = (y.double() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    npix = B * ho * ho
+    dp = spec.dgrad_problem(H, H)
+    Cp = dp["Cin"]
+    sums = torch.zeros(16, 2, Cp, dtype=torch.float64)
+    sums[0, 0, :cout] = g.double().sum((0, 2, 3))
+    sums[0, 1, :cout] = (g.double() * xhat).sum((0, 2, 3))
+    dy_ref = (gamma.double() * invstd).view(1, -1, 1, 1) * (g.double() - (sums[0, 0, :cout] / npix).view(1, -1, 1, 1) - xhat * (sums[0, 1, :cout] / npix).view(1, -1, 1, 1))
+    gx_ref = (TF.conv_transpose2d(dy_ref, w.double(), None, stride, pad, output_padding=(H + 2 * pad - k) % stride) if kind == "conv"
+              else TF.conv2d(dy_ref, w.double(), None, stride, pad))
+
+    def padc(t, fill=0.0):      # NHWC with the channel padding of the GEMM's K extent
+        t = ops.nhwc(t)
+        return (torch.nn.functional.pad(t, (0, Cp - cout), value=fill) if Cp != cout else t).contiguous().to(dev)
+    g_d, y_d = padc(g), padc(y)
+    vec = lambda v, fill: torch.nn.functional.pad(v.float(), (0, Cp - cout), value=fill).to(dev)
+    mean_d, invstd_d, gamma_d = vec(mean, 0.0), vec(invstd, 1.0), vec(gamma, 1.0)
+    sums_d, coef, lin4 = sums.to(dev), torch.zeros(3, Cp, device=dev), torch.zeros(4, Cp, device=dev)
+    dgam, dbet = torch.zeros(Cp, device=dev), torch.zeros(Cp, device=dev)
+    L.call("awr_bn_bwd_finalize_lin", L.ptr(sums_d), Cp, npix, L.ptr(gamma_d), L.ptr(mean_d), L.ptr(invstd_d), L.ptr(coef), L.ptr(lin4), L.ptr(dgam), L.ptr(dbet), 0, 16, L.stream())
+    assert rel_err(dgam[:cout].cpu(), (g.double() * xhat).sum((0, 2, 3))) < 1e-5 and rel_err(dbet[:cout].cpu(), g.double().sum((0, 2, 3))) < 1e-5
+    assert float(sums_d.abs().max()) == 0.0          # the accumulator is re-armed
+    dy_mat = torch.empty_like(g_d)
+    L.call("awr_bn_bwd_apply_only", L.ptr(g_d), None, L.ptr(y_d), L.ptr(mean_d), L.ptr(invstd_d), None, None, L.ptr(coef), npix, Cp, L.ptr(dy_mat), None, None, L.stream())
+    assert rel_err(ops.nchw(dy_mat)[:, :cout].cpu(), dy_ref) < 2e-6
+    wd = ops.pack_weight(w.to(dev), spec.dgrad_pack())
+    outs = []
+    for lazy in (False, True):
+        out = torch.full((B, H, H, dp["N"]), float("nan"), device=dev)
+        if not dp["full"]:
+            out.zero_()
+        a = ops.make_conv_args(dp, B, g_d if lazy else dy_mat, wd, out, res=None if dp["full"] else out, T=spec.T)
+        a.tile_m, a.tile_n, a.accum = tm, tn, accum
+        if lazy:
+            a.in_bnb_y, a.in_bnb_coef = L.ptr(y_d), L.ptr(lin4)
+        L.call("awr_conv_gemm", C.byref(a), L.stream())
+        torch.cuda.synchronize()
+        outs.append(ops.nchw(out)[:, :cin].cpu())
+        assert rel_err(outs[-1], gx_ref) < 3e-6, lazy
+    assert rel_err(outs[1], outs[0]) < 2e-6
+
+
 def test_conv_fused_prologue_epilogue_stats(ops, dev):
     """conv( relu(x*s+t) ) * so + to + res -> relu, with per-channel statistics of the pre-ReLU value."""
     B, H, cin, cout = 2, 16, 64, 96           # N = 96: not a multiple of the 64/128 tile

@@ -100,7 +100,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -130,6 +130,22 @@ def main():
                     continue
                 res.append("%s %5.1f|%5.1f" % (tile, run_fwd(spec, B, H, tile)[1], run_fwd(spec, B, H, tile, stats=True)[1]))
             print("%-26s %s" % (name, "  ".join(res)), flush=True)
+    elif args.mode == "wgradset":    # workgroup-per-tap weight gradient, every tile x split-K candidate of the plan autotuner; plain and with the
+        B = args.batch                # un-materialised BatchNorm loader on the layer input (AWR_WGRAD_DMA / AWR_WGRAD_KP: one process per variant)
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8),
+                  ("layer2.0 3x3s2 64->128 @64", ops.ConvSpec("conv", 64, 128, 3, 2, 1), 64), ("deconv 512->256 @8", ops.ConvSpec("deconv", 512, 256, 4, 2, 1), 8),
+                  ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32), ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64),
+                  ("hg 1x1 256->128 @64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 64), ("hg 1x1 128->256 @64", ops.ConvSpec("conv", 128, 256, 1, 1, 0), 64)]
+        print("AWR_WGRAD_DMA=%s AWR_WGRAD_KP=%s batch %d: TF per (tile/blocks), plain | affine loader" % (os.environ.get("AWR_WGRAD_DMA", "1"), os.environ.get("AWR_WGRAD_KP", "0"), B))
+        for name, spec, H in shapes:
+            res = []
+            pr = spec.wgrad_problem(H, H)
+            for tile, blocks in (((1, 1), 2048), ((1, 1), 3072), ((1, 1), 4096), ((2, 1), 1536), ((2, 1), 2048), ((1, 2), 2048)):
+                if (tile[0] == 2 and pr["Cd"] <= 64) or (tile[1] == 2 and pr["Cg"] <= 64):
+                    continue
+                res.append("%s/%d %5.1f|%5.1f" % (tile, blocks, run_wgrad(spec, B, H, tile, algo=1, blocks=blocks)[1], run_wgrad(spec, B, H, tile, algo=1, blocks=blocks, affine=True)[1]))
+            print("%-28s %s" % (name, "  ".join(res)), flush=True)
     elif args.mode == "tiles":       # forward only, every tile, a few representative layers (used by tools/probe_gemm.sh)
         B = args.batch
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16),
