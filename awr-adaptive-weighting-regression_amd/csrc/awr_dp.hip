@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <set>
+#include <vector>
 
 #include <rccl/rccl.h>      // types and prototypes only: every call goes through the pointers below
 
@@ -31,13 +33,15 @@ struct Api {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
     char path[256] = "";
+    char err[256] = "";       // why the library could not be opened (dlerror() right after the failed call: the next dl* call clears it)
 };
 
+static Api g_api;
 static Api* api() {
-    static Api a;
+    Api& a = g_api;
     static std::once_flag once;
     static bool ok = false;
-    std::call_once(once, []() {
+    std::call_once(once, [&a]() {
         // the copy the process already holds (a framework's) first, then the system's; AWR_RCCL_LIB overrides
         const char* env = getenv("AWR_RCCL_LIB");
         const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -48,6 +52,10 @@ static Api* api() {
                 if (a.handle) {
                     strncpy(a.path, n, sizeof a.path - 1);
                     break;
+                }
+                if (pass == 1) {
+                    const char* e = dlerror();
+                    if (e) strncpy(a.err, e, sizeof a.err - 1);
                 }
             }
         if (!a.handle) return;
@@ -61,6 +69,7 @@ static Api* api() {
         AWR_SYM(GetVersion, "ncclGetVersion");
 #undef AWR_SYM
         ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.Broadcast && a.GetErrorString;
+        if (!ok) snprintf(a.err, sizeof a.err, "%s lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / Broadcast / GetErrorString", a.path);
     });
     return ok ? &a : nullptr;
 }
@@ -71,16 +80,27 @@ struct awr_dp {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;      // the collectives' own stream: they never queue in front of the plan's weight-gradient launches
-    hipEvent_t ev[64];
-    unsigned ev_next = 0;
+    // ordering events: one per hand-over since the last awr_dp_wait, created on demand (a host that exchanges tensor by tensor -- 458 for
+    // Hourglass-2 -- must not wrap a fixed ring onto an event whose wait has not been enqueued yet); awr_dp_wait starts the list over
+    // (hipStreamWaitEvent captures the record it waits for when it is called: re-recording afterwards is safe)
+    std::vector<hipEvent_t> ev;
+    size_t ev_next = 0;
 };
+
+// live communicators: a plan keeps a raw pointer (awr_plan_set_dp) and must not call into one its host has destroyed
+static std::mutex g_live_mu;
+static std::set<const awr_dp*> g_live;
+extern "C" int awr_dp_is_live(const awr_dp* d) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return g_live.count(d) ? 1 : 0;
+}
 
 using namespace awrdp;
 
 #define DP_API()                                                                                                             \
     Api* A = api();                                                                                                          \
     if (!A) {                                                                                                                \
-        set_error("data parallel: librccl.so could not be opened (set AWR_RCCL_LIB to its path): %s", dlerror() ? dlerror() : "missing symbols"); \
+        set_error("data parallel: librccl.so could not be used (set AWR_RCCL_LIB to its path): %s", awrdp::g_api.err[0] ? awrdp::g_api.err : "not found"); \
         return AWR_ERR_UNSUPPORTED;                                                                                          \
     }
 #define DP_TRY(call)                                                        \
@@ -135,14 +155,16 @@ int awr_dp_init(int rank, int world, const void* id128, awr_dp** out) {
         delete d;
         return AWR_ERR_HIP;
     }
-    for (auto& e : d->ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     const ncclResult_t r = A->CommInitRank(&d->comm, world, id, rank);      // collective: every rank of the job calls it (current device)
     if (r != ncclSuccess) {
         set_error("ncclCommInitRank(rank %d of %d): %s", rank, world, A->GetErrorString(r));
-        for (auto& e : d->ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(d->stream);
         delete d;
         return AWR_ERR_HIP;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.insert(d);
     }
     *out = d;
     return AWR_OK;
@@ -150,6 +172,13 @@ int awr_dp_init(int rank, int world, const void* id128, awr_dp** out) {
 
 int awr_dp_destroy(awr_dp* d) {
     if (!d) return AWR_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!g_live.erase(d)) {
+            set_error("dp_destroy: not a live communicator (destroyed twice?)");
+            return AWR_ERR_ARG;
+        }
+    }
     Api* A = api();
     (void)hipStreamSynchronize(d->stream);
     if (A && d->comm) (void)A->CommDestroy(d->comm);
@@ -168,8 +197,18 @@ int awr_dp_info(const awr_dp* d, int* rank, int* world, int* device) {
 }
 
 // `buf` is final in `stream` order -> collective on the communicator's stream behind an event; awr_dp_wait orders a stream after it
+static int next_event(awr_dp* d, hipEvent_t* out) {
+    if (d->ev_next == d->ev.size()) {
+        hipEvent_t e;
+        DP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->ev.push_back(e);
+    }
+    *out = d->ev[d->ev_next++];
+    return AWR_OK;
+}
 static int order_behind(awr_dp* d, hipStream_t stream) {
-    hipEvent_t e = d->ev[d->ev_next++ % 64];
+    hipEvent_t e;
+    if (int rc = next_event(d, &e)) return rc;
     DP_HIP(hipEventRecord(e, stream));
     DP_HIP(hipStreamWaitEvent(d->stream, e, 0));
     return AWR_OK;
@@ -193,9 +232,11 @@ int awr_dp_broadcast(awr_dp* d, float* buf, int64_t n, int root, void* stream) {
 
 int awr_dp_wait(awr_dp* d, void* stream) {
     AWR_REQUIRE(d, "dp_wait: null pointer");
-    hipEvent_t e = d->ev[d->ev_next++ % 64];
+    hipEvent_t e;
+    if (int rc = next_event(d, &e)) return rc;
     DP_HIP(hipEventRecord(e, d->stream));
     DP_HIP(hipStreamWaitEvent(awr::as_stream(stream), e, 0));
+    d->ev_next = 0;      // every wait on the events handed out so far has been enqueued: the list starts over
     return AWR_OK;
 }
 

@@ -737,7 +737,9 @@ static int log2_exact(int v) {
 static int nhwc_geometry(int B, int J, int F, int H, int Cp, int* chunks, int* tiles_per_wg) {
     if (int e = check_head_dims(B, J, F, H)) return e;
     AWR_REQUIRE(J <= 64, "head (NHWC): at most 64 joints (got %d)", J);
-    AWR_REQUIRE(Cp >= 4 * J && Cp % 32 == 0 && Cp <= 256, "head (NHWC): Cp=%d must be a multiple of 32 in [4J, 256]", Cp);
+    // (64 (Cp + 4) + 64) floats of dynamic LDS per workgroup must stay below the 64 KB a launch gets without opting in: Cp <= 224, i.e. J <= 56;
+    // wider maps take the NCHW kernels (awr_plan_set_nhwc_boundary refuses, the engines fall back)
+    AWR_REQUIRE(Cp >= 4 * J && Cp % 32 == 0 && Cp <= 224, "head (NHWC): Cp=%d must be a multiple of 32 in [4J, 224]", Cp);
     AWR_REQUIRE(Cp <= 4 * (J <= 16 ? 16 : J <= 32 ? 32 : 64), "head (NHWC): Cp=%d too wide for %d joints (expected 4J rounded up to 32)", Cp, J);
     const int P = F * F;
     AWR_REQUIRE(P % TPX == 0, "head (NHWC): F*F must be a multiple of %d", TPX);

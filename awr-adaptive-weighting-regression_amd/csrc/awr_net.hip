@@ -29,6 +29,8 @@
 
 #include "awr_common.h"
 
+extern "C" int awr_dp_is_live(const awr_dp* d);      // csrc/awr_dp.hip: the registry of communicators that have not been destroyed
+
 namespace awrnet {
 
 using awr::set_error;
@@ -607,6 +609,7 @@ struct Tn {
     // gradient reads g = d(loss)/d(bn(y)) (masked) and y itself and forms d(y) = a1 g + a2 (y - mean) + a3 on the fly (awr_conv_args.in_bnb_y);
     // d(y) is still written -- by an apply launch that travels with the weight gradient on its side stream
     bool conv_out = false;
+    int conv_taps = 0;
     const float *lz_g = nullptr, *lz_lin4 = nullptr, *lz_mean = nullptr, *lz_invstd = nullptr, *lz_coef = nullptr;
     std::string name;
     int64_t npix() const { return (int64_t)B * H * W; }
@@ -869,6 +872,7 @@ struct Builder {
         const Prob prob = fwd_problem(spec, x->H, x->W);
         Tn* y = new_t(B, prob.Hout, prob.Wout, prob.N, true, layer->name + ".out");
         y->conv_out = o.res == nullptr;      // (its gradient has exactly one reader pair: this conv's weight and data gradient)
+        y->conv_taps = spec.T();
         if (o.want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, (int)prob.phases.size()), prob.N);
         const float* bias = o.use_bias ? layer->bias_ptr() : nullptr;
         join_if(o.res);
@@ -1286,10 +1290,15 @@ struct Builder {
         // Off the critical chain (round 4): when the masked gradient g is already in memory (fused reduction, no residual: nobody accumulates
         // into that buffer later) and y is a plain conv output, the data gradient of that conv evaluates the BatchNorm backward itself from
         // (g, y) and four coefficient vectors -- only the small finalize stays between the two dependent data-gradient GEMMs; the apply pass
-        // that writes d(y) for the weight gradient is emitted by conv_bwd on the weight gradient's side stream.  AWR_NO_LAZY_BNB=1 = A/B hook.
-        static const bool no_lazy_bnb = getenv("AWR_NO_LAZY_BNB") != nullptr;
-        const bool lazy_bnb = !no_lazy_bnb && fused && relu && !res && !acc && !g_out && y->conv_out && y->needs_grad && C <= 512 &&
-                              awr_get_gemm_products() == 1 && awr_get_gemm_staging() == 2;
+        // that writes d(y) for the weight gradient is emitted by conv_bwd on the weight gradient's side stream.
+        // Measured (profiles/r04_bn_bwd_lazy.txt) and NOT the default: the implicit GEMM re-stages every input element once per tap, so a 3x3
+        // data gradient pays the arithmetic and the second tensor's traffic NINE times (ResNet18 13.28 -> 14.2 ms, Hourglass-1 24.1 -> 25.9 ms
+        // with every eligible BatchNorm); restricted to single-tap (1x1) convolutions it is a wash (Hourglass-1 23.9 vs 24.1 ms).  The upper
+        // bound -- the step with the apply passes simply left out -- is 12.76 / 21.7 ms, so the pass IS exposed, but the consumer is the
+        // wrong place to hide it.  AWR_LAZY_BNB: 0 = never (default), 1 = 1x1 convolutions, 2 = every eligible BatchNorm.
+        const int lazy_mode = env_or("AWR_LAZY_BNB", 0);
+        const bool lazy_bnb = lazy_mode > 0 && fused && relu && !res && !acc && !g_out && y->conv_out && (lazy_mode > 1 || y->conv_taps == 1) && y->needs_grad &&
+                              C <= 512 && awr_get_gemm_products() == 1 && awr_get_gemm_staging() == 2;
         {
             const float* gam = bn->gamma;
             float *gg = bn->ggamma, *gb = bn->gbeta;
@@ -1983,6 +1992,11 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
         if (comm) NET_CHECK(stream_wait(P, main, comm));      // next step's scratch fill / optimiser must see the scatters
     }
+    if (is_bwd && P.dp && !P.dp_error && !awr_dp_is_live(P.dp)) {
+        P.dp = nullptr;
+        set_error("plan: the data-parallel communicator attached with awr_plan_set_dp has been destroyed (detach it with awr_plan_set_dp(plan, NULL) first)");
+        return AWR_ERR_ARG;
+    }
     if (is_bwd && P.dp && P.n_buckets <= 1 && !P.dp_error)        // a one-bucket plan has no markers: one exchange after the backward
         P.dp_error = awr_dp_allreduce(P.dp, P.net->grads, P.net->layout.n_active, stream);
     if (is_bwd && P.dp) NET_CHECK(awr_dp_wait(P.dp, stream));      // ... and the reduced gradients
@@ -2254,6 +2268,10 @@ int awr_plan_head_nhwc(const awr_plan* p, int stage, const float** pred, float**
 
 int awr_plan_set_nhwc_boundary(awr_plan* p, int on) {
     AWR_REQUIRE(p, "plan_set_nhwc_boundary: null pointer");
+    if (on && p->net->J > 56) {      // Cp = 4J rounded up to 32 > 224: the NHWC head kernels' LDS tile would exceed 64 KB (awr_head.hip: nhwc_geometry)
+        set_error("plan_set_nhwc_boundary: the NHWC head / loss kernels serve at most 56 joints (got %d): use the NCHW boundary", p->net->J);
+        return AWR_ERR_UNSUPPORTED;
+    }
     if (on && p->training) {
         for (size_t s = 0; s < p->head_grads.size(); ++s)
             if ((p->supervised & (1u << s)) && !p->head_grads[s]) {
@@ -2340,7 +2358,12 @@ static StreamPool& stream_pool() {
     std::vector<hipStream_t> cand;
     for (int i = 0; i < NC; ++i) {
         hipStream_t s;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        // AWR_SIDE_PRIORITY=low: the side / branch streams (weight gradients, forked branches) yield to the caller's stream, so that the
+        // dependent chain on it runs at solo speed and the side work fills what it leaves (same-box A/B hook)
+        static const bool low_prio = []() { const char* e = getenv("AWR_SIDE_PRIORITY"); return e && e[0] == 'l'; }();
+        int least = 0, greatest = 0;
+        if (low_prio) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if ((low_prio ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
         cand.push_back(s);
     }
     hipEvent_t e0, e1, eb;
@@ -2420,9 +2443,16 @@ int awr_plan_set_bucket_callback(awr_plan* p, awr_bucket_cb cb, void* user) {
 }
 
 // the plan's own bucket callback while a communicator is attached: gradient arena [lo, hi) is final in `stream` order
+static int dp_dead(awr_plan* p) {      // the host destroyed the communicator before detaching it (awr_plan_set_dp(plan, NULL)): fail, do not dereference
+    if (awr_dp_is_live(p->dp)) return 0;
+    awr::set_error("plan: the data-parallel communicator attached with awr_plan_set_dp has been destroyed (detach it with awr_plan_set_dp(plan, NULL) first)");
+    p->dp = nullptr;
+    return AWR_ERR_ARG;
+}
 static void dp_bucket(void* user, int64_t lo, int64_t hi, void* stream) {
     awr_plan* p = static_cast<awr_plan*>(user);
-    if (p->dp_error) return;
+    if (p->dp_error || !p->dp) return;
+    if ((p->dp_error = dp_dead(p))) return;
     p->dp_error = awr_dp_allreduce(p->dp, p->net->grads + lo, hi - lo, stream);
 }
 

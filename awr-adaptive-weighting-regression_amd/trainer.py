@@ -290,10 +290,16 @@ class TrainEngine:
             del self._trace[:]
             self._tev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             self._tev[0].record()
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self._core()
+        try:
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._core()
+        except Exception:
+            # the NHWC loss call ADDS onto self.acc and only awr_loss_finalize_reset re-arms it: a step that dies between the two would
+            # leave the next step's losses inflated
+            self.acc.zero_()
+            raise
         if self.trace_buckets:
             self._tev[1].record()
         self.net._counters += plan.bn_repeat          # num_batches_tracked of every BatchNorm (host side)

@@ -102,8 +102,9 @@ int awr_dense_loss(const float* offset_pred, const float* jt_gt, const float* im
  * awr_head_loss_step_nhwc = train.py:118-127 in one call: joints + (max, sum) statistics, the coordinate Huber loss (acc[0] +=
  * coord_weight * mean) and, when coord_weight != 0, its gradient through the head; the fused GT map + dense Huber loss (acc[1] +=
  * dense_weight * mean; util/feature_tool.py:12-39, model/loss.py:8-25); the total gradient w.r.t. the dense map written (not
- * accumulated) to grad.  coord_weight == 0 reads the map once (one pass + a merge kernel), otherwise twice.  acc: two doubles, zeroed
- * by the caller (awr_zero_f64) and read back with awr_loss_finalize. */
+ * accumulated) to grad.  coord_weight == 0 reads the map once (one pass + a merge kernel), otherwise twice.  acc: two doubles the call
+ * ADDS onto; they must be zero on entry -- zeroed once by the caller (awr_zero_f64), afterwards by awr_loss_finalize_reset, which reads
+ * the losses out and re-arms the accumulator in the same launch (a step that fails between the two calls must zero acc itself). */
 int64_t awr_head_nhwc_scratch(int B, int J, int F);
 int awr_head_forward_nhwc(const float* pred, int Cp, const float* img, int B, int J, int F, int H, float ks, float* scratch,
                           float* jt, float* stat /* optional */, void* stream);
@@ -508,7 +509,8 @@ int awr_dp_allreduce(awr_dp* dp, float* buf, int64_t n, void* stream);          
 int awr_dp_broadcast(awr_dp* dp, float* buf, int64_t n, int root, void* stream);     /* in place */
 int awr_dp_wait(awr_dp* dp, void* stream);
 /* dp != NULL: the plan's gradient buckets (n_buckets of awr_plan_create; 1 = one exchange after the backward) go through `dp`;
- * NULL detaches.  Replaces the bucket callback while set. */
+ * NULL detaches.  Replaces the bucket callback while set.  Lifetime: the plan keeps the pointer, not a reference -- detach (NULL) before
+ * awr_dp_destroy; a backward that finds its communicator destroyed fails with AWR_ERR_ARG instead of calling into it. */
 int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
 
 #ifdef __cplusplus
