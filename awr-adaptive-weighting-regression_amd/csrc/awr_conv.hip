@@ -260,9 +260,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
         // bias and folded-BatchNorm affine as ONE fused multiply-add per element, applied unconditionally: (v + b) s + t = v s + (b s + t);
         // without either it is v * 1 + 0 (exact), with a bias only v * 1 + b (exact) -- two packed instructions per row instead of the twelve
         // (two adds, two fmas, eight selects on the uniform flags) the compiler made of the two optional steps
-        float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
-        float4 osh = (a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
-        if (a.bias && nok) {
+        constexpr bool OAFF = EM < 3;      // (the reduction epilogues belong to data gradients: no bias, no folded BatchNorm -- their eight registers stay free)
+        float4 osc = (OAFF && a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
+        float4 osh = (OAFF && a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
+        if (OAFF && a.bias && nok) {
             const float4 bias = ld4(a.bias + n0);
             osh.x = bias.x * osc.x + osh.x; osh.y = bias.y * osc.y + osh.y; osh.z = bias.z * osc.z + osh.z; osh.w = bias.w * osc.w + osh.w;
         }
@@ -286,7 +287,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 float4 v = ld4(tbuf + row * LDK + 4 * c4);
                 const bool valid = nok && orow[i][q] != OOB;
                 const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
-                v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w;
+                if constexpr (OAFF) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                 if (res_on) {
                     const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // stage, no store phase, no staging registers.  DREG / GREG: that operand still travels through registers (fused BatchNorm + ReLU loader of
 // a never-materialised activation; the bias-gradient column sums need D in registers as well).
 template <int TM, int TN, int KP, bool DREG, bool GREG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? 5 : TM * TN == 2 ? 4 : 2))) void conv_wgrad_dma_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? 5 : TM * TN == 2 ? 4 : 3))) void conv_wgrad_dma_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int FM = BM / 4, FN = BN / 4;          // 16-byte chunks per pixel row
     constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows per 4 KB pass of the 256 threads
@@ -1641,6 +1642,197 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
             } else {
                 float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
                 atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of 3x3 stride-1 convolutions, one workgroup per KERNEL ROW (round 4)
+// ------------------------------------------------------------------------------------------
+// The workgroup-per-tap kernels give every tap its own workgroup: the nine taps of a filter each stream the same D pixels and a shifted
+// window of the same G pixels (PMC: ~4.5x the algorithmic bytes), a 64x64 tile has ONE accumulator per wave -- every MFMA waits for the
+// previous one (SQ_WAIT_INST_ANY 66 % of the wave cycles) -- and two LDS reads feed each MFMA.  Here a workgroup owns a 64x64 (cd x cg) tile
+// for the THREE taps of one kernel row (ty): a K-stage is 16 consecutive D pixels -- one row segment of 16 pixels, or two rows of an 8-wide
+// map -- and the G pixels of the same rows shifted by ty - 1, with one halo pixel on either side (PH x (PW + 2) pixel rows; pixels outside
+// the image are out-of-range DMA sources: zeros).  The B fragment of tap tx for D pixel p is the G pixel at row position p + tx: the three
+// taps read three consecutive positions, and position p + 2 of one pixel pair is position p' + 0 of the next -- per pixel pair ONE A read
+// and TWO new B reads feed THREE MFMAs into three independent accumulators.  Operands go global -> LDS by DMA (pixel-major rows: lane-linear,
+// no swizzle, as in conv_wgrad_dma_kernel), two stages in flight, one barrier per stage.
+//   GAFF: G is relu(g * scale + shift) of the stored tensor (a BatchNorm + ReLU output that was never written): per-lane constants (lane =
+//   channel) applied to the B fragments; halo / padding pixels must stay zero THROUGH the affine -- row validity is uniform per stage, the
+//   two halo columns only matter at the image's left / right edge (a per-lane 0 / 1 factor: the pair's two pixels sit in the two half-waves).
+//   The bias gradient (column sums of D = dY) is the sum of the A fragments over the stage's pixels: no register path for D either.
+template <int PW, bool GAFF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
+    constexpr int KP = 16;                           // D pixels per stage
+    constexpr int PH = KP / PW;                      // rows per stage (1 | 2)
+    constexpr int GW = PW + 2, GP = PH * GW;         // G pixel rows per stage: 18 | 20
+    constexpr int DST = KP * 64 * 4;                 // bytes of the D stage (4 KB)
+    constexpr int GST = 20 * 64 * 4;                 // ... of the G stage (five 1 KB DMA pieces)
+    constexpr int STAGE = DST + GST;
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * STAGE];
+
+    const int tiles_cg = (a.Cg + 63) >> 6, tiles_cd = (a.Cd + 63) >> 6;
+    int wg = blockIdx.x;
+    const int tcg = wg % tiles_cg; wg /= tiles_cg;
+    const int tcd = wg % tiles_cd; wg /= tiles_cd;
+    const int ty = wg;                               // kernel row 0..2
+    const int W = a.Wd, H = a.Hd;
+    const int segs_x = W / PW;                       // stages per image row (PH == 1) -- W >= PW, both powers of two
+    const int nstage = PH == 1 ? a.B * H * segs_x : a.B * (H / PH);
+    const int s_begin = blockIdx.y * stages_per_wg;
+    int s_end = s_begin + stages_per_wg;
+    if (s_end > nstage) s_end = nstage;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ch4 = (lane & 15) * 4;                 // this lane's 4 channels of a staged pixel row
+    const bool d_cok = tcd * 64 + ch4 < a.Cd, g_cok = tcg * 64 + ch4 < a.Cg;
+    const i32x4 rw_d = make_rsrc_words(a.D, (unsigned)a.B * H * W * a.Cd * 4u), rw_g = make_rsrc_words(a.G, (unsigned)a.B * H * W * a.Cg * 4u);
+    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
+    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
+    const unsigned d_col = (unsigned)(tcd * 64 + ch4) * 4u, g_col = (unsigned)(tcg * 64 + ch4) * 4u;
+    // staging roles, fixed for the kernel: D piece `wave` = pixels 4 wave .. 4 wave + 3 of the stage; G pieces `wave` and (wave 0 only) 4
+    const int dpx = 4 * wave + (lane >> 4);
+    int g_r[2], g_j[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = 4 * (i == 0 ? wave : 4) + (lane >> 4);
+        g_r[i] = slot < GP ? slot / GW : -(1 << 20);      // (a slot beyond the patch: always out of range)
+        g_j[i] = slot % GW;
+    }
+    unsigned edge_l = 1, edge_r = 1, rowmask = 3;        // the stage being MULTIPLIED: left / right halo column inside the image, rows inside
+    unsigned n_edge_l = 1, n_edge_r = 1, n_rowmask = 3;  // ... the stage being REQUESTED
+    auto issue = [&](int st, int buf) {
+        int b, y0, x0;
+        if constexpr (PH == 1) {
+            x0 = (st & (segs_x - 1)) * PW;
+            const int t = st >> (wlog - (PW == 16 ? 4 : 3));
+            y0 = t & (H - 1);
+            b = t >> hlog;
+        } else {
+            x0 = 0;
+            const int rows = H / PH;
+            y0 = (st & (rows - 1)) * PH;
+            b = st >> (hlog - 1);
+        }
+        const unsigned Dl = lds0 + (unsigned)(buf * STAGE), Gl = lds0 - (unsigned)wave * 1024u + (unsigned)(buf * STAGE + DST);
+        {
+            const int r = dpx / PW, c = dpx % PW;
+            const unsigned pix = (unsigned)((((b << hlog) + y0 + r) << wlog) + x0 + c);
+            dma16(rw_d, Dl, d_cok ? __umul24(pix, dpitch) + d_col : OOB);
+        }
+        const int gy0 = y0 + ty - 1;
+        n_rowmask = 0;
+#pragma unroll
+        for (int r = 0; r < PH; ++r) n_rowmask |= ((unsigned)(gy0 + r) < (unsigned)H) ? (1u << r) : 0u;
+        n_edge_l = x0 > 0;
+        n_edge_r = x0 + PW < W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && wave != 0) break;          // (wave-uniform: the fifth piece belongs to wave 0)
+            const int gy = gy0 + g_r[i], gx = x0 - 1 + g_j[i];
+            const bool ok = g_cok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned pix = (unsigned)((((b << hlog) + gy) << wlog) + gx);
+            dma16(rw_g, Gl + (unsigned)((i == 0 ? wave : 4) * 1024), ok ? __umul24(pix, gpitch) + g_col : OOB);
+        }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float gsc = 1.f, gsh = 0.f;
+    if (GAFF && tcg * 64 + wn * 32 + l31 < a.Cg) { gsc = a.g_scale[tcg * 64 + wn * 32 + l31]; gsh = a.g_shift[tcg * 64 + wn * 32 + l31]; }
+    const float g_lo = a.g_relu ? 0.f : -__builtin_inff();
+    const bool do_colsum = a.d_colsum != nullptr && ty == 0 && tcg == 0 && wn == 0;
+    float csum = 0.f;
+    const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * 64 + wm * 32 + l31;               // D[pixel][cd]
+    const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * 64 + wn * 32 + l31;         // G[patch pixel][cg]
+    auto compute = [&](int buf) {
+        // per-lane 0 / 1 factors of the two halo columns: position 0 is read by the half-wave h = 0 of the row's first pixel pair (tap 0),
+        // position PW + 1 by h = 1 of its last pair (tap 2)
+        const float lmul = (GAFF && half == 0 && !edge_l) ? 0.f : 1.f, rmul = (GAFF && half == 1 && !edge_r) ? 0.f : 1.f;
+        auto gread = [&](int r, int pos) -> float {      // G position `pos` (0 = left halo) of patch row r for this lane's half: pos + half
+            float v = b_frag[buf * (STAGE / 4) + (r * GW + pos) * 64];
+            if constexpr (GAFF) {
+                v = __builtin_amdgcn_fmed3f(v * gsc + gsh, g_lo, __builtin_inff());
+                if (!(rowmask & (1u << r))) v = 0.f;                 // (uniform) the whole G row is outside the image
+                if (pos == 0) v *= lmul;
+                if (pos == PW) v *= rmul;                            // (pos + half == PW + 1 for half = 1)
+            }
+            return v;
+        };
+#pragma unroll
+        for (int r = 0; r < PH; ++r) {
+            float b0 = gread(r, 0);
+#pragma unroll
+            for (int kp = 0; kp < PW / 2; ++kp) {
+                const float fa = a_frag[buf * (STAGE / 4) + (r * PW + 2 * kp) * 64];
+                const float b1 = gread(r, 2 * kp + 1), b2 = gread(r, 2 * kp + 2);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b2, acc[2], 0, 0, 0);
+                if (do_colsum) csum += fa;
+                b0 = b2;
+                // (left alone the scheduler hoists all 25 fragment reads of the stage in front of its MFMAs: 130 registers; a fence
+                // every second pixel pair keeps two pairs of reads in flight ahead of the matrix instructions)
+                if (kp & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto stage_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait();
+        __syncthreads();
+    };
+    if (s_begin < s_end) {
+        issue(s_begin, 0);
+        stage_done();
+        for (int st = s_begin; st < s_end; st += 2) {
+            edge_l = n_edge_l; edge_r = n_edge_r; rowmask = n_rowmask;
+            const bool more1 = st + 1 < s_end;
+            if (more1) issue(st + 1, 1);
+            compute(0);
+            if (!more1) break;
+            stage_done();
+            edge_l = n_edge_l; edge_r = n_edge_r; rowmask = n_rowmask;
+            const bool more2 = st + 2 < s_end;
+            if (more2) issue(st + 2, 0);
+            compute(1);
+            if (more2) stage_done();
+        }
+    }
+    {
+        const int cg = tcg * 64 + wn * 32 + l31;
+        float* const Rw = a.R + (a.split_stride ? (int64_t)blockIdx.y * a.split_stride : 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = tcd * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (cd < a.Cd && cg < a.Cg) {
+                    const unsigned off = (unsigned)((cd * 9 + ty * 3 + j) * a.ld + cg);       // (R holds Cd x 9 x ld < 2^31 floats)
+                    if (a.split_stride) Rw[off] = acc[j][r];
+                    else atomicAdd(Rw + off, acc[j][r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (a.d_colsum != nullptr && ty == 0 && tcg == 0) {      // (uniform per workgroup) lane (l31, half) of the wn = 0 waves holds its channel's sum over its half's pixels
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (wn == 0) red[wm * 64 + lane] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            const int cd = tcd * 64 + tid;
+            const float t = red[(tid >> 5) * 64 + (tid & 31)] + red[(tid >> 5) * 64 + 32 + (tid & 31)];
+            if (cd < a.Cd) {
+                if (a.split_stride) a.d_colsum[(size_t)blockIdx.y * a.Cd + cd] = t;
+                else atomicAdd(a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + cd, t);
             }
         }
     }
@@ -2178,6 +2370,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(!a->bnr_y || (a->bnr_coef && a->stats && (!a->res || (a->bnr_act && a->res == a->out))),
                 "conv_gemm: fused BN-backward reduction needs coef + stats; accumulating (res) only in place and with bnr_act");
     AWR_REQUIRE(!a->bnr_act || a->bnr_y, "conv_gemm: bnr_act without bnr_y");
+    AWR_REQUIRE(!a->bnr_y || (!a->bias && !a->out_scale), "conv_gemm: the fused BatchNorm-backward reduction belongs to a data gradient: no bias / output affine");
     AWR_REQUIRE(!a->bnr2_y || (a->bnr_y && a->bnr2_coef && a->stats2), "conv_gemm: a second fused reduction (bnr2_y) needs bnr_y, bnr2_coef and stats2");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
@@ -2297,6 +2490,7 @@ static int wgrad_taps_patch_rows(const awr_wgrad_args* a) {
 // launch geometry of one weight-gradient problem: algorithm, tile, split-K depth.  Shared by the launch and by
 // awr_conv_wgrad_splits (a deterministic-mode caller sizes its per-chunk copies of R with it)
 struct wgrad_launch {
+    int row_pw;         // > 0: one-workgroup-per-kernel-row kernel (3x3 stride 1), segments of this many pixels (8 | 16)
     int taps_ph;        // > 0: one-wave-per-tap kernel with this patch height
     int TM, TN, tiles;
     int64_t nsplit, chunk;
@@ -2308,7 +2502,7 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
     AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),
                 "conv_wgrad: scale/shift must come in pairs");
-    AWR_REQUIRE(a->algo >= 0 && a->algo <= 2, "conv_wgrad: algo must be 0 (automatic), 1 (workgroup per tap) or 2 (wave per tap)");
+    AWR_REQUIRE(a->algo >= 0 && a->algo <= 3, "conv_wgrad: algo must be 0 (automatic), 1 (workgroup per tap), 2 (wave per tap) or 3 (workgroup per kernel row)");
     AWR_REQUIRE(a->split_stride >= 0 && (a->split_stride == 0 || a->max_split >= 1), "conv_wgrad: split_stride > 0 (deterministic K-chunk copies) needs max_split >= 1");
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
     AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
@@ -2319,6 +2513,28 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     const int algo = a->algo ? a->algo : (env_algo ? env_algo : 1);
     AWR_REQUIRE(a->algo != 2 || ph, "conv_wgrad: algo 2 (wave per tap) does not serve this geometry / product mode");
     w->taps_ph = 0;
+    w->row_pw = 0;
+    {   // one workgroup per kernel row: 3x3, stride 1, same-size power-of-two maps, taps row-major from the top-left one, D plain
+        auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+        bool ok = g_products == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
+                  a->Hd >= 2 && !a->d_scale && M < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24);
+        for (int t = 0; ok && t < 9; ++t) ok = a->dy[t] == t / 3 - 1 && a->dx[t] == t % 3 - 1;
+        static const int env_row = env_int("AWR_WGRAD_ROW", 0);      // study hook: 1 = wherever the geometry allows (explicit algo wins)
+        AWR_REQUIRE(a->algo != 3 || ok, "conv_wgrad: algo 3 (workgroup per kernel row) serves 3x3 stride-1 filters on power-of-two maps >= 8 wide in the FP32-MFMA mode");
+        if (ok && (a->algo == 3 || (a->algo == 0 && env_row))) {
+            w->row_pw = a->Wd >= 16 ? 16 : 8;
+            const int64_t nstage = M / 16;
+            w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64) * 3;
+            const int want = a->target_blocks > 0 ? a->target_blocks : 1024;
+            int64_t nsplit = (want + w->tiles - 1) / w->tiles;
+            if (nsplit > nstage / 8) nsplit = nstage / 8;            // at least 8 stages (128 pixels) per workgroup
+            if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
+            if (nsplit < 1) nsplit = 1;
+            w->chunk = (nstage + nsplit - 1) / nsplit;
+            w->nsplit = (nstage + w->chunk - 1) / w->chunk;
+            return AWR_OK;
+        }
+    }
     if (ph && algo == 2) {
         auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
         w->taps_ph = ph;
@@ -2379,6 +2595,19 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     if (int e = wgrad_plan(a, &w)) return e;
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)w.tiles, (unsigned)w.nsplit);
+    if (w.row_pw) {
+        int wlog = 0, hlog = 0;
+        while ((1 << wlog) < a->Wd) ++wlog;
+        while ((1 << hlog) < a->Hd) ++hlog;
+        if (w.row_pw == 16) {
+            if (a->g_scale) hipLaunchKernelGGL((conv_wgrad_row_kernel<16, true>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
+            else hipLaunchKernelGGL((conv_wgrad_row_kernel<16, false>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
+        } else {
+            if (a->g_scale) hipLaunchKernelGGL((conv_wgrad_row_kernel<8, true>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
+            else hipLaunchKernelGGL((conv_wgrad_row_kernel<8, false>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
+        }
+        return check_launch("conv_wgrad_row_kernel");
+    }
     if (w.taps_ph) {
         if (a->T == 16) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 4, 2>), grid, dim3(1024), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
         else if (a->sg == 2) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 3, 2>), grid, dim3(768), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);

@@ -447,8 +447,8 @@ def main():
     tpath = os.path.join(REPO, "profiles", tfiles[-1]) if tfiles else ""
     if tpath and args.net == "resnet_18" and args.batch == 64 and nprod == 1:      # the PMC passes profile exactly this command
         tj = json.load(open(tpath))
-        key = "conv_gemm_kernel" if dom.startswith("conv_gemm") else "conv_wgrad_kernel"
-        ent = [v for k, v in tj.items() if key in k]
+        keys = ("conv_gemm_kernel", "conv_gemm_dma_kernel") if dom.startswith("conv_gemm") else ("conv_wgrad_kernel", "conv_wgrad_dma_kernel", "conv_wgrad_row_kernel")
+        ent = [v for k, v in tj.items() if any(key in k for key in keys)]
         nl = sum(v["launches"] for v in ent)
         if nl:
             traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_x2"] + v["write_MB_per_launch"]) for v in ent) / nl * 1e6)

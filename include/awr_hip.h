@@ -292,7 +292,9 @@ typedef struct awr_wgrad_args {
     int target_blocks;      /* split-K: aim for this many workgroups; 0 = heuristic */
     int algo;               /* 0 = automatic; 1 = one workgroup per (tap, channel tile, pixel chunk); 2 = one WAVE per tap: a
                                workgroup owns a 64x64 channel tile for all taps and stages D / halo'd G patches once
-                               (3x3 stride 1/2 and 4x4 stride-2 filters on power-of-two maps) */
+                               (3x3 stride 1/2 and 4x4 stride-2 filters on power-of-two maps); 3 = one workgroup per KERNEL ROW: the three
+                               taps of a row share the staged D pixels and one halo'd G row segment, three accumulators per wave, operands by
+                               LDS-DMA (3x3 stride-1 filters, power-of-two maps at least 8 wide, D without a fused affine) */
     int8_t dy[16], dx[16];
     int64_t split_stride;   /* 0: split-K partial sums are combined with atomics in R.  > 0 (deterministic mode): K-chunk y stores its
                                tile at R + y*split_stride floats and its column sums at d_colsum + y*Cd; nothing needs zeroing */

@@ -2,9 +2,7 @@
 # Round 4 checkpoint on ONE box: accumulation probe, full -m gpu suite, smoke, the default bench line (timed: the driver runs exactly this).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r4g
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-python tools/probes/accum_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/accum_probe.txt
-AWR_ACCUM=1 python tools/probes/accum_probe.py --env 2>&1 | grep -v amdgpu.ids | head -3 | tee -a $OUT/accum_probe.txt
-/usr/bin/time -v python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" > $OUT/gpu_tests.log; grep -E "passed|failed|Elapsed" $OUT/gpu_tests.log | tail -4
+( time python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" > $OUT/gpu_tests.log ) 2>&1 | grep real; grep -E "passed|failed" $OUT/gpu_tests.log | tail -4
 cp gpurun_out/parity_report.json $OUT/parity_report.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 ( time python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
@@ -16,3 +14,5 @@ for k in ("b256", "hg1_train_b64", "config5", "config3", "split_mode", "cpu_base
     print(k, json.dumps(d.get(k))[:400])
 print("forward", json.dumps(d.get("forward"))[:500])
 PY
+bash tools/gpu_profiles.sh r04 > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
+bash tools/gpu_trace.sh r04 > /dev/null 2>&1; head -3 gpurun_out/timeline_r04.txt

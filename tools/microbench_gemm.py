@@ -141,7 +141,7 @@ def main():
         for name, spec, H in shapes:
             res = []
             pr = spec.wgrad_problem(H, H)
-            for tile, blocks in (((1, 1), 2048), ((1, 1), 3072), ((1, 1), 4096), ((2, 1), 1536), ((2, 1), 2048), ((1, 2), 2048)):
+            for tile, blocks in (((1, 1), 2048), ((1, 1), 3072), ((1, 1), 4096), ((2, 1), 1536), ((2, 1), 2048), ((1, 2), 2048), ((2, 2), 768), ((2, 2), 1024), ((2, 2), 1536)):
                 if (tile[0] == 2 and pr["Cd"] <= 64) or (tile[1] == 2 and pr["Cg"] <= 64):
                     continue
                 res.append("%s/%d %5.1f|%5.1f" % (tile, blocks, run_wgrad(spec, B, H, tile, algo=1, blocks=blocks)[1], run_wgrad(spec, B, H, tile, algo=1, blocks=blocks, affine=True)[1]))
