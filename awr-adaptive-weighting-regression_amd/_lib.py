@@ -103,6 +103,7 @@ _SIGS = {
     "awr_unpack_wgrads_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
+    "awr_conv_wgrad_algo_ok": ([C.POINTER(WgradArgs), _I], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),
     "awr_set_gemm_products": ([_I], C.c_int),
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),

@@ -1039,6 +1039,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         }
     }
     const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();
+    float f_lo[AFF ? TM : 1], f_hi[AFF ? TM : 1];      // clamp bounds of the lane's fragment rows for the current tap
     auto set_ftap = [&](int tap) {
         if constexpr (AFF) {
             const int tp = ph.tap[tap];
@@ -1047,7 +1048,10 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int iy = f_iy[i] + dy, ix = f_ix[i] + dx;
-                fmask |= (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) ? (1u << i) : 0u;
+                const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                fmask |= ok ? (1u << i) : 0u;
+                f_lo[i] = ok ? relu_lo : 0.f;
+                f_hi[i] = ok ? __builtin_inff() : 0.f;
             }
         }
     };
@@ -1131,6 +1135,12 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     const char* const a_row = smem_raw + (wm * 32 * TM + l31) * ROWB;
     const char* const b_row = smem_raw + AROWS * ROWB + (wn * 32 * TN + l31) * ROWB;
     int ctap = 0, cc0 = 0;      // the stage the MFMAs are at (the requests run one stage ahead)
+    // MASKED = false (AFF == 3, chosen by the launcher for single-tap launches: a 1x1 conv has no padding): the padding selects -- four per
+    // fragment float4, half of the fragment-side arithmetic's measured cost (profiles/r04_microbench_affine_probe.txt) -- are compiled out.
+    // (A run-time fast path for fully valid taps was built too: two copies of the stage behind a wave-uniform branch cost 30-70 registers --
+    // the allocator keeps both arms' accumulator copies -- and a 3x3 tile of 64 consecutive pixels spans whole image rows anyway, so only
+    // its dx = 0 taps would ever qualify.)
+    constexpr bool MASKED = AFF == 1 || AFF == 2;
     auto compute = [&](int buf) {
         const bool aff_stage = AFF != 0 && (!DUAL || cc0 < cin1);       // (wave-uniform)
 #pragma unroll
@@ -1146,22 +1156,23 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                              k3 = ld4(aff_tab + 2 * AFF_MAXC + cc0 + 8 * s + 4 * half), mu = ld4(aff_tab + 3 * AFF_MAXC + cc0 + 8 * s + 4 * half);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const bool ok = fmask & (1u << i);
+                    const bool ok = !MASKED || (fmask & (1u << i));
                     const float4 g = fa[i], y = ld4(reinterpret_cast<const float*>(a_row + BM * ROWB + fo + i * 32 * ROWB));
                     // (y - mean first, like the apply kernel: a nearly constant channel would cancel catastrophically in a2 y + a3')
                     fa[i].x = ok ? g.x * k1.x + ((y.x - mu.x) * k2.x + k3.x) : 0.f; fa[i].y = ok ? g.y * k1.y + ((y.y - mu.y) * k2.y + k3.y) : 0.f;
                     fa[i].z = ok ? g.z * k1.z + ((y.z - mu.z) * k2.z + k3.z) : 0.f; fa[i].w = ok ? g.w * k1.w + ((y.w - mu.w) * k2.w + k3.w) : 0.f;
                 }
-            } else if constexpr (AFF == 1) {
+            } else if constexpr (AFF == 1 || AFF == 3) {
                 if (aff_stage) {
                     const float4 sc = ld4(aff_tab + cc0 + 8 * s + 4 * half), sh = ld4(aff_tab + AFF_MAXC + cc0 + 8 * s + 4 * half);
+                    // clamp(x, lo, hi) with (lo, hi) = (0 | -inf, +inf) on rows inside the image and (0, 0) on padding rows: the ReLU and the
+                    // padding rule in ONE v_med3 per element, bounds chosen once per tap (set_ftap) -- no compare, no select per element
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        const bool ok = fmask & (1u << i);
+                        const float lo = MASKED ? f_lo[MASKED ? i : 0] : relu_lo, hi = MASKED ? f_hi[MASKED ? i : 0] : __builtin_inff();
                         float4 v = fa[i];
-                        v.x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, relu_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, relu_lo, __builtin_inff());
-                        v.z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, relu_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, relu_lo, __builtin_inff());
-                        fa[i].x = ok ? v.x : 0.f; fa[i].y = ok ? v.y : 0.f; fa[i].z = ok ? v.z : 0.f; fa[i].w = ok ? v.w : 0.f;
+                        fa[i].x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, lo, hi); fa[i].y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, lo, hi);
+                        fa[i].z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, lo, hi); fa[i].w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, lo, hi);
                     }
                 }
             }
@@ -1663,8 +1674,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
 //   channel) applied to the B fragments; halo / padding pixels must stay zero THROUGH the affine -- row validity is uniform per stage, the
 //   two halo columns only matter at the image's left / right edge (a per-lane 0 / 1 factor: the pair's two pixels sit in the two half-waves).
 //   The bias gradient (column sums of D = dY) is the sum of the A fragments over the stage's pixels: no register path for D either.
+#ifndef AWR_ROW_FENCE
+#define AWR_ROW_FENCE 2      // pixel pairs of fragment reads the scheduler may hoist in front of their MFMAs (study hook: 2 | 4 | 8)
+#endif
 template <int PW, bool GAFF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
     constexpr int KP = 16;                           // D pixels per stage
     constexpr int PH = KP / PW;                      // rows per stage (1 | 2)
     constexpr int GW = PW + 2, GP = PH * GW;         // G pixel rows per stage: 18 | 20
@@ -1752,16 +1766,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
     const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * 64 + wm * 32 + l31;               // D[pixel][cd]
     const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * 64 + wn * 32 + l31;         // G[patch pixel][cg]
     auto compute = [&](int buf) {
-        // per-lane 0 / 1 factors of the two halo columns: position 0 is read by the half-wave h = 0 of the row's first pixel pair (tap 0),
-        // position PW + 1 by h = 1 of its last pair (tap 2)
-        const float lmul = (GAFF && half == 0 && !edge_l) ? 0.f : 1.f, rmul = (GAFF && half == 1 && !edge_r) ? 0.f : 1.f;
+        // Padding through the affine WITHOUT per-read work: a G row outside the image, and the two halo columns at the image's left / right
+        // edge (position 0 is read by the half-wave h = 0 of a row's first pixel pair, position PW + 1 by h = 1 of its last pair), get
+        // scale = shift = 0 -- clamp(0 * 0 + 0) = 0 -- chosen once per stage; every fragment read then costs one multiply-add and one clamp
+        float rsc[PH], rsh[PH], lsc[PH], lsh[PH], esc[PH], esh[PH];
+        if constexpr (GAFF) {
+#pragma unroll
+            for (int r = 0; r < PH; ++r) {
+                const bool rv = rowmask & (1u << r);
+                rsc[r] = rv ? gsc : 0.f; rsh[r] = rv ? gsh : 0.f;
+                const bool lv = rv && (half != 0 || edge_l), ev = rv && (half != 1 || edge_r);
+                lsc[r] = lv ? gsc : 0.f; lsh[r] = lv ? gsh : 0.f;
+                esc[r] = ev ? gsc : 0.f; esh[r] = ev ? gsh : 0.f;
+            }
+        }
         auto gread = [&](int r, int pos) -> float {      // G position `pos` (0 = left halo) of patch row r for this lane's half: pos + half
             float v = b_frag[buf * (STAGE / 4) + (r * GW + pos) * 64];
             if constexpr (GAFF) {
-                v = __builtin_amdgcn_fmed3f(v * gsc + gsh, g_lo, __builtin_inff());
-                if (!(rowmask & (1u << r))) v = 0.f;                 // (uniform) the whole G row is outside the image
-                if (pos == 0) v *= lmul;
-                if (pos == PW) v *= rmul;                            // (pos + half == PW + 1 for half = 1)
+                const float sc = pos == 0 ? lsc[r] : pos == PW ? esc[r] : rsc[r], sh = pos == 0 ? lsh[r] : pos == PW ? esh[r] : rsh[r];
+                v = __builtin_amdgcn_fmed3f(v * sc + sh, g_lo, __builtin_inff());
             }
             return v;
         };
@@ -1779,7 +1802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
                 b0 = b2;
                 // (left alone the scheduler hoists all 25 fragment reads of the stage in front of its MFMAs: 130 registers; a fence
                 // every second pixel pair keeps two pairs of reads in flight ahead of the matrix instructions)
-                if (kp & 1) __builtin_amdgcn_sched_barrier(0);
+                if ((kp & (AWR_ROW_FENCE - 1)) == AWR_ROW_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -2249,6 +2272,7 @@ static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, i
     if (mode == 3 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 1, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, 0>(a, grid, st, epre, em); return; }
 #endif
     if (aff == 2) launch_dma_em<TM, TN, 16, 2, 2>(a, grid, st, epre, em);
+    else if (aff == 3) launch_dma_em<TM, TN, 16, 2, 3>(a, grid, st, epre, em);
     else if (aff == 1) launch_dma_em<TM, TN, 16, 2, 1>(a, grid, st, epre, em);
     else launch_dma_em<TM, TN, 16, 2, 0>(a, grid, st, epre, em);
 }
@@ -2461,7 +2485,10 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     const int dma_mode = g_staging;
     if (dma_mode && g_products == 1 && ((!aff && !a->in_bnb_y) || (a->in2 ? a->Cin1 : a->Cin) <= AFF_MAXC)) {
         const int em = a->bnr_y ? ((a->bnr_act || a->res || a->bnr2_y) ? 4 : 3) : a->stats ? 2 : 1;
-        launch_dma(a, TM, TN, grid, st, dma_mode, a->in_bnb_y ? 2 : aff ? 1 : 0, epre && !a->in_bnb_y, em);
+        // single-tap launches whose tap is (0, 0) never read outside the image: the fused input affine without its padding selects
+        bool pad_free = true;
+        for (int p = 0; p < a->nphase && pad_free; ++p) pad_free = a->ph[p].ntaps == 1 && (a->ph[p].tap[0] & 0xffff) == 0;
+        launch_dma(a, TM, TN, grid, st, dma_mode, a->in_bnb_y ? 2 : aff ? (pad_free ? 3 : 1) : 0, epre && !a->in_bnb_y, em);
         return check_launch("conv_gemm_dma_kernel");
     }
     static const bool occ6 = getenv("AWR_NO_OCC6") == nullptr;
@@ -2497,6 +2524,15 @@ struct wgrad_launch {
     int pc_log, pr_log;
 };
 
+static bool wgrad_row_ok(const awr_wgrad_args* a) {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
+    bool ok = g_products == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
+              a->Hd >= 2 && !a->d_scale && M < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24);
+    for (int t = 0; ok && t < 9; ++t) ok = a->dy[t] == t / 3 - 1 && a->dx[t] == t % 3 - 1;
+    return ok;
+}
+
 static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
     AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
@@ -2515,18 +2551,23 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     w->taps_ph = 0;
     w->row_pw = 0;
     {   // one workgroup per kernel row: 3x3, stride 1, same-size power-of-two maps, taps row-major from the top-left one, D plain
-        auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-        bool ok = g_products == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
-                  a->Hd >= 2 && !a->d_scale && M < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24);
-        for (int t = 0; ok && t < 9; ++t) ok = a->dy[t] == t / 3 - 1 && a->dx[t] == t % 3 - 1;
-        static const int env_row = env_int("AWR_WGRAD_ROW", 0);      // study hook: 1 = wherever the geometry allows (explicit algo wins)
+        const bool ok = wgrad_row_ok(a);
+        // default (algo 0): wherever the gathered operand is plain -- isolated launches 114-131 TF against 99-120 for the best per-tap
+        // geometry -- and, with the fused BatchNorm loader (its arithmetic sits between every fragment read and its MFMA: -10 %), only on
+        // the 64-channel layers with >= 64x64 maps, where the per-tap kernel is at its worst (95 -> 101 TF).  AWR_WGRAD_ROW: 0 = never,
+        // 1 = wherever the geometry allows; an explicit algo wins, and the plan autotuner times algo 3 against the per-tap geometries.
+        static const int env_row = env_int("AWR_WGRAD_ROW", -1);
+        const bool want_row = env_row >= 0 ? env_row != 0 : (!a->g_scale || (a->Wd >= 64 && a->Cd <= 64 && a->Cg <= 64));
         AWR_REQUIRE(a->algo != 3 || ok, "conv_wgrad: algo 3 (workgroup per kernel row) serves 3x3 stride-1 filters on power-of-two maps >= 8 wide in the FP32-MFMA mode");
-        if (ok && (a->algo == 3 || (a->algo == 0 && env_row))) {
+        if (ok && (a->algo == 3 || (a->algo == 0 && want_row))) {
             w->row_pw = a->Wd >= 16 ? 16 : 8;
             const int64_t nstage = M / 16;
             w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64) * 3;
+            // four workgroups per CU are resident (registers): 1024 slots.  The workgroups of a launch are equally long, so the count that
+            // fits ONE generation wins (isolated launches: 768 / 1536 workgroups 114-119 TF, 1026 -- two generations, the second almost
+            // empty -- 106; profiles/r04_microbench_wgrad_row.txt): floor, not ceil
             const int want = a->target_blocks > 0 ? a->target_blocks : 1024;
-            int64_t nsplit = (want + w->tiles - 1) / w->tiles;
+            int64_t nsplit = want / w->tiles;
             if (nsplit > nstage / 8) nsplit = nstage / 8;            // at least 8 stages (128 pixels) per workgroup
             if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
             if (nsplit < 1) nsplit = 1;
@@ -2575,6 +2616,14 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     w->chunk = chunk;
     w->nsplit = (M + chunk - 1) / chunk;
     return AWR_OK;
+}
+
+int awr_conv_wgrad_algo_ok(const awr_wgrad_args* a, int algo) {
+    if (!a) return 0;
+    if (algo == 0 || algo == 1) return 1;
+    if (algo == 2) return g_products == 1 && wgrad_taps_patch_rows(a) > 0;
+    if (algo == 3) return wgrad_row_ok(a) ? 1 : 0;
+    return 0;
 }
 
 int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit) {

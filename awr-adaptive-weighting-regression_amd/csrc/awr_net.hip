@@ -2055,7 +2055,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
     for (auto& g : P.gemms) {
         if (g.wa && g.wa->algo == 2) continue;      // the wave-per-tap kernel has one geometry
         if (g.ca && g.ca->w2) continue;             // ... and so has the fused conv pair
-        struct Cand { int tm, tn, tb; };
+        struct Cand { int tm, tn, tb, algo = 0; };
         std::vector<Cand> cands;
         if (g.ca) {
             cands = {{1, 1, 0}, {2, 1, 0}};
@@ -2071,12 +2071,17 @@ static int autotune(awr_plan& P, int reps, void* stream) {
             if (g.wa->Cd > 64) { cands.push_back({2, 1, 1536}); cands.push_back({2, 1, 2048}); }
             if (g.wa->Cg > 64) cands.push_back({1, 2, 2048});
             if (g.wa->Cd > 64 && g.wa->Cg > 64 && awr_get_gemm_products() != 1) { cands.push_back({2, 2, 1024}); cands.push_back({2, 2, 2048}); }
+            // one workgroup per kernel row (3x3 stride 1): its own split-K depths; the per-tap candidates above then run as algo 1
+            if ((g.wa->algo == 0 || g.wa->algo == 3) && awr_conv_wgrad_algo_ok(g.wa, 3)) {
+                for (auto& c : cands) c.algo = 1;
+                for (int tb : {768, 1024, 1536, 2048}) cands.push_back({1, 1, tb, 3});
+            }
         }
         float best_t = 1e30f;
         Cand best = cands[0];
         for (auto& c : cands) {
             if (g.ca) { g.ca->tile_m = c.tm; g.ca->tile_n = c.tn; if (c.tb) g.ca->split_k = c.tb; }
-            else { g.wa->tile_m = c.tm; g.wa->tile_n = c.tn; if (c.tb) g.wa->target_blocks = c.tb; }
+            else { g.wa->tile_m = c.tm; g.wa->tile_n = c.tn; if (c.tb) g.wa->target_blocks = c.tb; if (c.algo) g.wa->algo = c.algo; }
             if ((rc = launch(g))) break;      // warm-up
             (void)hipEventRecord(e0, main);
             for (int r = 0; r < reps && rc == AWR_OK; ++r) rc = launch(g);
@@ -2089,7 +2094,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
         }
         if (rc) break;
         if (g.ca) { g.ca->tile_m = best.tm; g.ca->tile_n = best.tn; if (best.tb) g.ca->split_k = best.tb; }
-        else { g.wa->tile_m = best.tm; g.wa->tile_n = best.tn; if (best.tb) g.wa->target_blocks = best.tb; }
+        else { g.wa->tile_m = best.tm; g.wa->tile_n = best.tn; if (best.tb) g.wa->target_blocks = best.tb; if (best.algo) g.wa->algo = best.algo; }
         g.tm = best.tm; g.tn = best.tn; g.tb = best.tb; g.us = best_t * 1e3f; g.tuned = true;
     }
     (void)hipEventDestroy(e0);

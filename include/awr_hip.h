@@ -301,6 +301,8 @@ typedef struct awr_wgrad_args {
     int max_split;          /* with split_stride: number of copies the caller allocated (caps the split-K depth) */
 } awr_wgrad_args;
 int awr_conv_wgrad(const awr_wgrad_args* a, void* stream);
+/* 1 if awr_wgrad_args.algo = `algo` serves this geometry in the current product / staging mode (what a tuner may try), else 0 */
+int awr_conv_wgrad_algo_ok(const awr_wgrad_args* a, int algo);
 /* number of K-chunk copies the launch described by `a` writes (split_stride mode) */
 int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit);
 

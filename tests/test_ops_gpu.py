@@ -786,6 +786,47 @@ def test_wgrad_one_wave_per_tap(ops, L, dev, kind, cin, cout, k, stride, B, H):
         assert rel_err(out.cpu(), gw_ref) < 1e-5, blocks
 
 
+@pytest.mark.parametrize("cin,cout,B,H,affine", [(64, 64, 2, 32, True), (64, 96, 3, 16, False), (128, 160, 2, 8, True), (96, 64, 1, 64, True), (64, 64, 5, 8, False)])
+def test_wgrad_one_workgroup_per_kernel_row(ops, L, dev, cin, cout, B, H, affine):
+    """awr_conv_wgrad algo 3 (3x3 stride 1: a workgroup contracts 16 staged D pixels against the three taps of one kernel row from one halo'd
+    G row segment, three accumulators per wave, operands by LDS-DMA) against float64 autograd and against algo 1: maps of 64 / 32 / 16 pixels
+    (one-row stages) and 8 pixels (two-row stages), ragged channel tiles, the fused BatchNorm + ReLU loader on the gathered operand (halo and
+    padding pixels must stay zero through it), the bias gradient from the A fragments, and split-K depths with a ragged last chunk."""
+    import ctypes as C
+    spec = ops.ConvSpec("conv", cin, cout, 3, 1, 1)
+    x = rnd(B, cin, H, H, seed=2)
+    s_, t_ = rnd(cin, seed=5) + 0.3, rnd(cin, seed=6) * 0.5
+    a = TF.relu(x * s_.view(1, -1, 1, 1) + t_.view(1, -1, 1, 1)) if affine else x
+    wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    y_ref = TF.conv2d(a.double(), wd, None, 1, 1)
+    gy = rnd(*y_ref.shape, seed=4)
+    (gw_ref,) = torch.autograd.grad(y_ref, [wd], gy.double())
+    xg, gyg = ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev)
+    aff = (s_.to(dev), t_.to(dev), True) if affine else None
+    bg = torch.empty(cout, device=dev)
+    gw = ops.conv_wgrad(spec, xg, gyg, x_affine=aff, bias_grad=bg, algo=3)
+    assert rel_err(gw.cpu(), gw_ref) < 1e-5
+    assert rel_err(bg.cpu(), gy.double().sum((0, 2, 3))) < 1e-5
+    old = ops.conv_wgrad(spec, xg, gyg, x_affine=aff, algo=1)
+    assert rel_err(gw.cpu(), old.cpu()) < 2e-6
+    prob = spec.wgrad_problem(H, H)
+    for blocks in (1, 7, 100000):
+        R = torch.zeros(prob["Cd"], 9, prob["Cg"], device=dev)
+        wa = ops.make_wgrad_args(prob, B, gyg, xg, R, prob["Cg"], algo=3, **({"g_affine": aff} if aff else {}))
+        wa.target_blocks = blocks
+        L.call("awr_conv_wgrad", C.byref(wa), L.stream())
+        out = torch.empty(cout, cin, 3, 3, device=dev)
+        L.call("awr_unpack_wgrad", L.ptr(R), prob["d0"], prob["d1"], 9, prob["Cg"], L.ptr(out), 0, L.stream())
+        assert rel_err(out.cpu(), gw_ref) < 1e-5, blocks
+    # geometries the kernel does not serve are refused, not mis-computed
+    bad = ops.ConvSpec("conv", cin, cout, 3, 2, 1)
+    pb = bad.wgrad_problem(H, H)
+    Rb = torch.zeros(pb["Cd"], 9, pb["Cg"], device=dev)
+    wb = ops.make_wgrad_args(pb, B, ops.nhwc(rnd(B, cout, H // 2, H // 2, seed=7)).to(dev), xg, Rb, pb["Cg"], algo=3)
+    with pytest.raises(Exception):
+        L.call("awr_conv_wgrad", C.byref(wb), L.stream())
+
+
 @pytest.mark.parametrize("B,H,cin,k,n1,cx,tm", [(2, 16, 128, 3, 128, 0, 1), (3, 10, 128, 3, 128, 0, 1), (1, 8, 64, 1, 128, 0, 1),      # ragged M (300 pixels), a 1x1 first conv
                                                 (2, 16, 128, 3, 128, 128, 1), (3, 10, 64, 3, 64, 64, 2), (3, 10, 64, 3, 64, 64, 1), (2, 16, 64, 3, 64, 0, 2)])
 def test_fused_conv_pair(ops, L, dev, B, H, cin, k, n1, cx, tm):

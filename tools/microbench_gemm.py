@@ -30,7 +30,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def run_fwd(spec, B, H, tile=None, stats=False):
+def run_fwd(spec, B, H, tile=None, stats=False, affine=False):
     dev = torch.device("cuda:0")
     x = torch.randn(B, H, H, spec.cin_pad, device=dev)
     wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == "conv" else (spec.cin, spec.cout, spec.k, spec.k)
@@ -39,7 +39,10 @@ def run_fwd(spec, B, H, tile=None, stats=False):
     prob = spec.fwd_problem(H, H)
     out = torch.empty(B, prob["Hout"], prob["Wout"], prob["N"], device=dev)
     st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64) if stats else None
-    a = ops.make_conv_args(prob, B, x, wp, out, stats=st, T=spec.T)
+    aff = {}
+    if affine:      # the un-materialised BatchNorm + ReLU input
+        aff = dict(in_scale=torch.rand(spec.cin_pad, device=dev) + 0.5, in_shift=torch.randn(spec.cin_pad, device=dev) * 0.1, relu_in=True)
+    a = ops.make_conv_args(prob, B, x, wp, out, stats=st, T=spec.T, **aff)
     if tile:
         L.call("awr_debug_force_tile", *tile)
     s = L.stream()
@@ -122,13 +125,13 @@ def main():
                   ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32), ("head 1x1 256->64 @64", ops.ConvSpec("conv", 256, 64, 1, 1, 0), 64),
                   ("hg 1x1 256->128 @64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 64), ("hg 1x1 128->256 @64", ops.ConvSpec("conv", 128, 256, 1, 1, 0), 64),
                   ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64), ("hg 1x1 256->128 @16", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 16)]
-        print("AWR_DMA=%s batch %d: TF per tile, plain | with statistics epilogue" % (os.environ.get("AWR_DMA", "0"), B))
+        print("AWR_DMA=%s batch %d: TF per tile, plain | with statistics epilogue | statistics + fused input affine" % (os.environ.get("AWR_DMA", "2"), B))
         for name, spec, H in shapes:
             res = []
             for tile in ((1, 1), (2, 1), (1, 2), (2, 2)):
                 if spec.cout <= 64 and tile[1] == 2:
                     continue
-                res.append("%s %5.1f|%5.1f" % (tile, run_fwd(spec, B, H, tile)[1], run_fwd(spec, B, H, tile, stats=True)[1]))
+                res.append("%s %5.1f|%5.1f|%5.1f" % (tile, run_fwd(spec, B, H, tile)[1], run_fwd(spec, B, H, tile, stats=True)[1], run_fwd(spec, B, H, tile, stats=True, affine=True)[1]))
             print("%-26s %s" % (name, "  ".join(res)), flush=True)
     elif args.mode == "wgradset":    # workgroup-per-tap weight gradient, every tile x split-K candidate of the plan autotuner; plain and with the
         B = args.batch                # un-materialised BatchNorm loader on the layer input (AWR_WGRAD_DMA / AWR_WGRAD_KP: one process per variant)
@@ -145,6 +148,9 @@ def main():
                 if (tile[0] == 2 and pr["Cd"] <= 64) or (tile[1] == 2 and pr["Cg"] <= 64):
                     continue
                 res.append("%s/%d %5.1f|%5.1f" % (tile, blocks, run_wgrad(spec, B, H, tile, algo=1, blocks=blocks)[1], run_wgrad(spec, B, H, tile, algo=1, blocks=blocks, affine=True)[1]))
+            if spec.kind == "conv" and spec.k == 3 and spec.stride == 1:      # one workgroup per kernel row (algo 3): split-K candidates
+                for blocks in (512, 768, 1024, 1536, 2048, 3072):
+                    res.append("row/%d %5.1f|%5.1f" % (blocks, run_wgrad(spec, B, H, None, algo=3, blocks=blocks)[1], run_wgrad(spec, B, H, None, algo=3, blocks=blocks, affine=True)[1]))
             print("%-28s %s" % (name, "  ".join(res)), flush=True)
     elif args.mode == "tiles":       # forward only, every tile, a few representative layers (used by tools/probe_gemm.sh)
         B = args.batch
