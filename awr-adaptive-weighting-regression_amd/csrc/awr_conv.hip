@@ -1038,8 +1038,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
             }
         }
     }
-    const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();
-    float f_lo[AFF ? TM : 1], f_hi[AFF ? TM : 1];      // clamp bounds of the lane's fragment rows for the current tap
+    float f_hi[AFF ? TM : 1];      // upper clamp bound of the lane's fragment rows for the current tap: +inf inside the image, 0 on padding rows
     auto set_ftap = [&](int tap) {
         if constexpr (AFF) {
             const int tp = ph.tap[tap];
@@ -1050,7 +1049,6 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 const int iy = f_iy[i] + dy, ix = f_ix[i] + dx;
                 const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
                 fmask |= ok ? (1u << i) : 0u;
-                f_lo[i] = ok ? relu_lo : 0.f;
                 f_hi[i] = ok ? __builtin_inff() : 0.f;
             }
         }
@@ -1169,7 +1167,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                     // padding rule in ONE v_med3 per element, bounds chosen once per tap (set_ftap) -- no compare, no select per element
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        const float lo = MASKED ? f_lo[MASKED ? i : 0] : relu_lo, hi = MASKED ? f_hi[MASKED ? i : 0] : __builtin_inff();
+                        const float hi = MASKED ? f_hi[MASKED ? i : 0] : __builtin_inff(), lo = a.relu_in ? 0.f : -hi;      // (padding rows: hi = 0, so lo = 0 either way)
                         float4 v = fa[i];
                         fa[i].x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, lo, hi); fa[i].y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, lo, hi);
                         fa[i].z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, lo, hi); fa[i].w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, lo, hi);
