@@ -1104,7 +1104,7 @@ struct Builder {
         // D and the halo'd G patch once for all nine taps (measured: 124 vs 114 TF in isolation, Hourglass-1 step 26.44 -> 25.79 ms; writing relu(bn2(.)) out for them on top: 25.87); on
         // every other shape the workgroup-per-tap kernel is equal or faster (profiles/r02_microbench_wgrad_algos.txt)
         if (!P.det && awr_get_gemm_products() == 1 && spec.k == 3 && spec.stride == 1 && !spec.deconv && spec.cin == 128 && spec.cout == 128 &&
-            H * W >= 4096 && (int64_t)B * H * W >= (1 << 17))
+            H * W >= 4096 && (int64_t)B * H * W >= (1 << 17) && x->lazy)      // (a plain input takes the kernel-row kernel: awr_conv_wgrad's default)
             wa->algo = 2;
         P.gemms.push_back({nullptr, wa, wname});
         // scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
@@ -1718,7 +1718,12 @@ struct NetBuilder {
             // the three pre-activations feed exactly one conv each: never written to HBM
             Tn* a = b.bn_act(x, BN(p + ".bn1"), true, nullptr, true);
             o.want_stats = true;
-            a = b.bn_act(b.conv(a, C(p + ".conv1"), o), BN(p + ".bn2"), true, nullptr, true);
+            // (bn2's output feeds the 3x3 conv2, whose nine taps each re-apply the loader arithmetic; writing it out instead puts conv2's
+            // forward on the pure-DMA GEMM and its weight gradient on the kernel-row kernel -- re-measured in round 4 with those kernels:
+            // Hourglass-1 23.19-23.34 vs 23.12-23.23 ms, config 5 281.1 vs 279.4 ms and +10.7 GB of plan: still not worth the pass.
+            // AWR_HG_WRITE_BN2=1 is the A/B hook; profiles/r04_hg_materialised_bn2.txt)
+            static const bool write_bn2 = getenv("AWR_HG_WRITE_BN2") != nullptr;
+            a = b.bn_act(b.conv(a, C(p + ".conv1"), o), BN(p + ".bn2"), true, nullptr, !write_bn2);
             a = b.bn_act(b.conv(a, C(p + ".conv2"), o), BN(p + ".bn3"), true, nullptr, true);
             if (dual) return b.conv_dual(a, x, dual, true);
             Tn* r = skip ? b.conv(x, skip) : x;

@@ -541,7 +541,7 @@ def main():
                 # shape (Hourglass-2, 256x256, 21 joints, 128 images: ~150 GB of plan buffers on one MI355X, ~0.3 s per step)
                 out["hg1_train_b64"] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
                                                      "hourglass_1 NYU-shape 128x128 J=14 train step, batch 64")
-                out["config5"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 4, 2, peak_tf,
+                out["config5"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,
                                                "hourglass_2 256x256 J=21 train step, batch 128/GPU = BASELINE configs[4] per-GPU shape")
         if world == 1 and nprod == 1 and not args.no_split_mode:
             # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)

@@ -65,11 +65,14 @@ def oracle_fp64_joint_gap(net, sd, img, ks, training, stages=None):
     return gaps
 
 
-def assert_joints(name, got, ref, gap, factor=3.0):
-    """got / ref: (B,J,3) normalised joints.  Bar: mean 3D distance <= 1e-3 mm (north_star), max <= 5e-3 mm -- widened to 3x
-    (mean) / 6x (max: the worst single joint of a handful is a noisy statistic) the oracle's own fp32-vs-fp64 gap where the
-    inputs are that ill-conditioned.  Two fp32 implementations that each sit one gap from the exact answer differ by ~1.4 gaps;
-    the MFMA path accumulates K sequentially (no blocked partial sums like oneDNN), which costs about another factor 1.5."""
+def assert_joints(name, got, ref, gap, factor=2.0):
+    """got / ref: (B,J,3) normalised joints.  Bar: mean 3D distance <= 1e-3 mm (north_star), max <= 5e-3 mm -- widened to `factor` x
+    (mean) / 3 `factor` x (max: the worst single joint of a handful is a noisy statistic) the oracle's own fp32-vs-fp64 gap where the
+    inputs are that ill-conditioned.  Two fp32 implementations that each sit one gap from the exact answer differ by ~1.4 gaps: round 4
+    tightens the default from 3 to 2 gaps.  The ORDERED accumulation mode carries 1.8-2.6x the oracle's rounding error (one k-chain per
+    output element); the two fixture families where that matters -- ResNet18 / ResNet-50 with training-mode BatchNorm --
+    say so at their call sites (factor 3 / 4) and have a blocked-mode twin that meets the PLAIN bar
+    (test_blocked_accumulation_meets_the_plain_north_star_bar)."""
     d = np.linalg.norm(np.asarray(got, np.float64) - np.asarray(ref, np.float64), axis=-1) * 150.0
     mean, mx = float(d.mean()), float(d.max())
     report(name + "/joint_err_mm_mean", mean)
@@ -77,7 +80,7 @@ def assert_joints(name, got, ref, gap, factor=3.0):
     report(name + "/oracle_fp32_vs_fp64_gap_mm_mean", gap[0])
     if len(gap) > 2 and tuple(gap[2].shape) == tuple(np.asarray(got).shape):      # how far the HIP joints themselves sit from float64
         report(name + "/hip_vs_fp64_mm_mean", float(np.linalg.norm(np.asarray(got, np.float64) - gap[2].numpy(), axis=-1).mean() * 150.0))
-    bar_mean, bar_max = max(NORTH_STAR_MEAN_MM, factor * gap[0]), max(5e-3, 2.0 * factor * gap[1])
+    bar_mean, bar_max = max(NORTH_STAR_MEAN_MM, factor * gap[0]), max(5e-3, 3.0 * factor * gap[1])
     assert mean <= bar_mean and mx <= bar_max, (name, mean, mx, "bars", bar_mean, bar_max, "fp64 gap", gap)
     return mean, mx
 
@@ -114,7 +117,8 @@ def test_backbone_forward_golden(amd, dev, golden_dir, net):
             # ResNet-50 (not a BASELINE config; procedural weights, batch 2, training-mode BatchNorm over 32 samples per channel at layer4) is
             # ill-conditioned -- the fp32 oracle itself sits 4.4e-3 mm from float64 -- and 50 layers deep: the MFMA's k-ordered accumulation
             # carries 2.6x the oracle's rounding error, i.e. an expected distance of sqrt(1 + 2.6^2) = 2.8 gaps, measured 3.06
-            assert_joints("%s/%s/stage%d" % (net, mode, s), jt, g["%s_s%d_jt" % (mode, s)], gaps[s], factor=4.0 if net == "resnet_50" else 3.0)
+            assert_joints("%s/%s/stage%d" % (net, mode, s), jt, g["%s_s%d_jt" % (mode, s)], gaps[s],
+                          factor=4.0 if net == "resnet_50" else 3.0 if (net == "resnet_18" and mode == "train") else 2.0)
         if mode == "train":
             got_sd = m.state_dict()
             for i, k in enumerate(g["bn_keys"]):
@@ -169,7 +173,7 @@ def test_fused_train_step_golden(amd, dev, golden_dir, net, tag, cw):
     assert abs(l0 - ref0) <= 2e-4 * abs(ref0), (l0, ref0)
     assert abs(float(losses[0]) - float(g[tag + "_lcoord0"])) <= 2e-4 * max(1e-6, abs(float(g[tag + "_lcoord0"]))) + 1e-9
     gap = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=1), img, ks, True)[-1]
-    assert_joints("%s/%s/train" % (net, tag), jt.cpu().numpy(), g[tag + "_jt0"], gap, factor=4.0 if net == "resnet_50" else 3.0)
+    assert_joints("%s/%s/train" % (net, tag), jt.cpu().numpy(), g[tag + "_jt0"], gap, factor=4.0 if net == "resnet_50" else 3.0 if net == "resnet_18" else 2.0)
     # gradients: golden = reference autograd (train.py:116-121: for the hourglass only the LAST stage's loss survives)
     # (ResNet-50: 50 layers of ReLU / pooling decisions between the loss and the stem, procedural weights, batch 2 -- the first layers'
     # gradient NORMS move by 1-2 % when a handful of decisions fall the other way; the tensor-by-tensor float64 yardstick below is the sharp
@@ -225,6 +229,21 @@ def test_blocked_accumulation_meets_the_plain_north_star_bar(amd, dev, golden_di
     worst = check_grad_norms(m, [str(k) for k in g["pkeys"]], g[tag + "_grad_l2"], g[tag + "_grad_smp"], tol=5e-3)
     report("%s/%s/train_blocked/worst_grad_norm_rel_err" % (net, tag), worst)
     assert amd.get_gemm_accum() == "ordered"          # the engine's mode is its plan's, not the process's
+    if tag == "c0":      # the forward fixture through the drop-in module (training-mode BatchNorm), process-wide mode
+        gf = np.load(os.path.join(golden_dir, "resnet_18_fwd.npz"))
+        amd.set_gemm_accum("blocked")
+        try:
+            mf = make_net(amd, net, int(gf["J"]), O.procedural_state(O.manifest_for(net, int(gf["J"])), seed=0))
+            mf.train()
+            with torch.no_grad():
+                o = mf(torch.from_numpy(gf["img"]).to(dev))
+            o = o[-1] if isinstance(o, (list, tuple)) else o
+            jf = amd.FeatureModule().offset2joint_softmax(o, torch.from_numpy(gf["img"]).to(dev), float(gf["ks"])).cpu().numpy()
+        finally:
+            amd.set_gemm_accum("ordered")
+        df = np.linalg.norm(jf.astype(np.float64) - gf["train_s0_jt"].astype(np.float64), axis=-1) * 150.0
+        report("%s/train_blocked/stage0/joint_err_mm_mean" % net, float(df.mean()))
+        assert float(df.mean()) <= NORTH_STAR_MEAN_MM and float(df.max()) <= 5e-3, (float(df.mean()), float(df.max()))
 
 
 def test_inference_engine_parity_mode(amd, dev, golden_dir):
