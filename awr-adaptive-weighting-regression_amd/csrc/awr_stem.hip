@@ -193,7 +193,14 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
                                                         int tiles_per_wg, float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
     __shared__ float patch[(SP_RH + 4) * SP_PW];
-    __shared__ __attribute__((aligned(16))) float act[160 * 32];
+    // act[pixel][32 channels] as TWO PLANES of 16 channels, the second shifted by 16 floats (round 4).  The pooling threads read 16 bytes of
+    // pixel 2 px + dx: with one 32-float row per pixel, the sixteen lanes that one LDS cycle serves -- (px0, c 0-3), (px1, c 4-7), (px2, c 4-7),
+    // (px3, c 0-3) for lanes {0-3, 12-15, 20-27} -- fell on 8 distinct 16-byte slots (px stride = 64 floats = 0 mod the 16 slots): every
+    // window read 2-way conflicted (PMC: 4.2 M conflict cycles per launch).  Per plane a pixel is 4 slots, px advances 8, and the shifted
+    // second plane takes the other half: sixteen distinct slots; the conv's 4-byte stores (32 consecutive channels per pixel) stay
+    // conflict-free (plane 0 and plane 1 of one pixel sit 16 banks apart).
+    constexpr int SP_PLANE = 160 * 16 + 16;
+    __shared__ __attribute__((aligned(16))) float act[2 * SP_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
     const int tiles_x = Wo / SP_PX;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
         {
             const f32x16 acc = stem_conv_tile(patch, qy * SP_PW + qx, sl);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) act[(32 * wave + mfma_row(r, h)) * 32 + m] = fmaxf(acc[r] * sc + sh, 0.f);
+            for (int r = 0; r < 16; ++r) act[(m >> 4) * SP_PLANE + (32 * wave + mfma_row(r, h)) * 16 + (m & 15)] = fmaxf(acc[r] * sc + sh, 0.f);
         }
         __syncthreads();
         if (tid < SP_PY * SP_PX * 8) {
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(320) void stem_pool_kernel(const float* __restrict_
             // window row dy <-> conv row 2 oy - 1 + dy: only row / column -1 can fall outside (H, W even), torch pads with -inf
             for (int dy = (oy0 + py == 0) ? 1 : 0; dy < 3; ++dy)
                 for (int dx = (ox0 + px == 0) ? 1 : 0; dx < 3; ++dx) {
-                    const float4 v = ld4(&act[((2 * py + dy) * SP_RW + 2 * px + dx) * 32 + 4 * c4]);
+                    const float4 v = ld4(&act[(c4 >> 2) * SP_PLANE + ((2 * py + dy) * SP_RW + 2 * px + dx) * 16 + 4 * (c4 & 3)]);
                     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
