@@ -1983,6 +1983,8 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         if (wside && op.side_ok) {
             hipStream_t st = P.side[nside % P.side.size()];
             if (!op.pair_next) ++nside;
+            // (issued BESIDE its layer's data gradient; behind it -- i.e. beside the memory-bound BatchNorm-backward passes that follow -- was re-measured in
+            // round 4 with the LDS-DMA kernels: ResNet18 12.8 -> 13.9-14.0 ms, Hourglass-1 23.5 -> 23.9 ms, profiles/r04_wgrad_late.txt)
             NET_CHECK(stream_wait(P, st, awr::as_stream(cur)));      // its operands (dY, x) are final at this point of the issuing chain
             rc = op.fn((void*)st);
             pending = true;

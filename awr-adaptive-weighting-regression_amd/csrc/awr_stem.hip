@@ -33,7 +33,10 @@ constexpr int ST_TB = 26;        // columns of the weight-gradient result: 25 ta
 constexpr int ST_KS = 13;        // MFMA K-steps (2 taps each; tap 25 carries a zero weight)
 constexpr int ST_PW = 48;        // patch pitch of the 16x16-pixel kernels: the two 16-pixel runs of a half-wave sit 16 banks apart
 constexpr int ST_PH = 20;        // patch rows / used columns (16 + 2 * 2)
-constexpr int SP_PW = 24;        // patch pitch of the pooling kernel (21 used columns)
+constexpr int SP_PW = 49;        // patch pitch of the pooling kernel (21 used columns).  Its 32 conv pixels per half-wave are a run of the 9 x 17 pixel block, i.e.
+                                 // two or three patch rows of <= 17 consecutive floats: a pitch of 17 (mod 32) puts consecutive rows on disjoint banks.  (Round 1-3: 24 --
+                                 // rows r and r + 1 shared 9 banks, every one of the 13 A-operand reads per tile was 2-way conflicted: 4.18 M conflict cycles per launch,
+                                 // 0.23 M with 49; the kernel's time did not move -- 79 us either way -- profiles/r04_stem_lds_conflicts.txt.)
 
 // MFMA 32x32 C/D layout: lane = column (l & 31), register r of half-wave h = row (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
