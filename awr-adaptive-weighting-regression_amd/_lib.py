@@ -167,6 +167,8 @@ _SIGS = {
     "awr_plan_autotune": ([_P, _I, _P], C.c_int),
     "awr_plan_gemm": ([_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), C.POINTER(_I)], C.c_int),
     "awr_plan_set_gemm": ([_P, _I, _I, _I, _I, _F], C.c_int),
+    "awr_plan_gemm_algo": ([_P, _I, C.POINTER(_I)], C.c_int),
+    "awr_plan_set_gemm_algo": ([_P, _I, _I], C.c_int),
     # data-parallel API (csrc/awr_dp.hip)
     "awr_dp_available": ([C.POINTER(_I), C.POINTER(C.c_char_p)], C.c_int),
     "awr_dp_unique_id": ([_P], C.c_int),

@@ -1108,23 +1108,25 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         wtap = (unsigned)wt * a.Cin * 4u;
     };
     // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
-    auto issue = [&](int c0, int buf) {
+    // (`live` = false: a stage beyond the K extent, requested by the last trip of the pipelined loop -- every source out of range, zeros)
+    auto issue = [&](int c0, int buf, bool live = true) {
         const unsigned cb = (unsigned)c0 * 4u;
         const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(AROWS * ROWB);
+        const unsigned tm_ = live ? tapmask : 0u;
         if (DUAL && c0 >= cin1) {        // (wave-uniform) this stage comes from the second tensor
             const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) dma16(rw_in2, As + i * 4096u, (tapmask & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
+            for (int i = 0; i < RA; ++i) dma16(rw_in2, As + i * 4096u, (tm_ & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
         } else {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+            for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tm_ & (1u << i)) ? a_off[i] + cb : OOB);
             if constexpr (AFF == 2) {
 #pragma unroll
-                for (int i = 0; i < RA; ++i) dma16(rw_in2, As + (unsigned)(BM * ROWB) + i * 4096u, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
+                for (int i = 0; i < RA; ++i) dma16(rw_in2, As + (unsigned)(BM * ROWB) + i * 4096u, (tm_ & (1u << i)) ? a_off[i] + cb : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) dma16(rw_w, Bs + i * 4096u, w_off[i] + (wtap + cb));
+        for (int i = 0; i < RB; ++i) dma16(rw_w, Bs + i * 4096u, live ? w_off[i] + (wtap + cb) : OOB);
     };
 
     // fragment reads: lane (l31, half) wants chunk 2 s + half of its rows for sub-step s; physically chunk (2 s + half) ^ swz(l31)
@@ -1191,7 +1193,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     int tap = 0, c0 = 0;
     auto advance = [&]() {
         c0 += KB;
-        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
+        if (c0 == a.Cin) { c0 = 0; if (++tap < ph.ntaps) set_tap(tap); }
     };
 
     set_tap(0);
@@ -1213,6 +1215,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     stage_done();
     if constexpr (NBUF == 2) {
         // unrolled by two: the stage buffer is a compile-time constant in every LDS address
+#ifndef AWR_GEMM_LOOP_NOEXITS
         int ks = 0;
         for (; ks + 2 <= ksteps; ks += 2) {
             advance(); issue(c0, 1);      // (ks + 1 < ksteps holds here)
@@ -1224,6 +1227,15 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
             if (more) stage_done();
         }
         if (ks < ksteps) compute(0);      // odd stage count: the last stage sits in buffer 0
+#else
+        // study build: whole pairs of stages and nothing conditional inside the trip (the stages requested beyond the K extent come from nowhere:
+        // zeros) -- what took 30-60 registers off the weight-gradient kernels takes 4-10 off this one (104 -> 94 for the plain 128x128 tile),
+        // isolated launches +-2 % either way, the step 0.5 % slower (profiles/r04_loop_exits.txt)
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            advance(); issue(c0, 1, ks + 1 < ksteps); compute(0); stage_done();
+            advance(); issue(c0, 0, ks + 2 < ksteps); compute(1); stage_done();
+        }
+#endif
     } else {
         for (int ks = 0; ks < ksteps; ++ks) {
             const bool more = ks + 1 < ksteps;
@@ -1604,20 +1616,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
     issue(m_begin, 0);
     commit(0);
     stage_done();
+    // whole pairs of stages, no exit inside the trip (an exit between the two halves costs accumulator copies: the kernel-row kernel went from
+    // 123 to 81 registers when its exits went): a stage beyond the chunk is requested from nowhere -- zeros
     for (int m0 = m_begin; m0 < m_end; m0 += 2 * KP) {
-        const bool more1 = m0 + KP < m_end;
-        if (more1) issue(m0 + KP, 1);
-        compute(0);
-        if (!more1) break;
-        commit(1);
-        stage_done();
-        const bool more2 = m0 + 2 * KP < m_end;
-        if (more2) issue(m0 + 2 * KP, 0);
-        compute(1);
-        if (more2) {
-            commit(0);
-            stage_done();
-        }
+        issue(m0 + KP, 1); compute(0); commit(1); stage_done();
+        issue(m0 + 2 * KP, 0); compute(1); commit(0); stage_done();
     }
 
 #pragma unroll
@@ -1668,22 +1671,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
 // taps read three consecutive positions, and position p + 2 of one pixel pair is position p' + 0 of the next -- per pixel pair ONE A read
 // and TWO new B reads feed THREE MFMAs into three independent accumulators.  Operands go global -> LDS by DMA (pixel-major rows: lane-linear,
 // no swizzle, as in conv_wgrad_dma_kernel), two stages in flight, one barrier per stage.
-//   GAFF: G is relu(g * scale + shift) of the stored tensor (a BatchNorm + ReLU output that was never written): per-lane constants (lane =
-//   channel) applied to the B fragments; halo / padding pixels must stay zero THROUGH the affine -- row validity is uniform per stage, the
-//   two halo columns only matter at the image's left / right edge (a per-lane 0 / 1 factor: the pair's two pixels sit in the two half-waves).
+//   GAFF: G is relu(g * scale + shift) of the stored tensor (a BatchNorm + ReLU output that was never written).  The arithmetic runs ONCE per
+//   staged element, in LDS, one stage ahead of the MFMAs: three stage buffers -- stage s + 2 is being requested, stage s + 1 (landed behind
+//   the previous barrier) is rewritten in place by the 256 threads (five floats each), stage s feeds the matrix pipe through the same
+//   fragment reads as the plain kernel -- still one barrier per stage.  Halo / padding pixels stay zero THROUGH the affine: their DMA wrote
+//   zeros and the rewrite skips them (rows outside the image, the two halo columns at the image's left / right edge).  (First version:
+//   multiply-add + clamp on every B fragment, i.e. on every element three times and in the MFMAs' dependency chain: matrix pipe busy 0.61
+//   against 0.73 for the plain kernel, 110 vs 130 TF on the 128 -> 128 layers at 64x64 -- profiles/r04_microbench_wgrad_row.txt.)
 //   The bias gradient (column sums of D = dY) is the sum of the A fragments over the stage's pixels: no register path for D either.
 #ifndef AWR_ROW_FENCE
 #define AWR_ROW_FENCE 2      // pixel pairs of fragment reads the scheduler may hoist in front of their MFMAs (study hook: 2 | 4 | 8)
 #endif
+#ifndef AWR_ROW_WAVES
+#define AWR_ROW_WAVES 4      // study hook: `4, 4` caps the resident waves per SIMD at four (the kernel needs 79-96 registers: five or six would fit)
+#endif
 template <int PW, bool GAFF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWR_ROW_WAVES))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
     constexpr int KP = 16;                           // D pixels per stage
     constexpr int PH = KP / PW;                      // rows per stage (1 | 2)
     constexpr int GW = PW + 2, GP = PH * GW;         // G pixel rows per stage: 18 | 20
     constexpr int DST = KP * 64 * 4;                 // bytes of the D stage (4 KB)
     constexpr int GST = 20 * 64 * 4;                 // ... of the G stage (five 1 KB DMA pieces)
     constexpr int STAGE = DST + GST;
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * STAGE];
+    constexpr int NB = GAFF ? 3 : 2;                 // stage buffers
+    __shared__ __attribute__((aligned(16))) char smem_raw[NB * STAGE + (GAFF ? 512 : 0)];      // GAFF: + the tile's 64 (scale, shift) pairs
 
     const int tiles_cg = (a.Cg + 63) >> 6, tiles_cd = (a.Cd + 63) >> 6;
     int wg = blockIdx.x;
@@ -1715,10 +1726,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
         g_r[i] = slot < GP ? slot / GW : -(1 << 20);      // (a slot beyond the patch: always out of range)
         g_j[i] = slot % GW;
     }
-    unsigned edge_l = 1, edge_r = 1, rowmask = 3;        // the stage being MULTIPLIED: left / right halo column inside the image, rows inside
-    unsigned n_edge_l = 1, n_edge_r = 1, n_rowmask = 3;  // ... the stage being REQUESTED
-    auto issue = [&](int st, int buf) {
-        int b, y0, x0;
+    auto geom = [&](int st, int& b, int& y0, int& x0) {      // stage -> image, first D row, first D column
         if constexpr (PH == 1) {
             x0 = (st & (segs_x - 1)) * PW;
             const int t = st >> (wlog - (PW == 16 ? 4 : 3));
@@ -1730,23 +1738,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             y0 = (st & (rows - 1)) * PH;
             b = st >> (hlog - 1);
         }
+    };
+    auto issue = [&](int st, int buf) {
+        int b, y0, x0;
+        geom(st, b, y0, x0);
+        const bool live = st < s_end;      // (GAFF walks whole triples of stages: a stage beyond the range is requested from nowhere -- zeros)
         const unsigned Dl = lds0 + (unsigned)(buf * STAGE), Gl = lds0 - (unsigned)wave * 1024u + (unsigned)(buf * STAGE + DST);
         {
             const int r = dpx / PW, c = dpx % PW;
             const unsigned pix = (unsigned)((((b << hlog) + y0 + r) << wlog) + x0 + c);
-            dma16(rw_d, Dl, d_cok ? __umul24(pix, dpitch) + d_col : OOB);
+            dma16(rw_d, Dl, d_cok && live ? __umul24(pix, dpitch) + d_col : OOB);
         }
         const int gy0 = y0 + ty - 1;
-        n_rowmask = 0;
-#pragma unroll
-        for (int r = 0; r < PH; ++r) n_rowmask |= ((unsigned)(gy0 + r) < (unsigned)H) ? (1u << r) : 0u;
-        n_edge_l = x0 > 0;
-        n_edge_r = x0 + PW < W;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i == 1 && wave != 0) break;          // (wave-uniform: the fifth piece belongs to wave 0)
             const int gy = gy0 + g_r[i], gx = x0 - 1 + g_j[i];
-            const bool ok = g_cok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const bool ok = g_cok && live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             const unsigned pix = (unsigned)((((b << hlog) + gy) << wlog) + gx);
             dma16(rw_g, Gl + (unsigned)((i == 0 ? wave : 4) * 1024), ok ? __umul24(pix, gpitch) + g_col : OOB);
         }
@@ -1756,35 +1764,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float gsc = 1.f, gsh = 0.f;
-    if (GAFF && tcg * 64 + wn * 32 + l31 < a.Cg) { gsc = a.g_scale[tcg * 64 + wn * 32 + l31]; gsh = a.g_shift[tcg * 64 + wn * 32 + l31]; }
+    // GAFF: this thread rewrites float4 `tid` (and, threads 0..63, float4 256 + tid) of the landed G stage: pixel slot tid >> 4 (16 + (tid >> 4)),
+    // channels ch4 .. ch4 + 3 -- coefficients out of range are zero (those columns were never fetched: zeros stay zeros)
+    // (kept in LDS and re-read per stage: eight more resident registers spill at this kernel's 128)
+    float* const gco = reinterpret_cast<float*>(smem_raw + NB * STAGE);
+    if (GAFF && tid < 64) {
+        const bool cok = tcg * 64 + tid < a.Cg;
+        gco[tid] = cok ? a.g_scale[tcg * 64 + tid] : 0.f;
+        gco[64 + tid] = cok ? a.g_shift[tcg * 64 + tid] : 0.f;
+    }
     const float g_lo = a.g_relu ? 0.f : -__builtin_inff();
+    auto transform = [&](int st, int buf) {
+        if constexpr (GAFF) {
+            __builtin_amdgcn_sched_barrier(0);      // (its temporaries die before the stage's fragment reads start)
+            int b, y0, x0;
+            geom(st, b, y0, x0);
+            const int gy0 = y0 + ty - 1;
+            const bool edge_l = x0 > 0, edge_r = x0 + PW < W;
+            float* const Gs = reinterpret_cast<float*>(smem_raw + buf * STAGE + DST);
+            const float4 gsc = ld4(gco + ch4), gsh = ld4(gco + 64 + ch4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && tid >= 64) break;
+                const int slot = 16 * i + (tid >> 4);
+                if (slot >= GP) break;               // (PW == 16: the patch has 18 pixel slots)
+                const int r = slot / GW, j = slot - r * GW;
+                const bool ok = st < s_end && (unsigned)(gy0 + r) < (unsigned)H && (j != 0 || edge_l) && (j != GW - 1 || edge_r);
+                if (ok) {
+                    float4 v = ld4(Gs + slot * 64 + ch4);
+                    v.x = __builtin_amdgcn_fmed3f(v.x * gsc.x + gsh.x, g_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * gsc.y + gsh.y, g_lo, __builtin_inff());
+                    v.z = __builtin_amdgcn_fmed3f(v.z * gsc.z + gsh.z, g_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * gsc.w + gsh.w, g_lo, __builtin_inff());
+                    st4(Gs + slot * 64 + ch4, v);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     const bool do_colsum = a.d_colsum != nullptr && ty == 0 && tcg == 0 && wn == 0;
     float csum = 0.f;
     const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * 64 + wm * 32 + l31;               // D[pixel][cd]
     const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * 64 + wn * 32 + l31;         // G[patch pixel][cg]
     auto compute = [&](int buf) {
-        // Padding through the affine WITHOUT per-read work: a G row outside the image, and the two halo columns at the image's left / right
-        // edge (position 0 is read by the half-wave h = 0 of a row's first pixel pair, position PW + 1 by h = 1 of its last pair), get
-        // scale = shift = 0 -- clamp(0 * 0 + 0) = 0 -- chosen once per stage; every fragment read then costs one multiply-add and one clamp
-        float rsc[PH], rsh[PH], lsc[PH], lsh[PH], esc[PH], esh[PH];
-        if constexpr (GAFF) {
-#pragma unroll
-            for (int r = 0; r < PH; ++r) {
-                const bool rv = rowmask & (1u << r);
-                rsc[r] = rv ? gsc : 0.f; rsh[r] = rv ? gsh : 0.f;
-                const bool lv = rv && (half != 0 || edge_l), ev = rv && (half != 1 || edge_r);
-                lsc[r] = lv ? gsc : 0.f; lsh[r] = lv ? gsh : 0.f;
-                esc[r] = ev ? gsc : 0.f; esh[r] = ev ? gsh : 0.f;
-            }
-        }
         auto gread = [&](int r, int pos) -> float {      // G position `pos` (0 = left halo) of patch row r for this lane's half: pos + half
-            float v = b_frag[buf * (STAGE / 4) + (r * GW + pos) * 64];
-            if constexpr (GAFF) {
-                const float sc = pos == 0 ? lsc[r] : pos == PW ? esc[r] : rsc[r], sh = pos == 0 ? lsh[r] : pos == PW ? esh[r] : rsh[r];
-                v = __builtin_amdgcn_fmed3f(v * sc + sh, g_lo, __builtin_inff());
-            }
-            return v;
+            return b_frag[buf * (STAGE / 4) + (r * GW + pos) * 64];
         };
 #pragma unroll
         for (int r = 0; r < PH; ++r) {
@@ -1812,18 +1834,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     if (s_begin < s_end) {
         issue(s_begin, 0);
         stage_done();
-        for (int st = s_begin; st < s_end; st += 2) {
-            edge_l = n_edge_l; edge_r = n_edge_r; rowmask = n_rowmask;
-            const bool more1 = st + 1 < s_end;
-            if (more1) issue(st + 1, 1);
-            compute(0);
-            if (!more1) break;
+        if constexpr (GAFF) {
+            transform(s_begin, 0);
+            issue(s_begin + 1, 1);
             stage_done();
-            edge_l = n_edge_l; edge_r = n_edge_r; rowmask = n_rowmask;
-            const bool more2 = st + 2 < s_end;
-            if (more2) issue(st + 2, 0);
-            compute(1);
-            if (more2) stage_done();
+            // three stages per trip (every LDS address a compile-time constant; no exits inside the trip -- exits there cost accumulator
+            // copies the allocator spilled): buffer of stage st = (st - s_begin) % 3; the last trip's surplus stages are zeros
+            for (int st = s_begin; st < s_end; st += 3) {
+                issue(st + 2, 2); transform(st + 1, 1); compute(0); stage_done();
+                issue(st + 3, 0); transform(st + 2, 2); compute(1); stage_done();
+                issue(st + 4, 1); transform(st + 3, 0); compute(2); stage_done();
+            }
+        } else {
+            for (int st = s_begin; st < s_end; st += 2) {      // (whole pairs, for the same reason)
+                issue(st + 1, 1); compute(0); stage_done();
+                issue(st + 2, 0); compute(1); stage_done();
+            }
         }
     }
     {
@@ -2676,17 +2702,20 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
             (int64_t)a->B * a->Hg * a->Wg < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24))
             hshift_f32 = hshift | 64 | (gws << 8) | (ghs << 16);
     }
-    // LDS-DMA staging (conv_wgrad_dma_kernel) is OPT-IN (AWR_WGRAD_DMA=1; AWR_WGRAD_KP = stage depth in pixels, 16 | 32): isolated launches of the
-    // 64x64 tile gain 4-7 % with both operands plain (profiles/r04_microbench_wgrad_dma.txt), the wider tiles nothing, an operand that still goes
-    // through registers (fused BatchNorm loader, bias-gradient column sums) loses 5-10 %, and the step does not move: the weight gradient is
-    // not limited by its staging (it co-runs with the data-gradient chain, re-reads D once per tap and ends in split-K atomics).
-    static const int wdma = env_int("AWR_WGRAD_DMA", 0);
+    // LDS-DMA staging (conv_wgrad_dma_kernel): the default whenever BOTH operands are plain (AWR_WGRAD_DMA: 0 = never, 1 = always, unset = that
+    // rule; AWR_WGRAD_KP = stage depth in pixels, 16 | 32).  Since its pipelined loop lost its exits (162 -> 100 / 96 -> 69 / 50 -> 36 registers)
+    // isolated launches with plain operands gain 5-7 % on every layer shape (profiles/r04_microbench_wgrad_dma.txt) and the ResNet18 step 0.8 %;
+    // an operand that still goes through registers (fused BatchNorm loader, bias-gradient column sums) gains nothing in isolation and the
+    // Hourglass step (nearly all of whose weight gradients have one) nothing either.
+    static const int wdma = env_int("AWR_WGRAD_DMA", -1);
     static const int wkp = env_int("AWR_WGRAD_KP", 0);
     if (wdma && g_staging && g_products == 1 && hshift_f32 >= 64) {
         const bool dreg = a->d_scale != nullptr || a->d_colsum != nullptr, greg = a->g_scale != nullptr;
-        const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);
-        launch_wgrad_dma(a, TM, TN, kp, dreg, greg, grid, st, (int)chunk, wshift, hshift_f32);
-        return check_launch("conv_wgrad_dma_kernel");
+        if (wdma > 0 || (!dreg && !greg)) {
+            const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);
+            launch_wgrad_dma(a, TM, TN, kp, dreg, greg, grid, st, (int)chunk, wshift, hshift_f32);
+            return check_launch("conv_wgrad_dma_kernel");
+        }
     }
 #define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
     do {                                                                                                                                  \

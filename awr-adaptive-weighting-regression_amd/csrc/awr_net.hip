@@ -2060,11 +2060,20 @@ static int autotune(awr_plan& P, int reps, void* stream) {
     auto launch = [&](GemmRef& g) { return g.ca ? awr_conv_gemm(g.ca, stream) : awr_conv_wgrad(g.wa, stream); };
     int rc = AWR_OK;
     for (auto& g : P.gemms) {
-        if (g.wa && g.wa->algo == 2) continue;      // the wave-per-tap kernel has one geometry
-        if (g.ca && g.ca->w2) continue;             // ... and so has the fused conv pair
+        if (g.ca && g.ca->w2) continue;             // the fused conv pair has one geometry
         struct Cand { int tm, tn, tb, algo = 0; };
         std::vector<Cand> cands;
-        if (g.ca) {
+        if (g.wa && g.wa->algo == 2) {
+            // The wave-per-tap kernel has one geometry and stays.  AWR_TUNE_TAPS=1 (study hook) times it against the kernel-row kernel's split-K
+            // depths: isolated, the row kernel with its in-LDS BatchNorm loader wins on these layers (127 vs 122.5 TF) and the tuner takes it --
+            // and the Hourglass-1 step gets 0.3 ms SLOWER (23.6 -> 23.9 ms, three interleaved repetitions, profiles/r04_loop_exits.txt): a
+            // weight gradient is a side-stream kernel, what counts is how it shares the CUs with the data-gradient chain it runs beside, and
+            // 256 twelve-wave workgroups share better than 768-1280 four-wave ones that can fill every SIMD's register file.
+            static const bool tune_taps = getenv("AWR_TUNE_TAPS") != nullptr;
+            if (!tune_taps || !awr_conv_wgrad_algo_ok(g.wa, 3)) continue;
+            cands = {{1, 1, 0, 2}};
+            for (int tb : {768, 1024, 1280, 1536, 2048}) cands.push_back({1, 1, tb, 3});
+        } else if (g.ca) {
             cands = {{1, 1, 0}, {2, 1, 0}};
             if (g.ca->N > 64) { cands.push_back({1, 2, 0}); cands.push_back({2, 2, 0}); }
             if (g.ca->partial && g.ca->split_max > 1 && awr_get_gemm_products() == 1) {      // (tile, split-K depth) pairs; tb = depth
@@ -2081,14 +2090,14 @@ static int autotune(awr_plan& P, int reps, void* stream) {
             // one workgroup per kernel row (3x3 stride 1): its own split-K depths; the per-tap candidates above then run as algo 1
             if ((g.wa->algo == 0 || g.wa->algo == 3) && awr_conv_wgrad_algo_ok(g.wa, 3)) {
                 for (auto& c : cands) c.algo = 1;
-                for (int tb : {768, 1024, 1536, 2048}) cands.push_back({1, 1, tb, 3});
+                for (int tb : {768, 1024, 1280, 1536, 2048}) cands.push_back({1, 1, tb, 3});
             }
         }
         float best_t = 1e30f;
         Cand best = cands[0];
         for (auto& c : cands) {
             if (g.ca) { g.ca->tile_m = c.tm; g.ca->tile_n = c.tn; if (c.tb) g.ca->split_k = c.tb; }
-            else { g.wa->tile_m = c.tm; g.wa->tile_n = c.tn; if (c.tb) g.wa->target_blocks = c.tb; if (c.algo) g.wa->algo = c.algo; }
+            else { g.wa->tile_m = c.tm; g.wa->tile_n = c.tn; g.wa->target_blocks = c.tb; if (c.algo) g.wa->algo = c.algo; }
             if ((rc = launch(g))) break;      // warm-up
             (void)hipEventRecord(e0, main);
             for (int r = 0; r < reps && rc == AWR_OK; ++r) rc = launch(g);
@@ -2101,7 +2110,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
         }
         if (rc) break;
         if (g.ca) { g.ca->tile_m = best.tm; g.ca->tile_n = best.tn; if (best.tb) g.ca->split_k = best.tb; }
-        else { g.wa->tile_m = best.tm; g.wa->tile_n = best.tn; if (best.tb) g.wa->target_blocks = best.tb; if (best.algo) g.wa->algo = best.algo; }
+        else { g.wa->tile_m = best.tm; g.wa->tile_n = best.tn; g.wa->target_blocks = best.tb; if (best.algo) g.wa->algo = best.algo; }
         g.tm = best.tm; g.tn = best.tn; g.tb = best.tb; g.us = best_t * 1e3f; g.tuned = true;
     }
     (void)hipEventDestroy(e0);
@@ -2535,6 +2544,25 @@ int awr_plan_set_gemm(awr_plan* p, int i, int tile_m, int tile_n, int target_blo
         g.wa->tile_m = tile_m; g.wa->tile_n = tile_n; if (target_blocks) g.wa->target_blocks = target_blocks;
     }
     g.tm = tile_m; g.tn = tile_n; g.tb = target_blocks; g.us = us; g.tuned = true;
+    return AWR_OK;
+}
+
+int awr_plan_gemm_algo(const awr_plan* p, int i, int* algo) {
+    AWR_REQUIRE(p && algo && i >= 0 && i < (int)p->gemms.size(), "plan_gemm_algo: index out of range");
+    *algo = p->gemms[i].wa ? p->gemms[i].wa->algo : 0;
+    return AWR_OK;
+}
+
+int awr_plan_set_gemm_algo(awr_plan* p, int i, int algo) {
+    AWR_REQUIRE(p && i >= 0 && i < (int)p->gemms.size(), "plan_set_gemm_algo: index out of range");
+    GemmRef& g = p->gemms[i];
+    if (!g.wa) {
+        AWR_REQUIRE(algo == 0, "plan_set_gemm_algo: launch %d is not a weight gradient", i);
+        return AWR_OK;
+    }
+    AWR_REQUIRE(!p->det, "plan_set_gemm_algo: a deterministic plan keeps the default geometry of its weight gradients");
+    AWR_REQUIRE(algo >= 0 && algo <= 3 && awr_conv_wgrad_algo_ok(g.wa, algo), "plan_set_gemm_algo: algo %d does not serve launch %d", algo, i);
+    g.wa->algo = algo;
     return AWR_OK;
 }
 

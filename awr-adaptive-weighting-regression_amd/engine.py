@@ -319,7 +319,9 @@ class Plan:
     def _gemm(self, i):
         name, tm, tn, tb, us, tuned = C.c_char_p(), C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_int()
         L.call("awr_plan_gemm", self.h, i, C.byref(name), C.byref(tm), C.byref(tn), C.byref(tb), C.byref(us), C.byref(tuned))
-        return name.value.decode(), (tm.value, tn.value, tb.value), us.value, bool(tuned.value)
+        algo = C.c_int()
+        L.call("awr_plan_gemm_algo", self.h, i, C.byref(algo))
+        return name.value.decode(), (tm.value, tn.value, tb.value, algo.value), us.value, bool(tuned.value)
 
     def autotune(self, reps=3, cache_key=None):
         """Pick the fastest workgroup tile (and split-K depth) for every GEMM launch of this static plan by timing the candidates
@@ -340,10 +342,13 @@ class Plan:
                 ent = None
             if ent and all(n in ent for n in names):
                 for i, n in enumerate(names):
-                    (tm, tn, tb), t = ent[n]
+                    (tm, tn, tb, *rest), t = ent[n]
+                    algo = rest[0] if rest else 0     # (files written before the algorithm was stored: the plan's own choice stays)
                     if tm and tn:                     # (0, 0): a launch the tuner leaves alone (one-geometry kernels)
                         L.call("awr_plan_set_gemm", self.h, i, tm, tn, tb, float(t))
-                    self.tuned[n] = ((tm, tn, tb), t)
+                        if algo:
+                            L.call("awr_plan_set_gemm_algo", self.h, i, algo)
+                    self.tuned[n] = ((tm, tn, tb, algo), t)
                 return
         L.call("awr_plan_autotune", self.h, int(reps), L.stream())
         for i in range(self.n_gemm):

@@ -488,6 +488,10 @@ int awr_plan_autotune(awr_plan* plan, int reps, void* stream);
 int awr_plan_gemm(const awr_plan* plan, int i, const char** name, int* tile_m, int* tile_n, int* target_blocks,
                   float* us, int* tuned);
 int awr_plan_set_gemm(awr_plan* plan, int i, int tile_m, int tile_n, int target_blocks, float us);
+/* ... and the algorithm of a weight-gradient launch (awr_wgrad_args.algo: 0 automatic, 1 workgroup per tap, 2 wave per tap, 3 workgroup
+ * per kernel row; always 0 for conv launches): what a tuning cache stores beside the tile.  set: AWR_ERR_ARG if the launch cannot run it. */
+int awr_plan_gemm_algo(const awr_plan* plan, int i, int* algo);
+int awr_plan_set_gemm_algo(awr_plan* plan, int i, int algo);
 
 /* ------------------------------------------------------------------------------------------
  * Data-parallel API (net-new w.r.t. the reference, which hard-wires one GPU: train.py:29,:233).

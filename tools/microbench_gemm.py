@@ -103,7 +103,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset", "rowset"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -151,6 +151,19 @@ def main():
             if spec.kind == "conv" and spec.k == 3 and spec.stride == 1:      # one workgroup per kernel row (algo 3): split-K candidates
                 for blocks in (512, 768, 1024, 1536, 2048, 3072):
                     res.append("row/%d %5.1f|%5.1f" % (blocks, run_wgrad(spec, B, H, None, algo=3, blocks=blocks)[1], run_wgrad(spec, B, H, None, algo=3, blocks=blocks, affine=True)[1]))
+            print("%-28s %s" % (name, "  ".join(res)), flush=True)
+    elif args.mode == "rowset":      # kernel-row weight gradient only (algo 3) over its split-K depths, plain | fused BatchNorm loader; the wave-per-tap
+        B = args.batch                # kernel (algo 2) beside it -- same-box A/B of builds through AWR_LIB_PATH (tools/gpu_r4_p.sh)
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("hg pre.1 3x3 64->64 @128", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 128),
+                  ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32), ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8)]
+        print("%s batch %d: TF plain|affine loader" % (os.environ.get("AWR_LIB_PATH", "in-tree"), B))
+        for name, spec, H in shapes:
+            res = []
+            for blocks in (768, 1024, 1280, 1536, 2048, 2560, 3072):
+                res.append("row/%d %5.1f|%5.1f" % (blocks, run_wgrad(spec, B, H, None, algo=3, blocks=blocks)[1], run_wgrad(spec, B, H, None, algo=3, blocks=blocks, affine=True)[1]))
+            if L.lib.awr_conv_wgrad_algo_ok is not None and spec.cin == 128 and H >= 64:
+                res.append("taps %5.1f|%5.1f" % (run_wgrad(spec, B, H, None, algo=2)[1], run_wgrad(spec, B, H, None, algo=2, affine=True)[1]))
             print("%-28s %s" % (name, "  ".join(res)), flush=True)
     elif args.mode == "tiles":       # forward only, every tile, a few representative layers (used by tools/probe_gemm.sh)
         B = args.batch
