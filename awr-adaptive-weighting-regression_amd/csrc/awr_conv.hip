@@ -2576,20 +2576,20 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     w->row_pw = 0;
     {   // one workgroup per kernel row: 3x3, stride 1, same-size power-of-two maps, taps row-major from the top-left one, D plain
         const bool ok = wgrad_row_ok(a);
-        // default (algo 0): wherever the gathered operand is plain -- isolated launches 114-131 TF against 99-120 for the best per-tap
-        // geometry -- and, with the fused BatchNorm loader (its arithmetic sits between every fragment read and its MFMA: -10 %), only on
-        // the 64-channel layers with >= 64x64 maps, where the per-tap kernel is at its worst (95 -> 101 TF).  AWR_WGRAD_ROW: 0 = never,
-        // 1 = wherever the geometry allows; an explicit algo wins, and the plan autotuner times algo 3 against the per-tap geometries.
+        // default (algo 0): wherever the geometry allows -- isolated launches 121-136 TF against 105-127 for the best per-tap geometry with a
+        // plain gathered operand, 114-127 against 98-124 with the fused BatchNorm loader (since that became an in-LDS pass;
+        // profiles/r04_loop_exits.txt).  AWR_WGRAD_ROW=0: never; an explicit algo wins, and the plan autotuner times algo 3 against the
+        // per-tap geometries per launch.
         static const int env_row = env_int("AWR_WGRAD_ROW", -1);
-        const bool want_row = env_row >= 0 ? env_row != 0 : (!a->g_scale || (a->Wd >= 64 && a->Cd <= 64 && a->Cg <= 64));
+        const bool want_row = env_row != 0;
         AWR_REQUIRE(a->algo != 3 || ok, "conv_wgrad: algo 3 (workgroup per kernel row) serves 3x3 stride-1 filters on power-of-two maps >= 8 wide in the FP32-MFMA mode");
         if (ok && (a->algo == 3 || (a->algo == 0 && want_row))) {
             w->row_pw = a->Wd >= 16 ? 16 : 8;
             const int64_t nstage = M / 16;
             w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64) * 3;
-            // four workgroups per CU are resident (registers): 1024 slots.  The workgroups of a launch are equally long, so the count that
-            // fits ONE generation wins (isolated launches: 768 / 1536 workgroups 114-119 TF, 1026 -- two generations, the second almost
-            // empty -- 106; profiles/r04_microbench_wgrad_row.txt): floor, not ceil
+            // The workgroups of a launch are equally long, so the count that fits ONE generation of resident workgroups wins (five or six per
+            // CU by registers; isolated launches: 768 / 1024 / 1280 workgroups within 2 TF of each other, 1026 with the round's first build --
+            // two generations, the second almost empty -- 106 against 114-119; profiles/r04_microbench_wgrad_row.txt): floor, not ceil
             const int want = a->target_blocks > 0 ? a->target_blocks : 1024;
             int64_t nsplit = want / w->tiles;
             if (nsplit > nstage / 8) nsplit = nstage / 8;            // at least 8 stages (128 pixels) per workgroup

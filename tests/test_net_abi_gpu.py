@@ -104,6 +104,26 @@ def test_resnet18_train_step_through_the_c_abi_only(golden_dir):
             timed.setdefault(name.value.decode().split(":")[0], []).append(ms[i])
     assert len(timed["awr_conv_gemm"]) >= 20 and len(timed["awr_bn_finalize"]) >= 20 and len(timed["awr_bn_apply"]) >= 8 and "awr_stem_pool" in timed
     ok(lib.awr_plan_autotune(plan, 1, s))
+    # what a tuning cache stores per GEMM launch: tile, split-K target AND (weight gradients) the algorithm; presetting them is accepted,
+    # an algorithm the launch cannot run is refused
+    nm, tm, tn, tb, us, tuned, algo = C.c_char_p(), C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_int(), C.c_int()
+    seen = set()
+    for i in range(ng.value):
+        ok(lib.awr_plan_gemm(plan, i, C.byref(nm), C.byref(tm), C.byref(tn), C.byref(tb), C.byref(us), C.byref(tuned)))
+        ok(lib.awr_plan_gemm_algo(plan, i, C.byref(algo)))
+        kind = nm.value.decode().split(":")[0]
+        if tuned.value:
+            assert tm.value in (1, 2) and tn.value in (1, 2) and us.value > 0
+            ok(lib.awr_plan_set_gemm(plan, i, tm.value, tn.value, tb.value, us.value))
+            ok(lib.awr_plan_set_gemm_algo(plan, i, algo.value))
+        if kind == "awr_conv_wgrad":
+            assert algo.value in (0, 1, 2, 3)
+            seen.add(algo.value)
+            if nm.value.decode().endswith("layer2.0.conv1"):      # 3x3 stride 2: the kernel-row kernel does not serve it
+                assert lib.awr_plan_set_gemm_algo(plan, i, 3) != 0 and b"algo 3" in lib.awr_last_error()
+        else:
+            assert algo.value == 0 and lib.awr_plan_set_gemm_algo(plan, i, 1) != 0
+    assert 3 in seen or 1 in seen
     ok(lib.awr_plan_destroy(plan))
     ok(lib.awr_net_destroy(net))
 

@@ -990,3 +990,29 @@ def test_single_image_and_odd_batches(amd, dev, net):
         eng.step(img[:0].to(dev), jt_gt[:0].to(dev))
     with pytest.raises(L.AwrError):
         eng.step(img[:2].to(dev), jt_gt[:2].to(dev))
+
+
+def test_tuning_cache_round_trip(amd, dev, tmp_path, monkeypatch):
+    """AWR_TUNE_CACHE: the per-launch choices of the plan autotuner (tile, split-K target and -- weight gradients -- the algorithm) written by one
+    engine are what a second engine of the same shape runs with, without timing anything (engine.Plan.autotune, awr_plan_set_gemm[_algo])."""
+    import json
+    from awr_amd.trainer import TrainEngine
+    cache = tmp_path / "tune.json"
+    monkeypatch.setenv("AWR_TUNE_CACHE", str(cache))
+    J, ks, B = 14, 1.0, 4
+    man = O.manifest_for("resnet_18", J)
+    img, jt_gt = O.synth_batch(B, 128, J, seed=11)
+    tuned = []
+    for it in range(2):
+        m = make_net(amd, "resnet_18", J, O.procedural_state(man, seed=3))
+        eng = TrainEngine(m, B, 128, ks, coord_weight=1.0, use_graph=False)
+        losses, _ = eng.step(img.to(dev), jt_gt.to(dev))
+        assert torch.isfinite(losses).all()
+        tuned.append({k: (tuple(v[0]), v[1]) for k, v in eng.plan.tuned.items()})
+    ent = json.load(open(cache))
+    assert len(ent) == 1
+    stored = next(iter(ent.values()))
+    assert set(stored) == set(tuned[0]) and all(len(v[0]) == 4 for v in stored.values())
+    assert tuned[0] == tuned[1]
+    algos = {v[0][3] for k, v in tuned[1].items() if k.startswith("awr_conv_wgrad:")}
+    assert algos and algos <= {0, 1, 2, 3} and (algos & {1, 3})
