@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <map>
 #include <set>
 #include <vector>
 
@@ -88,11 +89,15 @@ struct awr_dp {
 };
 
 // live communicators: a plan keeps a raw pointer (awr_plan_set_dp) and must not call into one its host has destroyed
+// (keyed by address, valued by a process-wide generation number: a NEW communicator that the allocator places at a destroyed one's address
+// is a different generation, so a plan still holding the old pointer does not mistake it for its own)
 static std::mutex g_live_mu;
-static std::set<const awr_dp*> g_live;
-extern "C" int awr_dp_is_live(const awr_dp* d) {
+static std::map<const awr_dp*, unsigned long long> g_live;
+static unsigned long long g_next_gen = 1;
+extern "C" unsigned long long awr_dp_generation(const awr_dp* d) {      // 0 = not a live communicator
     std::lock_guard<std::mutex> lk(g_live_mu);
-    return g_live.count(d) ? 1 : 0;
+    auto it = g_live.find(d);
+    return it == g_live.end() ? 0ull : it->second;
 }
 
 using namespace awrdp;
@@ -164,7 +169,7 @@ int awr_dp_init(int rank, int world, const void* id128, awr_dp** out) {
     }
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
-        g_live.insert(d);
+        g_live[d] = g_next_gen++;
     }
     *out = d;
     return AWR_OK;

@@ -681,9 +681,11 @@ int awr_bn_bwd_apply(const float* dout, const float* act, const float* y, const 
                        invstd, coef, dgamma, dbeta, accumulate);
     if (int e = check_launch("bn_bwd_finalize_kernel")) return e;
     const int64_t n4 = npix * (C / 4);
-    // timing study only (results are WRONG): what the step would cost if the apply pass were free -- the upper bound of folding it into its consumers
+#ifdef AWR_STUDY_HOOKS      // study builds only (never the shipped library: a stray environment variable must not be able to corrupt training)
+    // timing study (results are WRONG): what the step would cost if the apply pass were free -- the upper bound of folding it into its consumers
     static const bool exp_skip = getenv("AWR_EXP_NO_BN_BWD_APPLY") != nullptr;
     if (exp_skip) return AWR_OK;
+#endif
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n4)), dim3(256), 0, as_stream(stream), dout, act, y, mean, invstd, mask_scale, mask_shift,
                        coef, n4, C, dy, dy_add, g_out);
     return check_launch("bn_bwd_apply_kernel");

@@ -29,7 +29,7 @@
 
 #include "awr_common.h"
 
-extern "C" int awr_dp_is_live(const awr_dp* d);      // csrc/awr_dp.hip: the registry of communicators that have not been destroyed
+extern "C" unsigned long long awr_dp_generation(const awr_dp* d);      // csrc/awr_dp.hip: generation of a communicator that has not been destroyed, else 0
 
 namespace awrnet {
 
@@ -704,6 +704,8 @@ struct awr_plan {
     void* bucket_user = nullptr;
     awr_dp* dp = nullptr;                 // native RCCL exchange of the buckets (awr_plan_set_dp)
     int dp_error = 0;
+    unsigned long long dp_gen = 0;      // generation of the attached communicator (awr_dp_generation at awr_plan_set_dp)
+    bool dp_lost = false;               // the attached communicator was destroyed under the plan: EVERY backward fails until awr_plan_set_dp is called again
     awr_bucket_cb saved_cb = nullptr;     // the host's callback while dp is attached
     void* saved_user = nullptr;
 };
@@ -890,9 +892,11 @@ struct Builder {
         a->stats = y->stats.p;
         a->stat_slots = y->stats.p ? y->stats.nslots : 0;
         a->relu_in = o.relu_in; a->relu_out = o.relu_out;
-        if (!P.training && !a->stats) {
+        if (!P.training && !a->stats && a->accum == 0) {
             // low-batch inference: a launch of a few workgroups, each walking a long K loop, is latency-bound -> split-K scratch
-            // (awr_conv_gemm picks the depth from the workgroup count, the tuner refines it)
+            // (awr_conv_gemm picks the depth from the workgroup count, the tuner refines it).  Not in a parity plan (blocked accumulation):
+            // the split-K kernel and the fused pair below accumulate in their own order -- a plan built in that mode only contains launch
+            // forms that honour it
             const int64_t wgs = ((int64_t)B * prob.Hq * prob.Wq + 63) / 64 * ((prob.N + 63) / 64) * (int64_t)prob.phases.size();
             int minsteps = 1 << 30;
             for (auto& ph : prob.phases) minsteps = std::min(minsteps, (int)ph.taps.size() * (a->Cin / 32));
@@ -927,7 +931,7 @@ struct Builder {
         const Spec &s2 = c2->spec, &s3 = c3->spec;
         const int64_t wgs = ((int64_t)x->B * x->H * x->W + 63) / 64;
         const int n1 = s2.cout;
-        if (off || P.training || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
+        if (off || P.training || awr_get_gemm_accum() != 0 || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
             (n1 != 128 && n1 != 64) || s3.cin != n1 || s3.cout != 2 * n1 || wgs < min_wgs || x->lazy || (dual && no_dual))
             return nullptr;
         if (dual && (dual->sk->spec.k != 1 || dual->sk->spec.stride != 1 || dual->sk->spec.cout != s3.cout || dual->sk->spec.cin_pad % 32 != 0 ||
@@ -1999,9 +2003,14 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
         for (auto st : P.branch) NET_CHECK(stream_wait(P, main, st));
         if (comm) NET_CHECK(stream_wait(P, main, comm));      // next step's scratch fill / optimiser must see the scatters
     }
-    if (is_bwd && P.dp && !P.dp_error && !awr_dp_is_live(P.dp)) {
+    if (is_bwd && P.dp && !P.dp_error && awr_dp_generation(P.dp) != P.dp_gen) {
         P.dp = nullptr;
-        set_error("plan: the data-parallel communicator attached with awr_plan_set_dp has been destroyed (detach it with awr_plan_set_dp(plan, NULL) first)");
+        P.dp_lost = true;
+    }
+    if (is_bwd && P.dp_lost) {      // sticky: replicas that skipped an exchange have diverged -- no later backward may report success
+        P.dp_error = 0;
+        set_error("plan: the data-parallel communicator attached with awr_plan_set_dp has been destroyed (detach it with awr_plan_set_dp(plan, NULL) first); "
+                  "gradients were NOT exchanged -- attach a communicator (or NULL) with awr_plan_set_dp to continue");
         return AWR_ERR_ARG;
     }
     if (is_bwd && P.dp && P.n_buckets <= 1 && !P.dp_error)        // a one-bucket plan has no markers: one exchange after the backward
@@ -2465,9 +2474,10 @@ int awr_plan_set_bucket_callback(awr_plan* p, awr_bucket_cb cb, void* user) {
 
 // the plan's own bucket callback while a communicator is attached: gradient arena [lo, hi) is final in `stream` order
 static int dp_dead(awr_plan* p) {      // the host destroyed the communicator before detaching it (awr_plan_set_dp(plan, NULL)): fail, do not dereference
-    if (awr_dp_is_live(p->dp)) return 0;
+    if (awr_dp_generation(p->dp) == p->dp_gen) return 0;
     awr::set_error("plan: the data-parallel communicator attached with awr_plan_set_dp has been destroyed (detach it with awr_plan_set_dp(plan, NULL) first)");
     p->dp = nullptr;
+    p->dp_lost = true;
     return AWR_ERR_ARG;
 }
 static void dp_bucket(void* user, int64_t lo, int64_t hi, void* stream) {
@@ -2483,8 +2493,11 @@ int awr_plan_set_dp(awr_plan* p, awr_dp* dp) {
         p->saved_cb = p->bucket_cb;
         p->saved_user = p->bucket_user;
     }
+    AWR_REQUIRE(!dp || awr_dp_generation(dp) != 0, "plan_set_dp: not a live communicator");
     p->dp = dp;
+    p->dp_gen = dp ? awr_dp_generation(dp) : 0;
     p->dp_error = 0;
+    p->dp_lost = false;
     if (dp) {
         p->bucket_cb = dp_bucket;
         p->bucket_user = p;

@@ -333,7 +333,8 @@ class Plan:
             return
         cache_file = os.environ.get("AWR_TUNE_CACHE")
         if cache_key:
-            cache_key += "/x%d/s%d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging())      # tile choices differ between the modes
+            # tile choices differ between the modes (products, staging, and the plan's accumulation order: blocked doubles the accumulators)
+            cache_key += "/x%d/s%d/a%d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging(), int(getattr(self, "accum", 0)))
         names = [self._gemm(i)[0] for i in range(self.n_gemm)]
         if cache_file and cache_key and os.path.exists(cache_file):
             try:

@@ -156,6 +156,7 @@ class AwrBackbone(nn.Module):
                 plan = Plan(self, B, H, H // getattr(self, "downsample", 2), self.J, training, supervised, bn_repeat, n_buckets)
             finally:
                 L.call("awr_set_gemm_accum", was)
+            plan.accum = acc          # 0 = ordered, 1 = blocked: what the plan's GEMM launches captured
             self._plans[key] = plan
         return plan
 

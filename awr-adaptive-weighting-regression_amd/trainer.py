@@ -404,6 +404,7 @@ class InferEngine:
         """parity=True: blocked accumulation in the GEMMs of this engine's plan (awr_amd.set_gemm_accum) -- scoring passes (test.py:67-86) care
         about the last digits of the joints, not about the last few per cent of throughput."""
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
+        self.parity = bool(parity)
         net.eval()
         self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if parity else None)
         if self.plan.n_side == 0:          # forward branches (ResNet downsample projections, Hourglass skip residuals) run beside the main chain
@@ -661,7 +662,9 @@ class Trainer:
         import numpy as np
         cfg = self.config
         world = torch.distributed.get_world_size(self.pg) if self.pg is not None else 1
-        inf = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False)
+        # scoring is the pass the parity mode exists for: blocked accumulation unless the config opts out (config.parity_infer)
+        inf = self._last_infer = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False,
+                                             parity=bool(getattr(cfg, "parity_infer", True)))
         ev = self.EvalUtil(self.testData.img_size, self.testData.paras, self.testData.flip, self.testData.jt_num)
         n, bs = len(self.testData), cfg.batch_size
         mine = [b for b in range((n + bs - 1) // bs) if b % world == self.rank]

@@ -123,8 +123,9 @@ def _make_net(awr_amd, name, J=14):
     return awr_amd.get_deconv_net(int(name.split("_")[1]), J, 2) if name.startswith("resnet") else awr_amd.PoseNet(name, J)
 
 
-def parity_mm(net_name, ks, dev):
-    """mean / max 3D joint difference (mm, 300 mm cube => x150) between the HIP path and the oracle, eval mode."""
+def parity_mm(net_name, ks, dev, parity=False):
+    """mean / max 3D joint difference (mm, 300 mm cube => x150) between the HIP path and the oracle, eval mode (parity=True: the engine's
+    blocked-accumulation plan, the mode Trainer.test scores with)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import awr_oracle as O
     import awr_amd
@@ -134,7 +135,7 @@ def parity_mm(net_name, ks, dev):
     m = _make_net(awr_amd, net_name)
     m.load_state_dict(sd)
     m = m.cuda()
-    jt = InferEngine(m, 4, 128, ks, use_graph=False)(img.to(dev)).cpu()
+    jt = InferEngine(m, 4, 128, ks, use_graph=False, parity=parity)(img.to(dev)).cpu()
     with torch.no_grad():
         ref = O.offset2joint_softmax(O.backbone_forward(net_name, sd, img)[-1], img, ks)
     d = (jt - ref).norm(dim=-1) * 150.0
@@ -149,7 +150,7 @@ def _pool_info(L):
     return k.value
 
 
-def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None):
+def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None, parity=False):
     """test.py:67-86 path: eval-mode BatchNorm folded into the GEMM epilogues, img -> dense map -> joints.  Returns images/s, ms per
     batch and the fraction of the MFMA roofline (algorithmic conv FLOPs of the forward / time / peak)."""
     from awr_amd.trainer import InferEngine
@@ -157,7 +158,7 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
     if net is None:
         torch.manual_seed(0)
         net = _make_net(awr_amd, net_name).cuda()
-    inf = InferEngine(net, batch, 128, ks, use_graph=graph)
+    inf = InferEngine(net, batch, 128, ks, use_graph=graph, parity=parity)
     imgs, _ = O.synth_batch(batch, 128, 14, seed=1234 + rank)
     imgs = imgs.to(dev)
     for _ in range(warmup):
@@ -188,14 +189,14 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
             "mfma_frac": round(flop_mult * 2 * macs / (el / steps) / 1e12 / peak_tf, 4)}
 
 
-def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, peak_tf, workload):
+def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, peak_tf, workload, accum=None):
     """Sub-record for one more single-GPU BASELINE training shape (same protocol as the headline: inputs resident in HBM, `warmup` untimed
     steps, `steps` steps between two synchronisations, the FULL fused step -- GT map, forward, head, Huber, backward, Adam)."""
     import time as _t
     from awr_amd.trainer import TrainEngine
     torch.manual_seed(0)
     net = (awr_amd.get_deconv_net(18, J, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, J)).cuda()
-    eng = TrainEngine(net, batch, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False)
+    eng = TrainEngine(net, batch, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False, accum=accum)
     img, jt = O.synth_batch(batch, H, J, seed=977)
     img, jt = img.to(dev), jt.to(dev)
     eng.compile(img, jt)
@@ -252,7 +253,42 @@ def _spawn_ranks(n):
     return rc
 
 
-def _ranks_seen(pg, dev):
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _pin_cpu_affinity(dev, local, nlocal):
+    """N > 1: keep the rank process (its launch thread issues ~190 launches per step) on the CPUs of its GPU's NUMA node -- the node the PCI
+    device reports under /sys; when the platform reports none (-1), an equal contiguous share of the allowed CPUs per local rank.  Returns
+    what was done (it goes into the line's `ranks_seen`)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        pr = torch.cuda.get_device_properties(dev)
+        node, src = -1, None
+        bus, devid, dom = getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None), getattr(pr, "pci_domain_id", 0)
+        if bus is not None and devid is not None:
+            src = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (int(dom), int(bus), int(devid))
+            if os.path.exists(src):
+                node = int(open(src).read().strip())
+        cpus = set()
+        if node >= 0:
+            cpus = _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) & allowed
+        if not cpus:          # no NUMA information: contiguous shares of what the launcher allowed
+            al = sorted(allowed)
+            per = max(1, len(al) // max(nlocal, 1))
+            cpus, src = set(al[local * per:(local + 1) * per]) or allowed, "equal share of the %d allowed CPUs" % len(al)
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node if node >= 0 else None, "n_cpus": len(cpus), "first_cpu": min(cpus), "source": src}
+    except Exception as e:          # never fatal: an unpinned rank is slower, not wrong
+        return {"numa_node": None, "error": "%s: %s" % (type(e).__name__, e)}
+
+
+def _ranks_seen(pg, dev, extra=None):
     """What actually ran: every rank's (rank, device index, device name, uuid / PCI bus id, pid), all-gathered."""
     pr = torch.cuda.get_device_properties(dev)
     me = {"rank": int(os.environ.get("RANK", "0")), "device": dev.index, "name": pr.name, "pid": os.getpid()}
@@ -260,11 +296,22 @@ def _ranks_seen(pg, dev):
         v = getattr(pr, k, None)
         if v is not None:
             me[k] = str(v)
+    if extra:
+        me.update(extra)
     if pg is None:
         return [me]
     out = [None] * torch.distributed.get_world_size(pg)
     torch.distributed.all_gather_object(out, me, group=pg)
     return out
+
+
+def _replicas_equal(net):
+    """Data parallel: True when every rank holds bitwise-identical active parameters (max == min over the ranks, element-wise)."""
+    flat = net.flat_params()[:net.n_active]
+    mx, mn = flat.clone(), flat.clone()
+    torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(mn, op=torch.distributed.ReduceOp.MIN)
+    return bool(torch.equal(mx, mn))
 
 
 def _rccl_version():
@@ -299,6 +346,9 @@ def main():
                                                                "the per-bucket all-reduce timeline is reported either way when N > 1")
     ap.add_argument("--no-hourglass-train", action="store_true", help="skip the Hourglass training sub-records 'hg1_train_b64' and 'config5'")
     ap.add_argument("--no-b256", action="store_true", help="skip the config-4 per-GPU shape (batch 256) sub-record")
+    ap.add_argument("--no-accurate-mode", action="store_true", help="skip the blocked-accumulation (parity mode) sub-record 'accurate_mode'")
+    ap.add_argument("--no-native-rccl", action="store_true", help="N > 1: skip the 'native_rccl' sub-record (same steps, gradient buckets exchanged by the "
+                                                                  "library's own RCCL communicator instead of torch.distributed work objects)")
     ap.add_argument("--deterministic", action="store_true", help="awr_amd.set_deterministic(True): bitwise-reproducible steps (no atomics on shared "
                                                                   "accumulators, no autotuning); reports what that costs")
     args = ap.parse_args()
@@ -321,6 +371,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = None
+    if world > 1 and os.environ.get("AWR_NO_AFFINITY") != "1":
+        affinity = _pin_cpu_affinity(dev, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     pg, backend = None, None
     if world > 1 or os.environ.get("AWR_FORCE_DP") == "1":      # AWR_FORCE_DP: exercise the data-parallel path on a 1-rank group (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -381,18 +434,14 @@ def main():
     warm = args.warmup
     elapsed = timed_steps(eng, img, jt, args.steps, warm)
     loss = float(eng.losses[2])
-    ranks_seen = _ranks_seen(pg, dev)
+    ranks_seen = _ranks_seen(pg, dev, {"cpu_affinity": affinity} if affinity is not None else None)
 
     # data-parallel self-test (after the timed region): replicas must hold bitwise-identical parameters after all those steps (every rank
     # stepped its own images; the all-reduced gradients and the optimiser are what keeps them together), and one traced step shows where
     # each bucket's exchange sat relative to the backward
     selftest = None
     if pg is not None and (args.dp_selftest or world > 1):
-        flat = net.flat_params()[:net.n_active]
-        mx, mn = flat.clone(), flat.clone()
-        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(mn, op=torch.distributed.ReduceOp.MIN)
-        same = bool(torch.equal(mx, mn))
+        same = _replicas_equal(net)
         eng.trace_buckets = True
         eng.step(img, jt)
         tl = eng.bucket_timeline()
@@ -523,12 +572,38 @@ def main():
         b256 = {"workload": "resnet_18-deconv train step, batch 256/GPU = BASELINE configs[3] per-GPU shape", "value": round(world * 256 * k2 / el2, 2), "unit": "images/s",
                 "n_gpus": world, "steps": k2, "warmup": 3, "ms_per_step": round(1e3 * el2 / k2, 3), "plan_gb": round(eng2.plan.bytes / 1e9, 1),
                 "step_mfma_frac": round(flop_mult * (tot_fl / max(nsteps_timed, 1)) * (256 / args.batch) / (el2 / k2) / 1e12 / peak_tf, 4)}
+        if pg is not None:          # north_star's scaling target is stated at this shape: the replicas must still agree bit for bit after its steps
+            b256["dp_selftest"] = {"replicas_bitwise_equal_after_steps": _replicas_equal(net), "steps_checked": k2 + 3}
         del eng2
         eng = None
         torch.cuda.empty_cache()
+    # N > 1: the same K steps with the gradient buckets exchanged by the library's own RCCL communicator (awr_dp_*: ncclAllReduce issued from
+    # inside the native backward replay, no Python callback per bucket) -- the A/B of the two transports in ONE run of the 8-GPU node
+    native = None
+    if pg is not None and nprod == 1 and not args.no_native_rccl and not args.deterministic:
+        if backend != "nccl":
+            native = {"skipped": "dist backend %r: the library's communicator is RCCL (one GPU per rank)" % backend}
+        else:
+            try:
+                eng = None
+                torch.cuda.empty_cache()
+                eng3 = TrainEngine(net, args.batch, 128, ks, coord_weight=args.coord_weight, dense_weight=1.0, lr=1e-3, process_group=pg,
+                                   use_graph=False, wgrad_streams=args.wgrad_streams, native_rccl=True)
+                eng3.compile(img, jt)
+                el3 = timed_steps(eng3, img, jt, args.steps, warm)
+                native = {"transport": "library-owned RCCL communicator (awr_dp_*, csrc/awr_dp.hip); the headline value uses torch.distributed work objects",
+                          "value": round(world * args.batch * args.steps / el3, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": warm, "ms_per_step": round(1e3 * el3 / args.steps, 3), "vs_headline": round(elapsed / el3, 4),
+                          "dp_selftest": {"replicas_bitwise_equal_after_steps": _replicas_equal(net), "steps_checked": warm + args.steps}}
+                del eng3
+            except Exception as e:          # (the headline has been measured: report, do not lose the line)
+                native = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            torch.cuda.empty_cache()
     if rank == 0:
         if b256 is not None:
             out["b256"] = b256
+        if native is not None:
+            out["native_rccl"] = native
         if world == 1 and not args.no_extras:
             # north_star's forward target (>= 40 % MFMA utilisation on the ResNet18-deconv forward) and BASELINE config 3, each ~1 s,
             # outside the timed train region
@@ -543,6 +618,20 @@ def main():
                                                      "hourglass_1 NYU-shape 128x128 J=14 train step, batch 64")
                 out["config5"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,
                                                "hourglass_2 256x256 J=21 train step, batch 128/GPU = BASELINE configs[4] per-GPU shape")
+        if world == 1 and nprod == 1 and not args.no_accurate_mode and not args.deterministic:
+            # the parity mode (blocked accumulation: awr_conv_args.accum = 1, what Trainer.test scores with and TrainEngine(accum="blocked") trains
+            # with): the headline's step at the same batch, the scoring pass at batch 128, and the joint error against the oracle in that mode
+            eng = None
+            torch.cuda.empty_cache()
+            am = {"accum": "blocked (a K extent restarts its rounding chain every 128 terms; DESIGN.md section 5)",
+                  "train": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
+                                         "%s train step, batch %d, TrainEngine(accum='blocked')" % (args.net, args.batch), accum="blocked"),
+                  "infer_b128": measure_inference(awr_amd, O, args.net, 128, dev, rank, 20, 5, False, peak_tf, flop_mult, parity=True)}
+            am["train"]["vs_headline"] = round(am["train"]["value"] / out["value"], 4)
+            if not args.no_parity:
+                mean_a, max_a = parity_mm(args.net, ks, dev, parity=True)
+                am["joint_err_mm_vs_oracle"] = {"mean": round(mean_a, 6), "max": round(max_a, 6)}
+            out["accurate_mode"] = am
         if world == 1 and nprod == 1 and not args.no_split_mode:
             # the same K steps in the opt-in split-operand mode (not the headline: `value` above is the FP32-MFMA path)
             awr_amd.set_gemm_products(6)

@@ -38,6 +38,10 @@ def test_bench_single_process_line():
         assert v["bytes_algorithmic"] > 0 and v["avg_us"] > 0 and abs(v["frac_of_8TBps"] - v["gbps"] / 8000.0) < 2e-3, (k, v)
     assert "adam_step" in d["roofline_hbm"] and ("head_loss_step_nhwc" in d["roofline_hbm"] or "dense_loss" in d["roofline_hbm"])
     assert d["b256"]["n_gpus"] == 1 and abs(d["b256"]["value"] - 256 * 1e3 / d["b256"]["ms_per_step"]) < 1e-2 * d["b256"]["value"]
+    # round 5: the parity mode (blocked accumulation) in the driver-run line -- the headline's step, the scoring pass, the joint error in that mode
+    am = d["accurate_mode"]
+    assert am["train"]["value"] > 0 and 0.5 < am["train"]["vs_headline"] < 1.2 and am["infer_b128"]["value"] > 0
+    assert am["joint_err_mm_vs_oracle"]["mean"] < 1e-3
 
 
 def test_bench_under_torchrun_with_forced_dp_path():
@@ -48,6 +52,9 @@ def test_bench_under_torchrun_with_forced_dp_path():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp1" and d["value"] > 0
+    # a 1-rank RCCL group runs the transport A/B for real: the library's own communicator exchanges the buckets, replicas (one) agree
+    nr = d["native_rccl"]
+    assert "error" not in nr and nr["value"] > 0 and nr["dp_selftest"]["replicas_bitwise_equal_after_steps"] is True, nr
 
 
 @pytest.mark.timeout(1200)
@@ -86,9 +93,17 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     env = dict(os.environ, AWR_DIST_BACKEND="gloo", AWR_FORCE_DEVICE="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-b256", "--dp-selftest"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--dp-selftest"]
     out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=1100, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
     _check_two_rank_line(d)
     assert d["config"]["launcher"].startswith("bench.py")
+    # round 5, what the first 8-GPU run has to answer in one go: (i) config 4's per-GPU shape (256 / GPU) with the replicas checked after ITS
+    # steps, (ii) the transport A/B (library-owned RCCL communicator; over gloo the record says why it was skipped), (iii) every rank pinned
+    # to CPUs (its GPU's NUMA node, or an equal share)
+    b = d["b256"]
+    assert b["n_gpus"] == 2 and b["dp_selftest"]["replicas_bitwise_equal_after_steps"] is True
+    assert "native_rccl" in d and ("skipped" in d["native_rccl"] or d["native_rccl"]["value"] > 0)
+    for r in d["ranks_seen"]:
+        assert "cpu_affinity" in r and (r["cpu_affinity"].get("n_cpus", 0) >= 1 or "error" in r["cpu_affinity"]), r

@@ -602,6 +602,9 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
         use_hipgraph = False
     tr = Trainer(Cfg(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
     mpe0 = tr.test(0)
+    # the scoring pass (test.py:67-86) is the one the parity mode was built for: config.parity_infer defaults to True and the
+    # engine Trainer.test built ran a plan whose GEMM launches captured the blocked accumulation
+    assert Cfg().parity_infer is True and tr._last_infer.parity and tr._last_infer.plan.accum == 1
     tr.train()
     work = os.path.join(str(tmp_path), "nyu", "checkpoint_t")
     log = open(os.path.join(work, "resnet_18_dense.log")).read()
@@ -624,6 +627,13 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     assert torch.equal(tr2.net.flat_params(), tr.net.flat_params()) and tr2.engine.step_count == tr.engine.step_count
     assert torch.equal(tr2.engine.m, tr.engine.m) and abs(tr2.engine.lr - 1e-3) < 1e-12       # LR force-reset (train.py:94-96)
     assert abs(tr2.test(1) - tr.test(1)) < 1e-5       # (mm, of ~80: two engines, independently autotuned tiles = different summation orders)
+
+    class Cfg3(Cfg2):      # opting out: the throughput mode (ordered accumulation) for scoring
+        parity_infer = False
+        exp_id = "t3"
+    tr3 = Trainer(Cfg3(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
+    m3 = tr3.test(1)
+    assert not tr3._last_infer.parity and tr3._last_infer.plan.accum == 0 and abs(m3 - tr.test(1)) < 1e-3
 
 
 @pytest.mark.parametrize("net,streams", [("resnet_18", 0), ("resnet_18", 2), ("hourglass_1", 2)])
@@ -765,7 +775,20 @@ def test_native_rccl_communicator_through_the_c_abi(amd, dev):
         if attach:
             plan.set_dp(None)
     assert float((grads[0] - grads[1]).abs().max() / grads[0].abs().max()) < 1e-4
+    # lifetime rule: a communicator destroyed UNDER a plan makes every later backward fail -- not only the first -- until the host
+    # detaches or re-attaches; replicas that silently skipped an exchange would diverge
+    from awr_amd._lib import AwrError
+    plan.set_dp(dp)
     dp.close()
+    for _ in range(2):
+        plan.forward()
+        with pytest.raises(AwrError):
+            plan.backward()
+        torch.cuda.synchronize()
+    plan.set_dp(None)
+    plan.forward()
+    plan.backward()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])

@@ -153,6 +153,13 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, t
             a.tile_m, a.tile_n = tm, tn
             L.call("awr_conv_gemm", C.byref(a), L.stream())
             got += [out.clone(), stats.sum(0).float()]
+            # (a2) the same without the statistics: the reduction-free epilogue (bias, folded BatchNorm, residual, ReLU)
+            out2 = torch.full((B, H, H, prob["N"]), float("nan"), device=dev)
+            a2 = ops.make_conv_args(prob, B, D(ops.nhwc(x)), wp, out2, in_scale=D(s_), in_shift=D(t_), relu_in=True, bias=D(bias),
+                                    out_scale=D(so), out_shift=D(to), res=D(ops.nhwc(res)), relu_out=True, T=spec.T)
+            a2.tile_m, a2.tile_n = tm, tn
+            L.call("awr_conv_gemm", C.byref(a2), L.stream())
+            got.append(out2.clone())
             # (b) strided conv, transposed conv, plain activations (both operands by DMA), ragged M
             for kind, ci, co, k, st, p, hh in (("conv", 128, 160, 3, 2, 1, 20), ("deconv", 64, 96, 4, 2, 1, 10), ("conv", 96, 64, 1, 1, 0, 12)):
                 sp = ops.ConvSpec(kind, ci, co, k, st, p)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# GPU-box sessions of one round, one function per study (replaces the per-session scripts of rounds 3-4; their outputs are in profiles/).
+#   gpurun --timeout N -- 'bash tools/gpu_session.sh <study> [args]'
+# Every study writes under gpurun_out/<study>/ ; summaries worth keeping are copied to profiles/ by hand.
+cd $GRAFT_REPO_ROOT
+STUDY=${1:?study name}; shift
+OUT=gpurun_out/$STUDY; mkdir -p $OUT
+export TMPDIR=/tmp
+QUIET="--no-cpu-baseline --no-parity --no-split-mode --no-extras --no-b256 --no-hourglass-train --no-accurate-mode"
+
+line() {   # line <label> <bench args...> : one bench run, one summary line (images/s, ms, roofline.frac, step_mfma_frac)
+  lab=$1; shift
+  python bench.py $QUIET "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
+print('$lab', d['value'], d['ms_per_step'], r.get('frac'), r.get('step_mfma_frac'))"
+}
+
+case $STUDY in
+epi)      # round 5: accumulator orientation / epilogue form of the LDS-DMA GEMM (AWR_EPI = 0 | 1 | 2)
+  timeout 1500 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward" 2>&1 | tail -3 | tee $OUT/ops.log
+  for e in 0 1 2; do AWR_EPI=$e timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | tee $OUT/fwdset_epi$e.txt; done
+  for e in 0 2; do AWR_EPI=$e timeout 300 python tools/microbench_gemm.py ksweep 2>&1 | grep -v amdgpu.ids | tee $OUT/ksweep_epi$e.txt; done
+  for i in 1 2 3; do for e in 0 1 2; do
+    AWR_EPI=$e line "r18 b64 epi$e" | tee -a $OUT/bench_ab.txt
+    AWR_EPI=$e line "hg1 b64 epi$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_EPI=$e line "hg1 infer b128 epi$e" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
+tests)    # the whole GPU suite
+  timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
+  ;;
+*) echo "unknown study $STUDY"; exit 2;;
+esac
