@@ -1364,6 +1364,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     conv_gemm_dma_body<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, SW>(a);
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-operand mode on LDS-DMA (round 5): BOTH operands arrive pre-cut
+// ------------------------------------------------------------------------------------------
+// conv_gemm_body<NP = 6> cuts every activation row into its three bf16 pieces while staging it -- ~90 VALU instructions per slice that have to hide
+// between bf16 MFMAs a third as long as the FP32 ones, once per (element, tap, column tile).  Here the PRODUCER has cut the tensor once
+// (awr_conv_args.in_split: the image awr_split_act / an epilogue's out_split wrote -- [pixel][Cin / 32][h | m | l][32] bf16, 6 bytes per element, the
+// format of the weights' split image), and both operands go global -> LDS by `buffer_load_dwordx4 ... lds` verbatim: no staging registers, no
+// arithmetic in the K loop but fragment reads and matrix instructions.
+//   * Stage = 16 k: per row three planes x two 16-byte chunks (k 0-7, k 8-15) = 96 bytes; two stages in LDS (128x128 tile: 2 x 24 KB).
+//   * LDS image: blocks of 16 rows, chunk-column-major inside a block -- slot(r, c) = (r / 16) * 96 + c * 16 + r % 16 (16-byte slots).  A
+//     ds_read_b128 lane group ({0-3, 12-15, 20-27} etc., MI355X_MICROARCH.md LDS) reads one chunk column c of sixteen rows that are distinct mod 16
+//     in two adjacent blocks (96 = 0 mod 16): sixteen distinct slots, conflict-free, without a swizzle -- 96-byte rows have no power-of-two XOR.
+//   * The DMA destination is lane-linear (M0 + 16 lane): wave instruction n fills slots [64 n, 64 n + 64) = four chunk columns of sixteen rows,
+//     i.e. sixteen 64-byte runs per instruction -- the access shape of the FP32 kernel's 16-float stages.  Out-of-range sources (padding taps,
+//     ragged rows) land zeros, and a zero has zero pieces.
+//   * Instructions are dealt round-robin to the four waves; which rows a lane serves is fixed for the launch (per-tap: one bounds test and one
+//     base offset per served row).
+template <int TM, int TN, int EM>
+__device__ __forceinline__ void conv_gemm_sdma_body(const awr_conv_args& a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int CPR = 6;                              // 16-byte chunks per row and stage
+    constexpr int NINSTR = (BM + BN) * CPR / 64;        // wave-level DMA instructions per stage
+    constexpr int NA = BM * CPR / 64;                   // ... of which the first NA fill the activation rows
+    constexpr int NI = (NINSTR + 3) / 4;                // per wave
+    constexpr int STAGE = (BM + BN) * CPR * 16;
+    constexpr int EPI = 4 * 32 * LDK * 4;               // the epilogue's four 32x36 transpose tiles
+    constexpr int BUFS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) char smem_raw[BUFS];
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+
+    const awr_phase& ph = a.ph[blockIdx.y];
+    const int M = a.B * a.Hq * a.Wq;
+    const int tilesN = (a.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int cslices = a.Cin / BK;                     // 192-byte slices per (row, tap)
+
+    // the rows / chunks this lane serves: instruction n = 4 i + wave fills slots [64 n, 64 n + 64)
+    int s_iy[NI], s_ix[NI];
+    unsigned s_img[NI], s_c[NI], s_off[NI];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = 4 * i + wave;
+        const int slot = 64 * n + lane, blk = slot / 96, w = slot - blk * 96, c = w >> 4, r = blk * 16 + (w & 15);
+        s_c[i] = (unsigned)((c >> 1) * 64 + (c & 1) * 16);      // byte offset of chunk c in the slice's first 16-k half
+        s_iy[i] = -(1 << 20); s_ix[i] = 0; s_img[i] = 0; s_off[i] = OOB;
+        if (n < NA) {                                            // an activation row: gathered, tap-dependent
+            const int m = tile_m * BM + r;
+            if (m < M) {
+                int qx, qy, b;
+                decode_row(a, m, qx, qy, b);
+                s_iy[i] = qy * a.si; s_ix[i] = qx * a.si; s_img[i] = (unsigned)b * a.Hin * a.Win;
+            }
+        } else if (n < NINSTR) {                                 // a weight row: [n][tap][slice][192 B]
+            s_off[i] = (unsigned)(tile_n * BN + (r - BM)) * (unsigned)a.T * (unsigned)cslices * 192u + s_c[i];
+        }
+    }
+    const i32x4 rw_in = make_rsrc_words(a.in_split, (unsigned)a.B * a.Hin * a.Win * a.Cin * 6u), rw_w = make_rsrc_words(a.w_split, OOB);
+    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
+    unsigned wtap = 0;
+    auto set_tap = [&](int tap) {
+        const int tp = ph.tap[tap];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (4 * i + wave < NA) {       // (wave-uniform)
+                const int iy = s_iy[i] + dy, ix = s_ix[i] + dx;
+                const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                s_off[i] = (s_img[i] + (unsigned)(iy * a.Win + ix)) * (unsigned)cslices * 192u + s_c[i];
+                okmask |= ok ? (1u << i) : 0u;
+            }
+        }
+        wtap = (unsigned)wt * (unsigned)cslices * 192u;
+    };
+    // request the stage (current tap, slice sl, 16-k half t) into stage buffer `buf`
+    auto issue = [&](int sl, int t, int buf, bool live = true) {
+        const unsigned kb = (unsigned)sl * 192u + (unsigned)t * 32u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = 4 * i + wave;
+            if (n < NINSTR) {              // (wave-uniform)
+                const unsigned dst = lds0 + (unsigned)(buf * STAGE) + (unsigned)i * 4096u;
+                if (n < NA) dma16(rw_in, dst, (live && (okmask & (1u << i))) ? s_off[i] + kb : OOB);
+                else dma16(rw_w, dst, live ? s_off[i] + wtap + kb : OOB);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: lane (l31, half) wants chunk column 2 p + half of its row for plane p
+    const int ra = wm * 32 * TM + l31, rb = BM + wn * 32 * TN + l31;
+    const char* const a_frag = smem_raw + (((ra >> 4) * 96 + (ra & 15)) << 4) + half * 256;
+    const char* const b_frag = smem_raw + (((rb >> 4) * 96 + (rb & 15)) << 4) + half * 256;
+    auto compute = [&](int buf) {
+        bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = ld_frag(a_frag + buf * STAGE + i * 3072 + p * 512);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = ld_frag(b_frag + buf * STAGE + j * 3072 + p * 512);
+        mfma_split16<TM, TN, 6>(fa, fb, acc);
+    };
+    int tap = 0, sl = 0, t = 0;
+    auto advance = [&]() {
+        t ^= 1;
+        if (t == 0 && ++sl == cslices) { sl = 0; if (++tap < ph.ntaps) set_tap(tap); }
+    };
+    auto stage_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait();
+        __syncthreads();
+    };
+    const int nstages = ph.ntaps * cslices * 2;          // (even)
+    set_tap(0);
+    issue(0, 0, 0);
+    stage_done();
+    // whole pairs of stages, nothing conditional inside the trip (the stage requested beyond the K extent comes from nowhere: zeros that
+    // nobody multiplies) -- the loop shape that took 30-60 registers off the weight-gradient kernels (profiles/r04_loop_exits.txt)
+    for (int ks = 0; ks < nstages; ks += 2) {
+        advance(); issue(sl, t, 1); compute(0); stage_done();
+        advance(); issue(sl, t, 0, ks + 2 < nstages); compute(1); stage_done();
+    }
+    gemm_epilogue<TM, TN, false, EM>(a, ph, acc, smem, M, tile_m, tile_n);
+}
+template <int TM, int TN, int EM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_sdma_kernel(const awr_conv_args a) {
+    conv_gemm_sdma_body<TM, TN, EM>(a);
+}
+
 // amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
 template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false, bool EPRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
@@ -2454,6 +2598,12 @@ static void launch_wgrad_dma(const awr_wgrad_args* a, int TM, int TN, int kp, bo
 // (plain functions, not lambdas, for the initialisers: hipcc 7.2 initialised a second namespace-scope `static int g = []() { ... }();` of one
 // translation unit with the FIRST lambda's body -- DESIGN.md 5, side finding of round 3)
 static int g_force_tm = 0, g_force_tn = 0, g_products = env_int("AWR_GEMM_PRODUCTS", 1);
+// Split-operand mode, weight gradients.  AWR_WGRAD_SPLIT=0 (round-5 study, profiles/r05_split_mode_studies.txt) runs them on the FP32-MFMA kernels instead
+// (kernel row, LDS-DMA per tap: exact fp32 products as well, and FASTER in isolation than the split-operand kernel whose staged rows are transposed and
+// cut in registers) -- and the step gets SLOWER: 10.77-10.91 -> 11.39-11.46 ms (a weight gradient runs beside the bf16 data-gradient chain; an FP32-MFMA
+// launch holds the matrix pipe three times as long per product).  Default: the split-operand weight gradient.
+static int g_wgrad_split = env_int("AWR_WGRAD_SPLIT", 1);
+static inline int wg_products() { return (g_products == 6 && g_wgrad_split) ? 6 : 1; }
 static int g_staging = env_int("AWR_DMA", 2);
 static int g_accum = env_int("AWR_ACCUM", 0);
 
@@ -2473,6 +2623,8 @@ int awr_set_gemm_products(int n) {
 }
 
 int awr_get_gemm_products(void) { return g_products; }
+
+int awr_get_wgrad_products(void) { return wg_products(); }
 
 int awr_set_gemm_staging(int mode) {
 #ifdef AWR_DMA_STUDY
@@ -2502,13 +2654,15 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream);
 int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a && a->in && a->w && a->out, "conv_gemm: null pointer");
     const int64_t in_img = (int64_t)a->Hin * a->Win * a->Cin, out_img = (int64_t)a->Hout * a->Wout * a->N;
+    const int in_b = a->in_split ? 6 : 4;      // bytes per input element the kernel addresses (pre-cut image: three bf16 pieces)
     int nchunk = 1;
-    while ((in_img * (a->B / nchunk) * 4 >= (1LL << 32) || out_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
+    while ((in_img * (a->B / nchunk) * in_b >= (1LL << 32) || out_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
     if (nchunk == 1) return conv_gemm_one(a, stream);
     for (int c = 0; c < nchunk; ++c) {
         awr_conv_args b = *a;
         b.B = a->B / nchunk;
         b.in = a->in + in_img * b.B * c;
+        if (a->in_split) b.in_split = static_cast<const char*>(a->in_split) + in_img * b.B * c * 6;
         b.out = a->out + out_img * b.B * c;
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
@@ -2620,6 +2774,27 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     const bool aff = a->in_scale != nullptr || a->relu_in;
+    // split-operand mode with a PRE-CUT activation image (in_split): both operands by LDS-DMA (conv_gemm_sdma_body)
+    static const int sdma_on = env_int("AWR_SPLIT_DMA", 1);      // 0: never (the same-box A/B hook back to the in-kernel cut)
+    if (g_products == 6 && a->in_split && sdma_on) {
+        AWR_REQUIRE(!aff && !a->in2 && !a->in_bnb_y && !(a->partial && a->split_k > 1),
+                    "conv_gemm: a pre-cut activation image (in_split) excludes input arithmetic (in_scale / relu_in), a second tensor and split-K");
+        AWR_REQUIRE((int64_t)a->B * a->Hin * a->Win * a->Cin * 6 < (1LL << 32), "conv_gemm: the pre-cut image must stay below 4 GB (32-bit buffer offsets)");
+        const int em = a->bnr_y ? ((a->bnr_act || a->res || a->bnr2_y) ? 4 : 3) : a->stats ? 2 : 1;
+#define AWR_SDMA_EM(tm, tn)                                                                                              \
+        do {                                                                                                             \
+            if (em == 4) hipLaunchKernelGGL((conv_gemm_sdma_kernel<tm, tn, 4>), grid, dim3(256), 0, st, *a);             \
+            else if (em == 3) hipLaunchKernelGGL((conv_gemm_sdma_kernel<tm, tn, 3>), grid, dim3(256), 0, st, *a);        \
+            else if (em == 2) hipLaunchKernelGGL((conv_gemm_sdma_kernel<tm, tn, 2>), grid, dim3(256), 0, st, *a);        \
+            else hipLaunchKernelGGL((conv_gemm_sdma_kernel<tm, tn, 1>), grid, dim3(256), 0, st, *a);                     \
+        } while (0)
+        if (TM == 2 && TN == 2) AWR_SDMA_EM(2, 2);
+        else if (TM == 2 && TN == 1) AWR_SDMA_EM(2, 1);
+        else if (TM == 1 && TN == 2) AWR_SDMA_EM(1, 2);
+        else AWR_SDMA_EM(1, 1);
+#undef AWR_SDMA_EM
+        return check_launch("conv_gemm_sdma_kernel");
+    }
     // short K loops (<= 8 slices) whose epilogue reads exactly one operand tensor: that tensor's rows are requested ahead (EPRE)
     static const bool no_epre = getenv("AWR_NO_EPRE") != nullptr;      // same-box A/B hook
     const bool epre = !no_epre && g_products == 1 && !a->in2 && a->nphase == 1 && a->ph[0].ntaps * (a->Cin / BK) <= 8 &&
@@ -2680,7 +2855,7 @@ struct wgrad_launch {
 static bool wgrad_row_ok(const awr_wgrad_args* a) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
-    bool ok = g_products == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
+    bool ok = wg_products() == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
               a->Hd >= 2 && !a->d_scale && M < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24);
     for (int t = 0; ok && t < 9; ++t) ok = a->dy[t] == t / 3 - 1 && a->dx[t] == t % 3 - 1;
     return ok;
@@ -2698,7 +2873,7 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
     AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
                 "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
     static const int env_algo = []() { const char* e = getenv("AWR_WGRAD_ALGO"); return e ? atoi(e) : 0; }();      // study hook
-    const int ph = g_products == 1 ? wgrad_taps_patch_rows(a) : 0;
+    const int ph = wg_products() == 1 ? wgrad_taps_patch_rows(a) : 0;
     const int algo = a->algo ? a->algo : (env_algo ? env_algo : 1);
     AWR_REQUIRE(a->algo != 2 || ph, "conv_wgrad: algo 2 (wave per tap) does not serve this geometry / product mode");
     w->taps_ph = 0;
@@ -2774,7 +2949,7 @@ static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
 int awr_conv_wgrad_algo_ok(const awr_wgrad_args* a, int algo) {
     if (!a) return 0;
     if (algo == 0 || algo == 1) return 1;
-    if (algo == 2) return g_products == 1 && wgrad_taps_patch_rows(a) > 0;
+    if (algo == 2) return wg_products() == 1 && wgrad_taps_patch_rows(a) > 0;
     if (algo == 3) return wgrad_row_ok(a) ? 1 : 0;
     return 0;
 }
@@ -2838,7 +3013,7 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     // Hourglass step (nearly all of whose weight gradients have one) nothing either.
     static const int wdma = env_int("AWR_WGRAD_DMA", -1);
     static const int wkp = env_int("AWR_WGRAD_KP", 0);
-    if (wdma && g_staging && g_products == 1 && hshift_f32 >= 64) {
+    if (wdma && g_staging && wg_products() == 1 && hshift_f32 >= 64) {
         const bool dreg = a->d_scale != nullptr || a->d_colsum != nullptr, greg = a->g_scale != nullptr;
         if (wdma > 0 || (!dreg && !greg)) {
             const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);
@@ -2848,7 +3023,7 @@ static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
     }
 #define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
     do {                                                                                                                                  \
-        if (g_products == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
+        if (wg_products() == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
         else if (hshift_f32 >= 64) hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn, true>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32); \
         else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32);                            \
     } while (0)

@@ -599,6 +599,49 @@ int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_
     return check_launch("pack_weight_kernel");
 }
 
+// eight consecutive channels per thread: two 16-byte reads, optional affine + ReLU, the exact three-way cut, three 16-byte writes (one per plane)
+__global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                        int64_t n8, int C, char* __restrict__ split) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int64_t e = i * 8;
+    float v[8];
+    *reinterpret_cast<float4*>(v) = ld4(x + e);
+    *reinterpret_cast<float4*>(v + 4) = ld4(x + e + 4);
+    if (scale) {
+        const int c = (int)(e % C);
+        float sc[8], sh[8];
+        *reinterpret_cast<float4*>(sc) = ld4(scale + c); *reinterpret_cast<float4*>(sc + 4) = ld4(scale + c + 4);
+        *reinterpret_cast<float4*>(sh) = ld4(shift + c); *reinterpret_cast<float4*>(sh + 4) = ld4(shift + c + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+    }
+    if (relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = __float_as_uint(v[k]) & 0xFFFF0000u;
+        const float r1 = v[k] - __uint_as_float(h[k]);
+        m[k] = __float_as_uint(r1) & 0xFFFF0000u;
+        l[k] = __float_as_uint(r1 - __uint_as_float(m[k]));
+    }
+    auto pk = [](unsigned lo, unsigned hi) { return (lo >> 16) | (hi & 0xFFFF0000u); };
+    char* dst = split + (e >> 5) * 192 + (e & 31) * 2;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
+    *reinterpret_cast<uint4*>(dst + 64) = make_uint4(pk(m[0], m[1]), pk(m[2], m[3]), pk(m[4], m[5]), pk(m[6], m[7]));
+    *reinterpret_cast<uint4*>(dst + 128) = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), pk(l[6], l[7]));
+}
+
+int awr_split_act(const float* x, const float* scale, const float* shift, int relu, int64_t npix, int C, void* split, void* stream) {
+    AWR_REQUIRE(x && split && npix > 0 && C > 0 && C % 32 == 0 && (scale == nullptr) == (shift == nullptr), "split_act: C must be a positive multiple of 32");
+    const int64_t n8 = npix * C / 8;
+    hipLaunchKernelGGL(split_act_kernel, dim3(nblk(n8)), dim3(256), 0, as_stream(stream), x, scale, shift, relu, n8, C, static_cast<char*>(split));
+    return check_launch("split_act_kernel");
+}
+
 int awr_split_weight(const float* packed, void* split, int64_t n, void* stream) {
     AWR_REQUIRE(packed && split && n > 0 && n % 32 == 0, "split_weight: n must be a positive multiple of 32");
     hipLaunchKernelGGL(split_weight_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), packed, split, n);

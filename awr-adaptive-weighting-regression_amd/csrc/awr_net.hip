@@ -1107,7 +1107,7 @@ struct Builder {
         // 128 -> 128 3x3 layers on >= 64x64 maps (the Hourglass residuals at full resolution): the one-wave-per-tap-row kernel stages
         // D and the halo'd G patch once for all nine taps (measured: 124 vs 114 TF in isolation, Hourglass-1 step 26.44 -> 25.79 ms; writing relu(bn2(.)) out for them on top: 25.87); on
         // every other shape the workgroup-per-tap kernel is equal or faster (profiles/r02_microbench_wgrad_algos.txt)
-        if (!P.det && awr_get_gemm_products() == 1 && spec.k == 3 && spec.stride == 1 && !spec.deconv && spec.cin == 128 && spec.cout == 128 &&
+        if (!P.det && awr_get_wgrad_products() == 1 && spec.k == 3 && spec.stride == 1 && !spec.deconv && spec.cin == 128 && spec.cout == 128 &&
             H * W >= 4096 && (int64_t)B * H * W >= (1 << 17) && x->lazy)      // (a plain input takes the kernel-row kernel: awr_conv_wgrad's default)
             wa->algo = 2;
         P.gemms.push_back({nullptr, wa, wname});
@@ -2095,7 +2095,7 @@ static int autotune(awr_plan& P, int reps, void* stream) {
             cands = {{1, 1, 2048}, {1, 1, 3072}, {1, 1, 4096}};
             if (g.wa->Cd > 64) { cands.push_back({2, 1, 1536}); cands.push_back({2, 1, 2048}); }
             if (g.wa->Cg > 64) cands.push_back({1, 2, 2048});
-            if (g.wa->Cd > 64 && g.wa->Cg > 64 && awr_get_gemm_products() != 1) { cands.push_back({2, 2, 1024}); cands.push_back({2, 2, 2048}); }
+            if (g.wa->Cd > 64 && g.wa->Cg > 64 && awr_get_wgrad_products() != 1) { cands.push_back({2, 2, 1024}); cands.push_back({2, 2, 2048}); }
             // one workgroup per kernel row (3x3 stride 1): its own split-K depths; the per-tap candidates above then run as algo 1
             if ((g.wa->algo == 0 || g.wa->algo == 3) && awr_conv_wgrad_algo_ok(g.wa, 3)) {
                 for (auto& c : cands) c.algo = 1;

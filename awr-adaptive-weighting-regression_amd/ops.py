@@ -107,9 +107,13 @@ class ConvSpec:
 
 
 def make_conv_args(prob, B, x, w, out, in_scale=None, in_shift=None, bias=None, out_scale=None, out_shift=None, res=None,
-                   stats=None, relu_in=False, relu_out=False, T=None, partial=None, split_k=0):
-    """partial: (split_max, *out.shape) scratch -> split-K (awr_hip.h: awr_conv_args.partial); split_k = 0 lets the library pick the depth."""
+                   stats=None, relu_in=False, relu_out=False, T=None, partial=None, split_k=0, in_split=None):
+    """partial: (split_max, *out.shape) scratch -> split-K (awr_hip.h: awr_conv_args.partial); split_k = 0 lets the library pick the depth.
+    in_split: the pre-cut image of x (split_act) for the split-operand mode's LDS-DMA kernel."""
     a = L.ConvArgs()
+    if in_split is not None:
+        a.in_split = L.ptr(in_split)
+        a._keep_split = in_split
     if partial is not None:
         a.partial, a.split_max, a.split_k = L.ptr(partial), partial.shape[0], split_k
         a._keep = partial
@@ -156,6 +160,15 @@ def alloc_packed(rows, T, ld, device):
     p = torch.zeros(rows, T, ld, device=device, dtype=torch.float32)
     p.split = torch.zeros(rows * T * ld * 3, device=device, dtype=torch.int16)
     return p
+
+
+def split_act(x, scale=None, shift=None, relu=False):
+    """Split image of an NHWC activation tensor (include/awr_hip.h: awr_split_act): [relu](x * scale + shift) cut exactly into three bf16
+    pieces, 6 bytes per element, the layout awr_conv_args.in_split reads."""
+    C_ = x.shape[-1]
+    out = torch.empty(x.numel() * 3, device=x.device, dtype=torch.int16)
+    L.call("awr_split_act", L.ptr(x), L.ptr(scale), L.ptr(shift), int(bool(relu)), x.numel() // C_, C_, L.ptr(out), L.stream())
+    return out
 
 
 def split_packed(p):

@@ -584,6 +584,22 @@ def main():
         if backend != "nccl":
             native = {"skipped": "dist backend %r: the library's communicator is RCCL (one GPU per rank)" % backend}
         else:
+            # This block runs code no multi-rank RCCL job has executed before (ncclCommInitRank from the library, collectives issued from the
+            # native replay): the measured headline must not be lost to a hang in it.  A watchdog emits the line without the A/B and ends the
+            # process when the block overruns its allowance (every rank arms one; rank 0 writes).
+            import threading
+
+            def _overrun():
+                if rank == 0:
+                    out["native_rccl"] = {"error": "did not finish within %d s: abandoned by the watchdog, headline unaffected" % native_allowance}
+                    if b256 is not None:
+                        out["b256"] = b256
+                    emit(json.dumps(out))
+                os._exit(0)
+            native_allowance = int(os.environ.get("AWR_NATIVE_RCCL_ALLOWANCE_S", "180"))
+            dog = threading.Timer(native_allowance, _overrun)
+            dog.daemon = True
+            dog.start()
             try:
                 eng = None
                 torch.cuda.empty_cache()
@@ -598,6 +614,7 @@ def main():
                 del eng3
             except Exception as e:          # (the headline has been measured: report, do not lose the line)
                 native = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            dog.cancel()
             torch.cuda.empty_cache()
     if rank == 0:
         if b256 is not None:

@@ -240,6 +240,9 @@ typedef struct awr_conv_args {
     int accum;              /* 0 = one k-ordered accumulation chain over the whole K extent (v_mfma_f32_32x32x2_f32 after v_mfma ...); 1 = BLOCKED: every */
                             /* 128 k the running sum is folded into a second accumulator set and restarted (chains of 128 + K / 128 terms, the */
                             /* rounding behaviour of oneDNN's blocked kernels that the reference's CPU numbers come from).  LDS-DMA staging, K > 256 */
+    const void* in_split;   /* optional (split-operand mode): the PRE-CUT image of `in` -- [pixel][Cin / 32][h | m | l][32] bf16, 6 bytes per element, written */
+                            /* by awr_split_act (or a producer's epilogue): both operands then travel global -> LDS by DMA and the K loop holds no cutting */
+                            /* arithmetic.  Excludes in_scale / relu_in (the producer applies them before it cuts), in2, in_bnb_y, split-K */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
@@ -257,6 +260,13 @@ int awr_debug_force_tile(int tm, int tn);
  * Replaces nothing in the reference (torch's conv precision is whatever cuDNN / oneDNN pick; cuDNN defaults to TF32). */
 int awr_set_gemm_products(int n);
 int awr_get_gemm_products(void);
+/* split image of an activation tensor x (npix, C), C % 32 == 0: every element [relu](x * scale[c] + shift[c]) (scale / shift optional) cut EXACTLY
+ * into three bf16 pieces, element idx -> shorts (idx / 32) * 96 + idx % 32 + {0, 32, 64} (the format of awr_split_weight).  What awr_conv_args.in_split
+ * reads: a BatchNorm + ReLU output that the FP32 mode never materialises is written ONCE here instead of being cut per (tap, column tile) in the GEMM. */
+int awr_split_act(const float* x, const float* scale, const float* shift, int relu, int64_t npix, int C, void* split, void* stream);
+/* the product mode awr_conv_wgrad runs in: awr_get_gemm_products(), unless $AWR_WGRAD_SPLIT=0 sends the split mode's weight gradients to the FP32-MFMA
+ * kernels (a measured-slower study arm: profiles/r05_split_mode_studies.txt) */
+int awr_get_wgrad_products(void);
 /* How the FP32-MFMA forward / data-gradient GEMM stages its operands (process-wide; default 2, or $AWR_DMA):
  *   2 = LDS-DMA: `buffer_load_dwordx4 ... lds` straight into swizzled, unpadded LDS rows, 16-float stages, double-buffered
  *       (weights always; activations whenever no fused input affine / ReLU has to touch them on the way in);

@@ -120,6 +120,93 @@ def test_conv_every_tile_shape(ops, L, dev, products, staging, tm, tn, kind, cin
         L.call("awr_set_gemm_staging", 2)
 
 
+def test_split_act_image_is_the_exact_three_way_cut(ops, L, dev):
+    """awr_split_act: every element of [relu](x * scale + shift) as three bf16 pieces whose sum is the fp32 value EXACTLY, in the layout of the
+    weights' split image (element idx -> shorts (idx / 32) * 96 + idx % 32 + {0, 32, 64})."""
+    x = rnd(3, 5, 7, 96, seed=5).to(dev) * 3.0
+    sc, sh = (rnd(96, seed=6) + 1.5).to(dev), rnd(96, seed=7).to(dev)
+    for affine, relu in ((False, False), (True, True), (True, False)):
+        img = ops.split_act(x, sc if affine else None, sh if affine else None, relu)
+        ref = x * sc + sh if affine else x
+        if relu:
+            ref = torch.relu(ref)
+        pl = img.view(-1, 3, 32)                                             # [slice][plane][32]
+        pieces = (pl.to(torch.int32) << 16).view(torch.float32)              # bf16 bits -> fp32
+        h, m, l = pieces[:, 0].reshape(-1), pieces[:, 1].reshape(-1), pieces[:, 2].reshape(-1)
+        tot = (h.double() + m.double() + l.double()).float()                 # (three 8-bit pieces: the double sum is exact)
+        assert torch.equal(tot.double(), h.double() + m.double() + l.double())
+        if affine:      # the kernel's multiply-add is fused (one rounding): compared with the float64 expression, within one ulp of the larger term
+            r64 = x.double() * sc.double() + sh.double()
+            r64 = torch.relu(r64) if relu else r64
+            bound = ((x.double() * sc.double()).abs() + sh.double().abs()).reshape(-1) * 2.0 ** -23
+            assert bool(((tot.double() - r64.reshape(-1)).abs() <= bound).all()), (affine, relu)
+        else:
+            assert torch.equal(tot, ref.reshape(-1)), (affine, relu)
+        assert torch.equal(h, (tot.view(torch.int32) & -65536).view(torch.float32))     # h = the top 16 bits of the value (truncation)
+        r1 = tot - h
+        assert torch.equal(m, (r1.view(torch.int32) & -65536).view(torch.float32)) and torch.equal(l, r1 - m)
+
+
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 3, 18), ("conv", 128, 160, 3, 2, 1, 2, 20),
+                                                              ("deconv", 64, 96, 4, 2, 1, 3, 10), ("conv", 96, 64, 1, 1, 0, 2, 12)])
+def test_split_mode_with_precut_activations_is_bit_identical(ops, L, dev, tm, tn, kind, cin, cout, k, stride, pad, B, H):
+    """Split-operand mode, both operands by LDS-DMA (awr_conv_args.in_split: the activation image cut ONCE by awr_split_act) against the
+    kernel that cuts every staged row itself: same pieces, same six products per 16 k, same order -> the SAME BITS, on ragged M / N, padding
+    taps (out-of-range DMA sources land zero pieces), strided and transposed phases; with bias / residual / ReLU / statistics epilogues.
+    And a BatchNorm + ReLU input: cut after the affine by the producer vs applied by the consumer's loader."""
+    import ctypes as C
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    x = rnd(B, cin, H, H, seed=1)
+    w = rnd(*((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)), seed=2, scale=0.05)
+    prob = spec.fwd_problem(H, H)
+    xin = ops.nhwc(x).to(dev)
+    if prob["Cin"] != cin:
+        xin = torch.nn.functional.pad(xin, (0, prob["Cin"] - cin))
+    xin = xin.contiguous()
+    L.call("awr_set_gemm_products", 6)
+    try:
+        wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+        ops.split_packed(wp)
+        bias = rnd(prob["N"], seed=3).to(dev)
+        res = rnd(B, prob["Hout"], prob["Wout"], prob["N"], seed=4).to(dev)
+        sc, sh = (rnd(prob["Cin"], seed=5) + 1.5).to(dev), rnd(prob["Cin"], seed=6).to(dev)
+        for form in ("plain", "epilogue", "stats", "bn_input"):
+            outs = []
+            for pre in (False, True):
+                out = torch.full((B, prob["Hout"], prob["Wout"], prob["N"]), float("nan"), device=dev)
+                kw = {}
+                if form in ("epilogue", "stats"):
+                    kw = dict(bias=bias, res=res, relu_out=True)
+                st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64) if form == "stats" else None
+                if form == "bn_input":
+                    if pre:
+                        kw["in_split"] = ops.split_act(xin, sc, sh, True)
+                    else:
+                        kw.update(in_scale=sc, in_shift=sh, relu_in=True)
+                elif pre:
+                    kw["in_split"] = ops.split_act(xin)
+                a = ops.make_conv_args(prob, B, xin, wp, out, stats=st, T=spec.T, **kw)
+                a.tile_m, a.tile_n = tm, tn
+                L.call("awr_conv_gemm", C.byref(a), L.stream())
+                torch.cuda.synchronize()
+                outs.append((out.clone(), None if st is None else st.sum(0).float()))
+            (o0, s0), (o1, s1) = outs
+            assert not torch.isnan(o1).any(), form
+            assert torch.equal(o0, o1), (form, float((o0 - o1).abs().max()))
+            if s0 is not None:
+                assert rel_err(s1.cpu(), s0.cpu()) < 1e-6
+        # and against float64
+        ref = TF.conv2d(x.double(), w.double(), None, stride, pad) if kind == "conv" else TF.conv_transpose2d(x.double(), w.double(), None, stride, pad)
+        out = torch.empty(B, prob["Hout"], prob["Wout"], prob["N"], device=dev)
+        a = ops.make_conv_args(prob, B, xin, wp, out, T=spec.T, in_split=ops.split_act(xin))
+        a.tile_m, a.tile_n = tm, tn
+        L.call("awr_conv_gemm", C.byref(a), L.stream())
+        assert rel_err(ops.nchw(out)[:, :cout].cpu(), ref) < 2e-6
+    finally:
+        L.call("awr_set_gemm_products", 1)
+
+
 @pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2), (2, 1), (2, 2)])
 def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, tn):
     """The LDS-DMA kernel (buffer_load ... lds into swizzled unpadded rows, 16-float stages) walks K in the same order as the register-staged

@@ -27,6 +27,31 @@ epi)      # round 5: accumulator orientation / epilogue form of the LDS-DMA GEMM
     AWR_EPI=$e line "hg1 infer b128 epi$e" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
   done; done
   ;;
+sdma)     # round 5: split-operand mode on LDS-DMA with a pre-cut activation image -- parity, isolated launches
+  timeout 1500 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -k "split" 2>&1 | tail -25 | tee $OUT/ops.log
+  timeout 900 python tools/microbench_gemm.py splitset 2>&1 | grep -v amdgpu.ids | tee $OUT/splitset.txt
+  for i in 1 2; do for w in 0 1; do
+    AWR_WGRAD_SPLIT=$w line "r18 b64 split-mode wgrad_split=$w" --gemm-products 6 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
+elem)     # HBM-bound BatchNorm kernels against a plain copy at the sizes the plans run them at
+  for sz in "262144 128" "262144 256" "262144 64" "65536 128" "65536 256" "1048576 64"; do
+    echo "== npix C = $sz"; python tools/microbench_elem.py $sz 2>&1 | grep -v amdgpu.ids
+  done | tee $OUT/elem.txt
+  ;;
+queues)   # HIP hardware queues: the runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) queues
+  for i in 1 2; do for q in 4 8; do
+    GPU_MAX_HW_QUEUES=$q line "r18 b64 queues=$q" | tee -a $OUT/bench_ab.txt
+    GPU_MAX_HW_QUEUES=$q line "hg1 b64 queues=$q" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  GPU_MAX_HW_QUEUES=8 python -c "
+import sys; sys.path.insert(0,'.')
+import torch, awr_amd
+from awr_amd import _lib as L
+import ctypes as C
+torch.zeros(1).cuda()
+n,k=C.c_int(),C.c_int(); L.call('awr_stream_pool_info', C.byref(n), C.byref(k)); print('GPU_MAX_HW_QUEUES=8: pool', n.value, 'independent', k.value)" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/bench_ab.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;

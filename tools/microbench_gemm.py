@@ -30,7 +30,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def run_fwd(spec, B, H, tile=None, stats=False, affine=False):
+def run_fwd(spec, B, H, tile=None, stats=False, affine=False, presplit=False):
     dev = torch.device("cuda:0")
     x = torch.randn(B, H, H, spec.cin_pad, device=dev)
     wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == "conv" else (spec.cin, spec.cout, spec.k, spec.k)
@@ -42,6 +42,8 @@ def run_fwd(spec, B, H, tile=None, stats=False, affine=False):
     aff = {}
     if affine:      # the un-materialised BatchNorm + ReLU input
         aff = dict(in_scale=torch.rand(spec.cin_pad, device=dev) + 0.5, in_shift=torch.randn(spec.cin_pad, device=dev) * 0.1, relu_in=True)
+    if presplit:      # split-operand mode, activation image cut once by the producer (LDS-DMA kernel)
+        aff = dict(in_split=ops.split_act(x, aff.get("in_scale"), aff.get("in_shift"), aff.get("relu_in", False)))
     a = ops.make_conv_args(prob, B, x, wp, out, stats=st, T=spec.T, **aff)
     if tile:
         L.call("awr_debug_force_tile", *tile)
@@ -50,6 +52,18 @@ def run_fwd(spec, B, H, tile=None, stats=False, affine=False):
     L.call("awr_debug_force_tile", 0, 0)
     macs = B * prob["Hout"] * prob["Wout"] * spec.cout * spec.cin * (spec.T if spec.kind == "conv" else spec.T / 4)
     return t, 2 * macs / t / 1e12
+
+
+def run_split_act(C_, B, H, affine=False):
+    """the producer-side cut on its own: one pass, 4 B read + 6 B written per element"""
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, H, H, C_, device=dev)
+    out = torch.empty(x.numel() * 3, device=dev, dtype=torch.int16)
+    sc = torch.rand(C_, device=dev) + 0.5 if affine else None
+    sh = torch.randn(C_, device=dev) if affine else None
+    s = L.stream()
+    t = timeit(lambda: L.call("awr_split_act", L.ptr(x), L.ptr(sc), L.ptr(sh), int(affine), x.numel() // C_, C_, L.ptr(out), s))
+    return t, x.numel() * 10 / t / 1e9
 
 
 def run_wgrad(spec, B, H, tile=None, algo=0, blocks=0, affine=False):
@@ -103,7 +117,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset", "rowset"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset", "rowset", "splitset"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -117,6 +131,31 @@ def main():
             (n0, t0), (n1, t1) = pts[-2], pts[-1]
             b = (t1 - t0) / (n1 - n0)
             print("   -> per-slice %.2f us, fixed %.1f us  (= %.1f slices)" % (b * 1e6, (t1 - b * n1) * 1e6, (t1 - b * n1) / b))
+    elif args.mode == "splitset":    # split-operand mode: the in-kernel cut (rounds 1-4) against the LDS-DMA kernel on a pre-cut activation image
+        B = args.batch
+        L.call("awr_set_gemm_products", 6)
+        shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
+                  ("layer3 3x3 256->256 @16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16), ("layer4 3x3 512->512 @8", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8),
+                  ("deconv 512->256 @8", ops.ConvSpec("deconv", 512, 256, 4, 2, 1), 8), ("deconv 256->256 @16", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 16),
+                  ("deconv 256->256 @32", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32), ("head 1x1 256->64 @64", ops.ConvSpec("conv", 256, 64, 1, 1, 0), 64),
+                  ("hg 1x1 256->128 @64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 64), ("hg 1x1 128->256 @64", ops.ConvSpec("conv", 128, 256, 1, 1, 0), 64),
+                  ("hg 3x3 128->128 @64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 64)]
+        print("split-operand mode, batch %d: TF-equivalent per tile: in-kernel cut plain|stats|stats+affine  ->  pre-cut image + LDS-DMA plain|stats" % B)
+        for name, spec, H in shapes:
+            res = []
+            for tile in ((1, 1), (2, 1), (1, 2), (2, 2)):
+                if spec.cout <= 64 and tile[1] == 2:
+                    continue
+                res.append("%s %5.1f|%5.1f|%5.1f -> %5.1f|%5.1f" % (tile, run_fwd(spec, B, H, tile)[1], run_fwd(spec, B, H, tile, stats=True)[1],
+                                                                 run_fwd(spec, B, H, tile, stats=True, affine=True)[1],
+                                                                 run_fwd(spec, B, H, tile, presplit=True)[1], run_fwd(spec, B, H, tile, stats=True, presplit=True)[1]))
+            print("%-26s %s" % (name, "  ".join(res)), flush=True)
+        print("awr_split_act alone (one pass, 10 B per element): us, GB/s -- plain | with BatchNorm affine + ReLU")
+        for C_, H in ((64, 64), (128, 32), (256, 16), (512, 8), (256, 64), (128, 64)):
+            t0, g0 = run_split_act(C_, B, H)
+            t1, g1 = run_split_act(C_, B, H, True)
+            print("  C=%3d @%2d: %7.1f us %6.0f GB/s | %7.1f us %6.0f GB/s" % (C_, H, t0 * 1e6, g0, t1 * 1e6, g1))
+        L.call("awr_set_gemm_products", 1)
     elif args.mode == "fwdset":      # forward / data-gradient GEMM only, every tile, plain and with the BatchNorm statistics epilogue: the
         B = args.batch                # same-box A/B of the staging variants (AWR_DMA=0..3, one process each; tools/gpu_r4_a.sh)
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
