@@ -1036,9 +1036,12 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 // SW: 0 = mfma(A fragment, W fragment) (lane = channel, registers = pixels), 1 = operand roles swapped (lane = pixel, registers = channels: 16-byte
 // bounce rows), 2 = swapped and, for the PLAIN epilogue, stored straight from the accumulators (no LDS in the epilogue at all)
-template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0>
+// FUSE2 (round 5): the fused conv pair of conv_gemm_body (a.w2: conv2 3x3 -> bn3 -> ReLU -> conv3 1x1 + skip in one launch, inference) with the FIRST GEMM on
+// LDS-DMA staging -- that GEMM is 80 % of the pair's work and was the last big launch family still on the register-staged kernel.
+template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
+    static_assert(!FUSE2 || (AFF == 0 && !EPRE && !DUAL && !ACCB && SW == 0), "FUSE2: plain first GEMM");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
     constexpr int LPR = KB / 4;                   // 16-byte chunks (= staging lanes) per row
@@ -1048,7 +1051,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     constexpr int STAGE = (AROWS + BN) * ROWB;
     constexpr bool DIRECT = SW == 2 && EM == 1;
     constexpr int EPI = DIRECT ? 0 : 4 * 32 * LDK * 4;         // the epilogue's four 32x36 transpose tiles
-    constexpr int BUFS = NBUF * STAGE > EPI ? NBUF * STAGE : EPI;
+    // FUSE2: [stage buffers, later the intermediate tile BM x (BN + 4)][w2 K-slices BN x 36, then the transpose tiles]
+    constexpr int F2A = BM * (BN + 4) * 4, F2B = BN * LDK * 4 > EPI ? BN * LDK * 4 : EPI;
+    constexpr int BUFS = FUSE2 ? (NBUF * STAGE > F2A ? NBUF * STAGE : F2A) + F2B : (NBUF * STAGE > EPI ? NBUF * STAGE : EPI);
     static_assert(RA >= 1 && RB >= 1, "tile too small for the stage shape");
     // AFF: the coefficient vectors of the fused input arithmetic behind the stage buffers (<= AFF_MAXC channels; the launcher checks)
     __shared__ __attribute__((aligned(16))) char smem_raw[BUFS + (AFF == 2 ? 4 : AFF ? 2 : 0) * AFF_MAXC * 4];
@@ -1056,7 +1061,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 
     const awr_phase& ph = a.ph[blockIdx.y];
     const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = (a.N + BN - 1) / BN;
+    const int tilesN = FUSE2 ? 1 : (a.N + BN - 1) / BN;      // (FUSE2: a.N is the second conv's channel count; the first has BN)
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1351,6 +1356,91 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
     }
+    if constexpr (FUSE2) {
+        // second GEMM exactly as in conv_gemm_body<FUSE2>: the tile (all BN channels of its BM pixels) -> bias / folded BatchNorm / ReLU in registers ->
+        // LDS as the A operand of the 1x1 conv3 (w2 [N][BN + N1x], register-staged 32-float slices), N = 2 BN in two unrolled passes
+        constexpr int P2 = BN + 4, ROWB2 = LDK * 4, RB2 = BN / 32;
+        float* const A2 = smem;
+        char* const B2 = smem_raw + (NBUF * STAGE > F2A ? NBUF * STAGE : F2A);
+        const int r0f = tid >> 3, kcf = (tid & 7) * 4;
+        __syncthreads();                                         // the stage buffers are dead
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * 32 * TN + j * 32 + l31;
+            const float b1 = a.bias ? a.bias[col] : 0.f, sc = a.out_scale ? a.out_scale[col] : 1.f, sh = a.out_shift ? a.out_shift[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[i][j][r] + b1) * sc + sh;
+                    if (a.relu_out) v = relu1(v);
+                    A2[(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * P2 + col] = v;
+                }
+        }
+        const int K2 = BN + a.N1x, nsl = K2 / BK, nsl_lds = BN / BK;
+        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, OOB);
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.N1x ? a.in2 : a.in, a.N1x ? (unsigned)M * (unsigned)a.N1x * 4u : 0u);
+        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 * TM + l31) * P2) * 4 + 16 * half;
+        const char* b2_frag = B2 + (wn * 32 * TN + l31) * ROWB2 + 16 * half;
+        unsigned x_off[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
+            x_off[i] = m < M ? ((unsigned)m * (unsigned)a.N1x + 4u * half) * 4u : OOB;
+        }
+        awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
+        e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
+        float4 rb2[RB2], xa[TM][4];
+        auto load_b2 = [&](int hf, int s2) {
+            const unsigned row0 = (unsigned)(hf * BN + r0f), k0 = (unsigned)(BK * s2 + kcf);
+#pragma unroll
+            for (int i = 0; i < RB2; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * (unsigned)K2 + k0) * 4u);
+        };
+        auto load_x = [&](int s2) {
+            const unsigned kb = (unsigned)(BK * (s2 - nsl_lds)) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xa[i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
+        };
+        load_b2(0, 0);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int s2 = 0; s2 < nsl; ++s2) {
+                if (s2 >= nsl_lds) load_x(s2);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < RB2; ++i) st4(reinterpret_cast<float*>(B2 + (r0f + 32 * i) * ROWB2) + kcf, rb2[i]);
+                __syncthreads();
+                if (s2 + 1 < nsl) load_b2(hf, s2 + 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float4 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = s2 < nsl_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + BK * s2 + 8 * s) : xa[i][s];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_frag + j * 32 * ROWB2) + 8 * s);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (hf == 0) load_b2(1, 0);
+            gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
+        }
+        return;
+    }
     if constexpr (DIRECT) {
         if constexpr (EPRE) gemm_epilogue_direct<TM, TN, true>(a, ph, acc, M, tile_m, tile_n, &epre, eoffd);
         else gemm_epilogue_direct<TM, TN, false>(a, ph, acc, M, tile_m, tile_n);
@@ -1362,6 +1452,10 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
     conv_gemm_dma_body<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, SW>(a);
+}
+template <int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_pair_kernel(const awr_conv_args a) {
+    conv_gemm_dma_body<TM, TN, 16, 2, 0, false, 1, false, false, 0, true>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2722,6 +2816,14 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
                         M * (int64_t)a->N1x * 4 < (1LL << 32),
                     "conv_gemm: tensors must stay below 4 GB (32-bit buffer offsets)");
         const dim3 grid2((unsigned)((M + (a->N1 == 64 && a->tile_m == 2 ? 127 : 63)) / (a->N1 == 64 && a->tile_m == 2 ? 128 : 64)), 1);
+        // first GEMM on LDS-DMA staging (round 5) whenever its input needs no arithmetic; AWR_DMA=0 / AWR_FUSE2_DMA=0: the register-staged pair
+        static const int pair_dma = env_int("AWR_FUSE2_DMA", 1);
+        if (pair_dma && g_staging != 0 && !a->in_scale && !a->relu_in) {
+            if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<1, 2>), grid2, dim3(256), 0, as_stream(stream), *a);
+            else if (a->tile_m == 2) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<2, 1>), grid2, dim3(256), 0, as_stream(stream), *a);
+            else hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<1, 1>), grid2, dim3(256), 0, as_stream(stream), *a);
+            return check_launch("conv_gemm_dma_pair_kernel");
+        }
         if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
         else if (a->tile_m == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, 1, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);
         else hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 0, false, false, false, true>), grid2, dim3(256), 0, as_stream(stream), *a);

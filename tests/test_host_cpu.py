@@ -230,3 +230,29 @@ def test_visualisation_and_pck_plot_without_cv2_or_matplotlib(tmp_path):
     cols = np.where(blue.any(0))[0]
     first_row = np.array([np.where(blue[:, c])[0].min() for c in cols])
     assert cols.size > 200 and first_row[0] > first_row[-1] + 100      # the curve climbs from the bottom-left to the top-right
+
+
+def test_bench_rank_affinity_helpers(monkeypatch):
+    """bench.py, N > 1: a rank is pinned to the CPUs of its GPU's NUMA node, or -- when /sys reports none -- to an equal contiguous share of
+    the allowed CPUs.  Pure host logic: exercised here without a GPU (the device query is stubbed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("awr_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and bench._cpulist("") == set()
+    allowed = sorted(os.sched_getaffinity(0))
+
+    class Props:          # a device whose PCI address has no sysfs entry: the equal-share fallback
+        pci_bus_id, pci_device_id, pci_domain_id = 0xfe, 0x1f, 0xffff
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: Props())
+    pinned = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.append(set(cpus)))
+    nlocal = 2 if len(allowed) >= 2 else 1
+    shares = [bench._pin_cpu_affinity(None, r, nlocal) for r in range(nlocal)]
+    assert all("error" not in s and s["numa_node"] is None and s["n_cpus"] >= 1 for s in shares), shares
+    assert len(pinned) == nlocal and all(p <= set(allowed) for p in pinned)
+    if nlocal == 2:
+        assert not (pinned[0] & pinned[1])                     # disjoint shares
+    # a failing query is reported, never raised (an unpinned rank is slower, not wrong)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: (_ for _ in ()).throw(RuntimeError("no device")))
+    assert "error" in bench._pin_cpu_affinity(None, 0, 1)

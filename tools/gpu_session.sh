@@ -52,6 +52,14 @@ import ctypes as C
 torch.zeros(1).cuda()
 n,k=C.c_int(),C.c_int(); L.call('awr_stream_pool_info', C.byref(n), C.byref(k)); print('GPU_MAX_HW_QUEUES=8: pool', n.value, 'independent', k.value)" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/bench_ab.txt
   ;;
+pair)     # round 5: the fused inference pair (conv2 -> bn3 -> ReLU -> conv3 + skip) with its first GEMM on LDS-DMA staging
+  timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_nets_gpu.py tests/test_full_size_gpu.py -m gpu -q --tb=short -k "pair or fused_conv or config3 or config_3" 2>&1 | tail -6 | tee $OUT/tests.log
+  for i in 1 2 3; do for v in 0 1; do
+    AWR_FUSE2_DMA=$v line "hg1 infer b128 pair_dma=$v" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  AWR_FUSE2_DMA=1 python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 --per-layer $OUT/per_layer_hg1_infer_b128.txt > /dev/null 2>&1
+  head -12 $OUT/per_layer_hg1_infer_b128.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
