@@ -1014,3 +1014,43 @@ def test_short_k_epilogue_operand_prefetch(ops, L, dev, tm, tn, cin, cout, B, H)
     torch.cuda.synchronize()
     assert rel_err(ops.nchw(g)[:, :cin].cpu(), g_ref) < 3e-6
     assert rel_err(sums.sum(0)[0][:cin].cpu(), g_ref.sum((0, 2, 3))) < 1e-5 and rel_err(sums.sum(0)[1][:cin].cpu(), (g_ref * xhat).sum((0, 2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize("staging_at_launch", [2, 0])
+def test_deterministic_wgrad_copies_survive_a_mode_switch(ops, L, dev, staging_at_launch):
+    """a deterministic plan sizes its K-chunk copies of a weight gradient when it is built; the kernel a launch picks follows the
+    process-wide staging mode AT LAUNCH TIME and may write fewer copies -- the batched scatter sums ALL of them.  awr_conv_wgrad zero-fills the
+    copies it leaves unwritten: poisoned scratch, copies sized in one mode, launched in the other, and the sum of all copies is the gradient."""
+    import ctypes as C
+    spec = ops.ConvSpec("conv", 64, 64, 3, 1, 1)
+    B, H = 4, 16
+    x, gy = rnd(B, 64, H, H, seed=1), rnd(B, 64, H, H, seed=2)
+    prob = spec.wgrad_problem(H, H)
+    D, G = (ops.nhwc(gy).to(dev), ops.nhwc(x).to(dev)) if prob["D"] == "dy" else (ops.nhwc(x).to(dev), ops.nhwc(gy).to(dev))
+    ld = prob["Cg"]
+    rsize = prob["Cd"] * len(prob["taps"]) * ld
+    ref = TF.conv2d(x.double().transpose(0, 1), gy.double().transpose(0, 1), padding=1).transpose(0, 1)      # (cout, cin, 3, 3)
+    sizes = {}
+    try:
+        for mode in (2, 0):          # how many copies each mode's kernel writes
+            L.call("awr_set_gemm_staging", mode)
+            a = ops.make_wgrad_args(prob, B, D, G, D, ld)
+            a.split_stride, a.max_split = rsize, 64
+            n = C.c_int()
+            L.call("awr_conv_wgrad_splits", C.byref(a), C.byref(n))
+            sizes[mode] = n.value
+        built = max(sizes.values()) + 2                      # what a plan built in the "larger" mode (and then some) would have allocated
+        R = torch.full((built, rsize), float("nan"), device=dev)
+        L.call("awr_set_gemm_staging", staging_at_launch)
+        a = ops.make_wgrad_args(prob, B, D, G, R, ld)
+        a.split_stride, a.max_split = rsize, built
+        L.call("awr_conv_wgrad", C.byref(a), L.stream())
+        torch.cuda.synchronize()
+        assert not torch.isnan(R).any()
+        assert bool((R[sizes[staging_at_launch]:] == 0).all())              # the unwritten copies were cleared, not left stale
+        grad = torch.empty(prob["d0"], prob["d1"], 3, 3, device=dev)
+        Rs = R.sum(0).contiguous()
+        L.call("awr_unpack_wgrad", L.ptr(Rs), prob["d0"], prob["d1"], spec.T, ld, L.ptr(grad), 0, L.stream())
+        assert rel_err(grad.cpu(), ref) < 2e-6
+    finally:
+        L.call("awr_set_gemm_staging", 2)
