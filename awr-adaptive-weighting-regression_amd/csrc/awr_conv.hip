@@ -1041,6 +1041,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
+    static_assert(AFF != 4 || (KB == 16 && NBUF == 2), "the in-LDS affine pass belongs to the shipped stage shape");
     static_assert(!FUSE2 || (AFF == 0 && !EPRE && !DUAL && !ACCB && SW == 0), "FUSE2: plain first GEMM");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
@@ -1107,7 +1108,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     // are staged (same pixel, same channel chunk, same padding rule) and the two multiply-adds run on the fragments -- the
     // awr_bn_bwd_apply pass between two dependent data-gradient GEMMs leaves the critical chain.
     float* const aff_tab = reinterpret_cast<float*>(smem_raw + BUFS);
-    int f_iy[AFF ? TM : 1], f_ix[AFF ? TM : 1];
+    // AFF == 4 (round 5): the same affine + ReLU as an IN-LDS pass -- the thread that requested a 16-byte chunk rewrites it in place once its own
+    // DMA has landed (behind its vmcnt wait, in front of the stage's barrier): once per element instead of once per (element, N-wave), off the
+    // fragment -> MFMA dependency chain, the padding rule a per-row skip (a row the request declared out of range holds the zeros it must keep).
+    constexpr bool FRAG_AFF = AFF == 1 || AFF == 2 || AFF == 3;      // arithmetic on the fragments
+    int f_iy[FRAG_AFF ? TM : 1], f_ix[FRAG_AFF ? TM : 1];
     unsigned fmask = 0;
     if constexpr (AFF) {
         for (int c = tid * 4; c < cin1; c += 1024) {
@@ -1121,22 +1126,26 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 st4(aff_tab + AFF_MAXC + c, a.in_shift ? ld4(a.in_shift + c) : make_float4(0, 0, 0, 0));
             }
         }
+        if constexpr (FRAG_AFF) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-            f_iy[i] = -(1 << 20);
-            f_ix[i] = 0;
-            if (m < M) {
-                int qx, qy, b;
-                decode_row(a, m, qx, qy, b);
-                f_iy[i] = qy * a.si;
-                f_ix[i] = qx * a.si;
+            for (int i = 0; i < TM; ++i) {
+                const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
+                f_iy[i] = -(1 << 20);
+                f_ix[i] = 0;
+                if (m < M) {
+                    int qx, qy, b;
+                    decode_row(a, m, qx, qy, b);
+                    f_iy[i] = qy * a.si;
+                    f_ix[i] = qx * a.si;
+                }
             }
+        } else {
+            __syncthreads();      // the first stage is rewritten in front of its barrier: the coefficient table has to be complete
         }
     }
-    float f_hi[AFF ? TM : 1];      // upper clamp bound of the lane's fragment rows for the current tap: +inf inside the image, 0 on padding rows
+    float f_hi[FRAG_AFF ? TM : 1];      // upper clamp bound of the lane's fragment rows for the current tap: +inf inside the image, 0 on padding rows
     auto set_ftap = [&](int tap) {
-        if constexpr (AFF) {
+        if constexpr (FRAG_AFF) {
             const int tp = ph.tap[tap];
             const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
             fmask = 0;
@@ -1281,11 +1290,29 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                         acc[i][j] = SW ? __builtin_amdgcn_mfma_f32_32x32x2f32((&fb[j].x)[k], (&fa[i].x)[k], acc[i][j], 0, 0, 0)
                                        : __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
         }
-        if constexpr (AFF) {
+        if constexpr (FRAG_AFF) {
             cc0 += KB;
             if (cc0 == a.Cin) { cc0 = 0; if (++ctap < ph.ntaps) set_ftap(ctap); }
         }
         fold();
+    };
+    // AFF == 4: rewrite this thread's own chunks of the stage it has just seen land (stage at channel offset c0s of the CURRENT tap state)
+    const float aff_lo = a.relu_in ? 0.f : -__builtin_inff();
+    auto rewrite = [&](int buf, int c0s) {
+        if constexpr (AFF == 4) {
+            if (DUAL && c0s >= cin1) return;       // (wave-uniform) the second tensor of a two-tensor K extent is plain
+            const float4 sc = ld4(aff_tab + c0s + kc), sh = ld4(aff_tab + AFF_MAXC + c0s + kc);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                if (tapmask & (1u << i)) {
+                    float* p = reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16);
+                    float4 v = ld4(p);
+                    v.x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, aff_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, aff_lo, __builtin_inff());
+                    v.z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, aff_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, aff_lo, __builtin_inff());
+                    st4(p, v);
+                }
+            }
+        }
     };
     int tap = 0, c0 = 0;
     auto advance = [&]() {
@@ -1306,13 +1333,14 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     }
     // stage_done: everything this wave asked for has landed (its own vmcnt), then the barrier: every wave's pieces are visible and every
     // wave is done reading the stage that is requested next.  The scheduling fence keeps the MFMAs of the stage in front of the wait.
-    auto stage_done = [&]() {
+    auto stage_done = [&](int buf = 0, int c0s = 0) {      // (buf, c0s): the stage that was requested last -- AFF == 4 rewrites it before the barrier
         __builtin_amdgcn_sched_barrier(0);
         dma_wait();
+        rewrite(buf, c0s);
         __syncthreads();
     };
     issue(0, 0);
-    stage_done();
+    stage_done(0, 0);
     if constexpr (NBUF == 2) {
         // unrolled by two: the stage buffer is a compile-time constant in every LDS address
 #ifndef AWR_GEMM_LOOP_NOEXITS
@@ -1320,11 +1348,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         for (; ks + 2 <= ksteps; ks += 2) {
             advance(); issue(c0, 1);      // (ks + 1 < ksteps holds here)
             compute(0);
-            stage_done();
+            stage_done(1, c0);
             const bool more = ks + 2 < ksteps;
             if (more) { advance(); issue(c0, 0); }
             compute(1);
-            if (more) stage_done();
+            if (more) stage_done(0, c0);
         }
         if (ks < ksteps) compute(0);      // odd stage count: the last stage sits in buffer 0
 #else
@@ -2656,6 +2684,12 @@ static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, i
 #ifdef AWR_DMA_STUDY
     if (mode == 1 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 2, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 2, 0>(a, grid, st, epre, em); return; }
     if (mode == 3 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 1, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, 0>(a, grid, st, epre, em); return; }
+#endif
+    // (round-5 study, -DAWR_AFF_LDS_STUDY + AWR_AFF_LDS=1: the fused input affine as an in-LDS pass, AFF == 4 -- fewer registers, bit-identical, NOT faster:
+    // profiles/r05_affine_lds_pass.txt)
+#ifdef AWR_AFF_LDS_STUDY
+    static const int aff_lds = env_int("AWR_AFF_LDS", 0);
+    if (aff && aff != 2 && aff_lds) { launch_dma_em<TM, TN, 16, 2, 4>(a, grid, st, epre, em); return; }
 #endif
     if (aff == 2) launch_dma_em<TM, TN, 16, 2, 2>(a, grid, st, epre, em);
     else if (aff == 3) launch_dma_em<TM, TN, 16, 2, 3>(a, grid, st, epre, em);

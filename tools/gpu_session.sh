@@ -60,6 +60,16 @@ pair)     # round 5: the fused inference pair (conv2 -> bn3 -> ReLU -> conv3 + s
   AWR_FUSE2_DMA=1 python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 --per-layer $OUT/per_layer_hg1_infer_b128.txt > /dev/null 2>&1
   head -12 $OUT/per_layer_hg1_infer_b128.txt
   ;;
+afflds)   # round 5: the fused input affine as an in-LDS pass (AWR_AFF_LDS=1, default) against the fragment-side form (0)
+  timeout 1500 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward or prologue or affine" 2>&1 | tail -3 | tee $OUT/ops.log
+  for e in 0 1; do AWR_AFF_LDS=$e timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | tee $OUT/fwdset_afflds$e.txt; done
+  for i in 1 2 3; do for e in 0 1; do
+    AWR_AFF_LDS=$e line "r18 b64 afflds$e" | tee -a $OUT/bench_ab.txt
+    AWR_AFF_LDS=$e line "hg1 b64 afflds$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_AFF_LDS=$e line "hg1 infer b128 afflds$e" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  for e in 0 1; do AWR_AFF_LDS=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 AWR_AFF_LDS=$e |" | tee -a $OUT/bench_ab.txt; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
