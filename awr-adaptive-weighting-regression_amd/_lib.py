@@ -102,6 +102,7 @@ _SIGS = {
     "awr_pack_weights_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_unpack_wgrads_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
+    "awr_conv_gemm_part": ([C.POINTER(ConvArgs), _I, _I, _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_conv_wgrad_algo_ok": ([C.POINTER(WgradArgs), _I], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),

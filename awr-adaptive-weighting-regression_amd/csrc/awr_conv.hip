@@ -2809,6 +2809,34 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     return AWR_OK;
 }
 
+// One of `nparts` equal batch parts of the launch `a` describes (images [part * B / nparts, (part + 1) * B / nparts)): images are independent rows of
+// the GEMM, so the parts are independent launches that may be issued at different points of a stream (the half-batch BatchNorm-backward wavefront of
+// the training plans: the data gradient of half A runs while half B's d(y) is still being written).  Deterministic mode: part p's workgroups take the
+// statistics slots from p * stat_slots / nparts on.
+int awr_conv_gemm_part(const awr_conv_args* a, int nparts, int part, void* stream) {
+    AWR_REQUIRE(a && nparts >= 1 && part >= 0 && part < nparts && a->B % nparts == 0 && !a->w2 && !(a->partial && a->split_max > 1),
+                "conv_gemm_part: part %d of %d of a batch of %d (no fused pair / split-K)", part, nparts, a ? a->B : 0);
+    if (nparts == 1) return awr_conv_gemm(a, stream);
+    const int64_t in_img = (int64_t)a->Hin * a->Win * a->Cin, out_img = (int64_t)a->Hout * a->Wout * a->N;
+    awr_conv_args b = *a;
+    b.B = a->B / nparts;
+    const int64_t ioff = in_img * b.B * part, ooff = out_img * b.B * part;
+    b.in = a->in + ioff;
+    if (a->in_split) b.in_split = static_cast<const char*>(a->in_split) + ioff * 6;
+    b.out = a->out + ooff;
+    if (a->res) b.res = a->res + ooff;
+    if (a->bnr_y) b.bnr_y = a->bnr_y + ooff;
+    if (a->bnr_act) b.bnr_act = a->bnr_act + ooff;
+    if (a->bnr2_y) b.bnr2_y = a->bnr2_y + ooff;
+    if (a->in2) {         // two-tensor K extent: Cin1 channels in `in`, the rest in `in2`
+        b.in = a->in + (int64_t)a->Hin * a->Win * a->Cin1 * b.B * part;
+        b.in2 = a->in2 + (int64_t)a->Hin * a->Win * (a->Cin - a->Cin1) * b.B * part;
+    }
+    if (a->in_bnb_y) b.in_bnb_y = a->in_bnb_y + ioff;
+    if (a->stat_slots > 0) b.stat_slot_base = a->stat_slot_base + part * (a->stat_slots / nparts);      // (slot = (base + workgroup) % stat_slots, as in the > 4 GB chunk loop)
+    return awr_conv_gemm(&b, stream);
+}
+
 static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
     AWR_REQUIRE(a->accum == 0 || a->accum == 1, "conv_gemm: accum=%d", a->accum);

@@ -609,6 +609,8 @@ struct Tn {
     // gradient reads g = d(loss)/d(bn(y)) (masked) and y itself and forms d(y) = a1 g + a2 (y - mean) + a3 on the fly (awr_conv_args.in_bnb_y);
     // d(y) is still written -- by an apply launch that travels with the weight gradient on its side stream
     bool conv_out = false;
+    bool half_ok = false;     // conv output whose data gradient may run as two half-batch parts (set by conv())
+    bool half_dy = false;     // ... and whose BatchNorm backward writes d(y) half by half: the second half on the weight gradient's stream
     int conv_taps = 0;
     const float *lz_g = nullptr, *lz_lin4 = nullptr, *lz_mean = nullptr, *lz_invstd = nullptr, *lz_coef = nullptr;
     std::string name;
@@ -616,7 +618,7 @@ struct Tn {
     int64_t numel() const { return npix() * C; }
 };
 
-enum OpKind { OP_CALL = 0, OP_ZERO, OP_COPY, OP_BUCKET, OP_FORK, OP_ENDFORK, OP_JOIN };
+enum OpKind { OP_CALL = 0, OP_ZERO, OP_COPY, OP_BUCKET, OP_FORK, OP_ENDFORK, OP_JOIN, OP_HALFWAIT };
 
 struct Op {
     int kind = OP_CALL;
@@ -629,6 +631,8 @@ struct Op {
     int sid = 0;              // fork / join stream id
     bool side_ok = false;     // weight-gradient launch that may run on a side stream
     bool pair_next = false;   // side_ok launch that shares the side stream of the NEXT side_ok launch (its producer: awr_bn_bwd_apply -> awr_conv_wgrad)
+    bool half_sig = false;    // side_ok launch (the second half of a BatchNorm-backward apply): record "half B is written" behind it; OP_HALFWAIT makes the
+                              // issuing chain wait for that record (NOT for the weight gradient queued behind it on the same side stream)
     bool gemm = false;        // conv / stem family (timed by run_timed)
     bool boundary = false;    // NCHW <-> NHWC bridge at the reference boundary: skipped while the plan's NHWC boundary is on
     double macs = 0.0;
@@ -875,6 +879,13 @@ struct Builder {
         Tn* y = new_t(B, prob.Hout, prob.Wout, prob.N, true, layer->name + ".out");
         y->conv_out = o.res == nullptr;      // (its gradient has exactly one reader pair: this conv's weight and data gradient)
         y->conv_taps = spec.T();
+        {   // half-batch BatchNorm-backward wavefront (bn_bwd / conv_bwd).  OPT-IN: built for VERDICT r4 item 3, parity-green, and measured SLOWER on every
+            // shape (ResNet18 12.8 -> 13.4 ms, Hourglass-1 23.5 -> 24.7 ms at 32 768 rows per half: two half-batch data gradients lose more than the
+            // hidden apply pass wins; profiles/r05_half_batch_wavefront.txt).  AWR_HALF_BNB_MIN_ROWS = rows of the data-gradient GEMM per half from
+            // which a layer takes part (read per plan); 0 = off, the default.
+            const int64_t half_min = env_or("AWR_HALF_BNB_MIN_ROWS", 0);
+            y->half_ok = P.training && half_min > 0 && !o.res && x->needs_grad && B % 2 == 0 && (int64_t)(B / 2) * x->H * x->W >= half_min;
+        }
         if (o.want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, (int)prob.phases.size()), prob.N);
         const float* bias = o.use_bias ? layer->bias_ptr() : nullptr;
         join_if(o.res);
@@ -1153,9 +1164,24 @@ struct Builder {
             // remember who wrote d(x), in order: a full-coverage dgrad that is the LAST producer can host the fused BN-backward reduction
             P.grad_writers[x].push_back(dp.full ? da : nullptr);
             const std::string dname = "awr_conv_dgrad:" + layer->name;
-            Op& dop = b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
-            dop.gemm = true;
-            dop.macs = layer_macs;
+            if (y->half_dy && res == nullptr) {      // d(y) arrives half by half (bn_bwd): part 0 now, part 1 behind the record of half B
+                Op& d0 = b(dname, [da](void* s) { return awr_conv_gemm_part(da, 2, 0, s); });
+                d0.gemm = true;
+                d0.macs = 0.5 * layer_macs;
+                Op& hw = b("__halfwait__", nullptr);
+                hw.kind = OP_HALFWAIT;
+                Op& d1 = b(dname + "/b", [da](void* s) { return awr_conv_gemm_part(da, 2, 1, s); });
+                d1.gemm = true;
+                d1.macs = 0.5 * layer_macs;
+            } else {
+                if (y->half_dy) {      // (cannot happen: half_ok excludes a fused residual) -- still correct: wait for half B first
+                    Op& hw = b("__halfwait__", nullptr);
+                    hw.kind = OP_HALFWAIT;
+                }
+                Op& dop = b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
+                dop.gemm = true;
+                dop.macs = layer_macs;
+            }
             P.gemms.push_back({da, nullptr, dname});
         }
         if (res) contribute_identity(res, dy);
@@ -1311,6 +1337,25 @@ struct Builder {
                 float* lin4 = alloc<float>(4 * (int64_t)C);
                 b("awr_bn_bwd_finalize", [=](void* s) { return awr_bn_bwd_finalize_lin(sp, C, npix, gam, mean, invstd, coef, lin4, gg, gb, 0, ns, s); });
                 y->lz_g = da; y->lz_lin4 = lin4; y->lz_mean = mean; y->lz_invstd = invstd; y->lz_coef = coef;
+            } else if (y->half_ok && y->needs_grad) {
+                // Half-batch wavefront (round 5): the reduction needs the whole batch, the apply and the data gradient behind it do
+                // not.  finalize -> apply(half A) on the issuing chain -> apply(half B) on the stream the layer's weight gradient is about to take
+                // (it waits for the chain, i.e. starts when half A is done, and the weight gradient queues behind it: it needs both halves anyway)
+                // -> conv_bwd issues dgrad(half A) beside it, waits for half B's record, then dgrad(half B).  The HBM-bound pass runs beside an
+                // MFMA-bound one instead of alone; no extra stream (the runtime's four hardware queues are taken).
+                b("awr_bn_bwd_finalize", [=](void* s) { return awr_bn_bwd_finalize(sp, C, npix, gam, invstd, coef, gg, gb, 0, ns, s); });
+                const int64_t hp = npix / 2, off = hp * C;
+                b("awr_bn_bwd_apply", [=](void* s) {
+                    return awr_bn_bwd_apply_only(da, act, yb, mean, invstd, msc, msh, coef, hp, C, gy, dy_add, g_out, s);
+                });
+                Op& hb = b("awr_bn_bwd_apply", [=](void* s) {
+                    return awr_bn_bwd_apply_only(da + off, act ? act + off : nullptr, yb + off, mean, invstd, msc, msh, coef, npix - hp, C, gy + off,
+                                                 dy_add ? dy_add + off : nullptr, g_out ? g_out + off : nullptr, s);
+                });
+                hb.side_ok = true;
+                hb.pair_next = true;
+                hb.half_sig = true;
+                y->half_dy = true;
             } else {
                 b("awr_bn_bwd_apply", [=](void* s) {
                     return awr_bn_bwd_apply(da, act, yb, mean, invstd, gam, msc, msh, sp, coef, npix, C, gy, dy_add, g_out, gg, gb, 0, ns, s);
@@ -1923,6 +1968,7 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
     size_t nside = 0;
     void* cur = stream;
     bool after_join = false;
+    hipEvent_t half_ev = nullptr;      // "half B of the last split BatchNorm-backward apply is written" (OP_HALFWAIT)
     auto hand_off = [&]() -> int {       // everything the bucket needs (main chain so far + weight gradients) -> comm stream
         NET_CHECK(stream_wait(P, comm, main));
         for (auto st : P.side)
@@ -1980,6 +2026,12 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
             case OP_JOIN:
                 if (use_side) NET_CHECK(stream_wait(P, main, is_bwd ? P.branch[op.sid % P.branch.size()] : P.side[op.sid % P.side.size()]));
                 continue;
+            case OP_HALFWAIT:      // the second half of a BatchNorm-backward apply went to a side stream: its record, not the stream's tail
+                if (half_ev) {
+                    HIP_TRY(hipStreamWaitEvent(awr::as_stream(cur), half_ev, 0));
+                    half_ev = nullptr;
+                }
+                continue;
             default:
                 break;
         }
@@ -1992,6 +2044,15 @@ static int run_list(awr_plan& P, std::vector<Op>& ops, void* stream, bool is_bwd
             NET_CHECK(stream_wait(P, st, awr::as_stream(cur)));      // its operands (dY, x) are final at this point of the issuing chain
             rc = op.fn((void*)st);
             pending = true;
+            if (op.half_sig && rc == AWR_OK) {
+                if (P.events.size() < 2048) {
+                    hipEvent_t e;
+                    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    P.events.push_back(e);
+                }
+                half_ev = P.events[P.ev_next++ % P.events.size()];
+                HIP_TRY(hipEventRecord(half_ev, st));
+            }
         } else {
             rc = op.fn(after_join ? stream : cur);
         }

@@ -248,6 +248,9 @@ typedef struct awr_conv_args {
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
  * Replaces nn.Conv2d / nn.ConvTranspose2d forward and their dgrad. */
 int awr_conv_gemm(const awr_conv_args* a, void* stream);
+/* one of `nparts` equal batch parts of that launch (B % nparts == 0): images are independent rows of the GEMM.  The training plans issue a data
+ * gradient as two half-batch parts so that the first runs while the BatchNorm-backward pass of the second half is still writing */
+int awr_conv_gemm_part(const awr_conv_args* a, int nparts, int part, void* stream);
 /* test hook: force the (TM,TN) in {1,2}^2 workgroup tile of awr_conv_gemm / awr_conv_wgrad
  * (0,0 = automatic choice).  Not for production use. */
 int awr_debug_force_tile(int tm, int tn);

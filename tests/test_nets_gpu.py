@@ -1039,3 +1039,42 @@ def test_tuning_cache_round_trip(amd, dev, tmp_path, monkeypatch):
     assert tuned[0] == tuned[1]
     algos = {v[0][3] for k, v in tuned[1].items() if k.startswith("awr_conv_wgrad:")}
     assert algos and algos <= {0, 1, 2, 3} and (algos & {1, 3})
+
+
+@pytest.mark.parametrize("net,streams", [("resnet_18", 2), ("resnet_18", 0), ("hourglass_1", 2)])
+def test_half_batch_batchnorm_backward_wavefront(amd, dev, net, streams, monkeypatch):
+    """Round 5: where half a batch still fills the chip the BatchNorm-backward apply is written half by half -- half A on the
+    issuing chain, half B on the stream the layer's weight gradient takes -- and the data gradient runs as two half-batch parts, the first beside
+    half B's pass (csrc/awr_net.hip: bn_bwd / conv_bwd, OP_HALFWAIT; awr_conv_gemm_part).  Forced on for every eligible layer of the batch-4 plans
+    here and compared, in deterministic mode, with the plan that applies and differentiates the whole batch at once: same losses, same gradients
+    (the fp64 statistics slots are summed in another order: not bit for bit), with and without side streams."""
+    from awr_amd.trainer import TrainEngine
+    J = 14
+    ks = 1.0 if net.startswith("resnet") else 0.4
+    img, jt_gt = O.synth_batch(4, 128, J, seed=83)
+    man = O.manifest_for(net, J)
+    amd.set_deterministic(True)
+    try:
+        res = []
+        for half_min in ("0", "1"):
+            monkeypatch.setenv("AWR_HALF_BNB_MIN_ROWS", half_min)
+            m = make_net(amd, net, J, O.procedural_state(man, seed=8))
+            eng = TrainEngine(m, 4, 128, ks, coord_weight=1.0, use_graph=False, autotune=False, wgrad_streams=streams)
+            names = eng.plan.op_names("bwd")
+            n_wait = sum(1 for n in names if n == "__halfwait__")
+            n_half = sum(1 for n in names if n.startswith("awr_conv_dgrad:") and n.endswith("/b"))
+            assert (n_wait > 0 and n_half == n_wait) if half_min == "1" else (n_wait == 0 and n_half == 0), (half_min, n_wait, n_half)
+            for it in range(2):
+                losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
+                torch.cuda.synchronize()
+                if it == 0:
+                    g0 = m.flat_grads()[:m.n_active].clone()
+            res.append((losses.clone(), g0, jt.clone(), n_wait))
+        (l0, g_a, j0, _), (l1, g_b, j1, n_wait) = res
+        d = float((g_a - g_b).double().norm() / g_a.double().norm())
+        assert d < 2e-6, d
+        assert float((l0 - l1).abs().max()) <= 1e-5 * float(l0.abs().max()) and float((j0 - j1).abs().max()) < 1e-5
+        report("%s/half_batch_wavefront/streams%d/layers" % (net, streams), n_wait)
+        report("%s/half_batch_wavefront/streams%d/grad_rel_diff" % (net, streams), d)
+    finally:
+        amd.set_deterministic(False)

@@ -70,6 +70,15 @@ afflds)   # round 5: the fused input affine as an in-LDS pass (AWR_AFF_LDS=1, de
   done; done
   for e in 0 1; do AWR_AFF_LDS=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 AWR_AFF_LDS=$e |" | tee -a $OUT/bench_ab.txt; done
   ;;
+halfbnb)  # round 5: half-batch BatchNorm-backward wavefront (AWR_HALF_BNB_MIN_ROWS: 0 = off, default 32768 rows per half)
+  timeout 1500 python -m pytest tests/test_nets_gpu.py -m gpu -q --tb=short -x -k "half_batch or side_streams or deterministic or bucketed" 2>&1 | tail -4 | tee $OUT/tests.log
+  for i in 1 2 3; do for v in 0 32768 8192; do
+    AWR_HALF_BNB_MIN_ROWS=$v line "r18 b64 half_min=$v" | tee -a $OUT/bench_ab.txt
+    AWR_HALF_BNB_MIN_ROWS=$v line "hg1 b64 half_min=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  for v in 0 32768; do AWR_HALF_BNB_MIN_ROWS=$v line "r18 b256 half_min=$v" --batch 256 | tee -a $OUT/bench_ab.txt; done
+  for v in 0 32768; do AWR_HALF_BNB_MIN_ROWS=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 half_min=$v |" | tee -a $OUT/bench_ab.txt; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
