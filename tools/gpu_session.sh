@@ -79,6 +79,28 @@ halfbnb)  # round 5: half-batch BatchNorm-backward wavefront (AWR_HALF_BNB_MIN_R
   for v in 0 32768; do AWR_HALF_BNB_MIN_ROWS=$v line "r18 b256 half_min=$v" --batch 256 | tee -a $OUT/bench_ab.txt; done
   for v in 0 32768; do AWR_HALF_BNB_MIN_ROWS=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 half_min=$v |" | tee -a $OUT/bench_ab.txt; done
   ;;
+traffic)  # does HBM / fabric traffic cost the GEMM family its clock?  16-float stages (shipped) vs 32-float stages (study build:
+          # hipcc -DAWR_DMA_STUDY -> awr-..._amd/lib_study/libawr_hip.so, AWR_DMA=1): PMC FETCH / WRITE per launch, MFMA busy, serial step time
+  export AWR_LIB_PATH=$GRAFT_REPO_ROOT/awr-adaptive-weighting-regression_amd/lib_study/libawr_hip.so
+  for m in 2 1; do
+    for i in 1 2; do AWR_DMA=$m line "r18 b64 serial AWR_DMA=$m" --wgrad-streams 0 | tee -a $OUT/bench_ab.txt; AWR_DMA=$m line "r18 b64 AWR_DMA=$m" | tee -a $OUT/bench_ab.txt; done
+    AWR_DMA=$m bash tools/gpu_pmc.sh traffic_dma$m > /dev/null 2>&1
+    cp gpurun_out/pmc_summary_traffic_dma$m.json $OUT/
+    rm -rf gpurun_out/pmc_sq_traffic_dma$m gpurun_out/pmc_fetch_traffic_dma$m gpurun_out/pmc_write_traffic_dma$m
+    python - <<PY | tee -a $OUT/bench_ab.txt
+import json
+d = json.load(open("$OUT/pmc_summary_traffic_dma$m.json"))
+for fam, keys in (("fwd/dgrad", ("conv_gemm_dma_kernel", "conv_gemm_kernel")), ("wgrad", ("conv_wgrad",))):
+    ent = [v for k, v in d.items() if any(x in k for x in keys)]
+    n = sum(v["launches"] for v in ent)
+    if n:
+        f = sum(v["launches"] * v["fetch_MB_per_launch_x2"] for v in ent) / n
+        w = sum(v["launches"] * v.get("write_MB_per_launch", 0.0) for v in ent) / n
+        b = sum(v["launches"] * v.get("mfma_busy_frac", 0.0) for v in ent) / n
+        print("AWR_DMA=$m %-10s launch-weighted: fetch x2 %.1f MB + write %.1f MB = %.1f MB per launch, MFMA busy %.3f (%d launches)" % (fam, f, w, f + w, b, n))
+PY
+  done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
