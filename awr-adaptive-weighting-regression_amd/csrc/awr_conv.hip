@@ -1040,8 +1040,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // LDS-DMA staging -- that GEMM is 80 % of the pair's work and was the last big launch family still on the register-staged kernel.
 template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
-    static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2), "stage shape");
+    static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2 || NBUF == 4), "stage shape");
     static_assert(AFF != 4 || (KB == 16 && NBUF == 2), "the in-LDS affine pass belongs to the shipped stage shape");
+    static_assert(NBUF != 4 || (KB == 16 && !ACCB && !FUSE2), "deep pipeline: 16-float stages, ordered accumulation");
     static_assert(!FUSE2 || (AFF == 0 && !EPRE && !DUAL && !ACCB && SW == 0), "FUSE2: plain first GEMM");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
@@ -1339,9 +1340,30 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         rewrite(buf, c0s);
         __syncthreads();
     };
-    issue(0, 0);
-    stage_done(0, 0);
-    if constexpr (NBUF == 2) {
+    if constexpr (NBUF == 4) {
+        // DEEP pipeline (round 5) for launches that cannot fill the chip (<= 2 workgroups per CU: low batch, the 4x4 ... 16x16 Hourglass levels, layer4):
+        // with one or two waves per SIMD nobody hides a stage's load latency (~1-2 us against 0.2 us of MFMAs per 16-float stage), so a workgroup
+        // keeps THREE stages in flight in four buffers -- the oldest is awaited with a COUNTED wait (vmcnt retires in order: at most the two younger
+        // stages' requests may still be outstanding), one barrier per stage as before.  Stages requested beyond the K extent come from nowhere (zeros
+        // nobody multiplies): the count stays constant through the tail; they are drained before the epilogue reuses the buffers.
+        constexpr int PER = RA * (AFF == 2 ? 2 : 1) + RB;      // DMA instructions per thread and stage
+        issue(0, 0);
+        advance(); issue(c0, 1, 1 < ksteps);
+        advance(); issue(c0, 2, 2 < ksteps);
+        for (int ks = 0; ks < ksteps; ks += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");      // stage ks + j has landed (this wave's share)
+                __syncthreads();                                                    // ... everybody's; and buffer (j + 3) % 4 (stage ks + j - 1) is free
+                advance(); issue(c0, (j + 3) & 3, ks + j + 3 < ksteps);
+                if (ks + j < ksteps) compute(j);
+            }
+        }
+        dma_wait();      // (the surplus requests of the tail: the epilogue's transpose tiles alias the stage buffers)
+    } else if constexpr (NBUF == 2) {
+        issue(0, 0);
+        stage_done(0, 0);
         // unrolled by two: the stage buffer is a compile-time constant in every LDS address
 #ifndef AWR_GEMM_LOOP_NOEXITS
         int ks = 0;
@@ -1365,6 +1387,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         }
 #endif
     } else {
+        issue(0, 0);
+        stage_done(0, 0);
         for (int ks = 0; ks < ksteps; ++ks) {
             const bool more = ks + 1 < ksteps;
             compute(0);
@@ -2691,6 +2715,23 @@ static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, i
     static const int aff_lds = env_int("AWR_AFF_LDS", 0);
     if (aff && aff != 2 && aff_lds) { launch_dma_em<TM, TN, 16, 2, 4>(a, grid, st, epre, em); return; }
 #endif
+    // deep pipeline (four stage buffers, three in flight) for launches of at most 384 workgroups (1.5 per CU) whose K loop is long enough to matter;
+    // ordered accumulation, no 128x128 tile (it never wins at that size), no un-materialised BatchNorm backward.  Measured (profiles/r05_deep_pipeline.txt):
+    // isolated launches do not move, steps whose launches are ALL small do -- ResNet18 train batch 4 3.59 -> 3.01 ms, batch 16 5.04 -> 4.59 ms (a launch
+    // that shares the CUs with the weight gradients of two side streams sees load latencies two buffers do not cover); with 512 the batch-64 steps
+    // lose 1 % (layer4, the Hourglass 8x8 levels), with 384 they are unchanged.  AWR_DEEP=0: never (A/B hook), AWR_DEEP_MAX_WGS: the bound
+    if constexpr (!(TM == 2 && TN == 2)) {
+        const int deep_on = env_int("AWR_DEEP", 1);      // (read per launch: tests and same-box A/Bs toggle it inside one process)
+        int minsteps = 1 << 30;
+        for (int p = 0; p < a->nphase; ++p) minsteps = a->ph[p].ntaps * (a->Cin / 16) < minsteps ? a->ph[p].ntaps * (a->Cin / 16) : minsteps;
+        static const int deep_wgs = env_int("AWR_DEEP_MAX_WGS", 384);
+        if (deep_on && aff != 2 && a->accum == 0 && (int64_t)grid.x * grid.y <= deep_wgs && minsteps >= 8) {
+            if (aff == 3) launch_dma_em<TM, TN, 16, 4, 3>(a, grid, st, epre, em);
+            else if (aff == 1) launch_dma_em<TM, TN, 16, 4, 1>(a, grid, st, epre, em);
+            else launch_dma_em<TM, TN, 16, 4, 0>(a, grid, st, epre, em);
+            return;
+        }
+    }
     if (aff == 2) launch_dma_em<TM, TN, 16, 2, 2>(a, grid, st, epre, em);
     else if (aff == 3) launch_dma_em<TM, TN, 16, 2, 3>(a, grid, st, epre, em);
     else if (aff == 1) launch_dma_em<TM, TN, 16, 2, 1>(a, grid, st, epre, em);

@@ -1,5 +1,7 @@
 """GPU parity of the backbone building blocks (implicit-GEMM conv family, BatchNorm pieces, pooling,
 layout bridges) through the C ABI, against float64 torch-CPU evaluations of the same operators."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -221,8 +223,11 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, t
     def D(t):      # device copy kept alive until the test ends (make_conv_args only stores raw pointers)
         keep.append(t.to(dev).contiguous())
         return keep[-1]
-    for staging in (0, 2):
-        L.call("awr_set_gemm_staging", staging)
+    # 0 = register staging; 2 = LDS-DMA: these small launches take the deep pipeline (four stage buffers, round 5); "2s" = LDS-DMA with the
+    # deep pipeline switched off (two stage buffers, what the chip-filling launches run)
+    for staging in (0, 2, "2s"):
+        L.call("awr_set_gemm_staging", 2 if staging == "2s" else staging)
+        os.environ["AWR_DEEP"] = "0" if staging == "2s" else "1"
         try:
             got = []
             # (a) fused prologue + full epilogue, ragged N
@@ -313,12 +318,14 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging(ops, L, dev, tm, t
             outs[staging] = got
         finally:
             L.call("awr_set_gemm_staging", 2)
-    assert len(outs[0]) == len(outs[2])
-    for i, (p, q) in enumerate(zip(outs[0], outs[2])):
-        if p.dtype == torch.float32 and p.dim() == 2:        # statistics: fp64 atomics in launch order, compared after rounding to fp32
-            assert rel_err(q.cpu(), p.cpu()) < 1e-6, i
-        else:
-            assert torch.equal(torch.nan_to_num(p, nan=-1234.0), torch.nan_to_num(q, nan=-1234.0)), i
+            os.environ.pop("AWR_DEEP", None)
+    for other in (2, "2s"):
+        assert len(outs[0]) == len(outs[other])
+        for i, (p, q) in enumerate(zip(outs[0], outs[other])):
+            if p.dtype == torch.float32 and p.dim() == 2:        # statistics: fp64 atomics in launch order, compared after rounding to fp32
+                assert rel_err(q.cpu(), p.cpu()) < 1e-6, (other, i)
+            else:
+                assert torch.equal(torch.nan_to_num(p, nan=-1234.0), torch.nan_to_num(q, nan=-1234.0)), (other, i)
 
 
 @pytest.mark.parametrize("accum", [0, 1])

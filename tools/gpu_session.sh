@@ -101,6 +101,29 @@ for fam, keys in (("fwd/dgrad", ("conv_gemm_dma_kernel", "conv_gemm_kernel")), (
 PY
   done
   ;;
+deep)     # round 5: deep pipeline (four stage buffers) for launches of at most two workgroups per CU (AWR_DEEP = 0 | 1)
+  timeout 1500 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward or prologue or dgrad_with" 2>&1 | tail -3 | tee $OUT/ops.log
+  timeout 600 python tools/microbench_gemm.py smallset 2>&1 | grep -v amdgpu.ids | tee $OUT/smallset.txt
+  for i in 1 2 3; do for e in 0 1; do
+    AWR_DEEP=$e line "r18 b64 deep$e" | tee -a $OUT/bench_ab.txt
+    AWR_DEEP=$e line "hg1 b64 deep$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP=$e line "hg1 infer b128 deep$e" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP=$e line "r18 infer b4 deep$e" --mode infer --batch 4 --steps 200 --warmup 20 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP=$e line "r18 train b4 deep$e" --batch 4 --steps 50 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP=$e line "r18 train b16 deep$e" --batch 16 --steps 50 | tee -a $OUT/bench_ab.txt
+  done; done
+  for e in 0 1; do AWR_DEEP=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 AWR_DEEP=$e |" | tee -a $OUT/bench_ab.txt; done
+  ;;
+deepwgs)  # deep pipeline: up to how many workgroups per launch (AWR_DEEP_MAX_WGS; 0 = off)
+  for i in 1 2; do for w in 0 128 256 384 512; do
+    AWR_DEEP_MAX_WGS=$w line "r18 b64 maxwgs$w" | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_MAX_WGS=$w line "hg1 b64 maxwgs$w" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_MAX_WGS=$w line "r18 train b4 maxwgs$w" --batch 4 --steps 50 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_MAX_WGS=$w line "r18 train b16 maxwgs$w" --batch 16 --steps 50 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_MAX_WGS=$w line "r18 infer b4 maxwgs$w" --mode infer --batch 4 --steps 200 --warmup 20 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_MAX_WGS=$w line "hg1 train b16 maxwgs$w" --net hourglass_1 --batch 16 --steps 30 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;

@@ -117,7 +117,7 @@ def run_split(spec, B, H, tile_a, tile_b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset", "rowset", "splitset"])
+    ap.add_argument("mode", choices=["ksweep", "layers", "split", "tiles", "wgrad", "fwdset", "wgradset", "rowset", "splitset", "smallset"])
     ap.add_argument("--batch", type=int, default=64)
     args = ap.parse_args()
     if args.mode == "ksweep":
@@ -156,6 +156,26 @@ def main():
             t1, g1 = run_split_act(C_, B, H, True)
             print("  C=%3d @%2d: %7.1f us %6.0f GB/s | %7.1f us %6.0f GB/s" % (C_, H, t0 * 1e6, g0, t1 * 1e6, g1))
         L.call("awr_set_gemm_products", 1)
+    elif args.mode == "smallset":    # launches that cannot fill the chip: the deep pipeline (AWR_DEEP=1, four stage buffers) against two buffers (0)
+        shapes = [("r18 layer1 3x3 64 @64 B4", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64, 4), ("r18 layer2 3x3 128 @32 B4", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32, 4),
+                  ("r18 layer3 3x3 256 @16 B4", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16, 4), ("r18 deconv 256->256 @32 B4", ops.ConvSpec("deconv", 256, 256, 4, 2, 1), 32, 4),
+                  ("r18 layer4 3x3 512 @8 B64", ops.ConvSpec("conv", 512, 512, 3, 1, 1), 8, 64), ("r18 layer3 3x3 256 @16 B16", ops.ConvSpec("conv", 256, 256, 3, 1, 1), 16, 16),
+                  ("hg 3x3 128 @16 B64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 16, 64), ("hg 3x3 128 @8 B64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 8, 64),
+                  ("hg 3x3 128 @4 B64", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 4, 64), ("hg 1x1 256->128 @16 B64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 16, 64),
+                  ("hg 1x1 128->256 @8 B64", ops.ConvSpec("conv", 128, 256, 1, 1, 0), 8, 64), ("hg 1x1 256->128 @4 B64", ops.ConvSpec("conv", 256, 128, 1, 1, 0), 4, 64)]
+        print("AWR_DEEP: us per launch, plain | statistics | statistics + affine -- two stage buffers -> deep (four)")
+        for name, spec, H, B in shapes:
+            res = []
+            for tile in ((1, 1), (2, 1), (1, 2)):
+                if spec.cout <= 64 and tile[1] == 2:
+                    continue
+                cell = []
+                for deep in ("0", "1"):
+                    os.environ["AWR_DEEP"] = deep
+                    cell.append("%5.1f|%5.1f|%5.1f" % (run_fwd(spec, B, H, tile)[0] * 1e6, run_fwd(spec, B, H, tile, stats=True)[0] * 1e6, run_fwd(spec, B, H, tile, stats=True, affine=True)[0] * 1e6))
+                res.append("%s %s -> %s" % (tile, cell[0], cell[1]))
+            print("%-28s %s" % (name, "   ".join(res)), flush=True)
+        os.environ.pop("AWR_DEEP", None)
     elif args.mode == "fwdset":      # forward / data-gradient GEMM only, every tile, plain and with the BatchNorm statistics epilogue: the
         B = args.batch                # same-box A/B of the staging variants (AWR_DMA=0..3, one process each; tools/gpu_r4_a.sh)
         shapes = [("layer1 3x3 64->64 @64", ops.ConvSpec("conv", 64, 64, 3, 1, 1), 64), ("layer2 3x3 128->128 @32", ops.ConvSpec("conv", 128, 128, 3, 1, 1), 32),
