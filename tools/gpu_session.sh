@@ -124,6 +124,13 @@ deepwgs)  # deep pipeline: up to how many workgroups per launch (AWR_DEEP_MAX_WG
     AWR_DEEP_MAX_WGS=$w line "hg1 train b16 maxwgs$w" --net hourglass_1 --batch 16 --steps 30 | tee -a $OUT/bench_ab.txt
   done; done
   ;;
+lazybnb)  # un-materialised BatchNorm backward inside the consuming data gradient, 1x1 convolutions only (AWR_LAZY_BNB=1), re-measured on the round-5 binary
+  for i in 1 2 3; do for v in 0 1; do
+    AWR_LAZY_BNB=$v line "r18 b64 lazy_bnb=$v" | tee -a $OUT/bench_ab.txt
+    AWR_LAZY_BNB=$v line "hg1 b64 lazy_bnb=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  for v in 0 1; do AWR_LAZY_BNB=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 lazy_bnb=$v |" | tee -a $OUT/bench_ab.txt; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
