@@ -103,6 +103,8 @@ _SIGS = {
     "awr_unpack_wgrads_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
     "awr_conv_gemm_part": ([C.POINTER(ConvArgs), _I, _I, _P], C.c_int),
+    "awr_maxpool_fwd_stats": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
+    "awr_upsample2_add_stats": ([_P, _P, _I, _I, _I, _I, _P, _P, _I, _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_conv_wgrad_algo_ok": ([C.POINTER(WgradArgs), _I], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),

@@ -200,11 +200,16 @@ __global__ void bn_fold_eval_kernel(int C, const float* __restrict__ gamma, cons
 // Column (channel) reductions over an (npix, C) matrix.  256 threads = rpp row-groups x C/4 float4
 // columns; each workgroup walks a contiguous slab of rows; per-thread fp32 partials are merged
 // through LDS and leave the workgroup as one fp64 atomic per channel per statistic.
-template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2: sum x only (bias grad, fp32 out)
+// MODE 3 / 4 (round 5): the rows are PRODUCED here and written out on the way -- 3: max-pool of x (optional un-materialised BatchNorm + ReLU on its input:
+// msc / msh), argmax recorded; 4: up1 + nearest-neighbour x2 up-sampling of `act` -- and their sum / sum of squares feed the BatchNorm that follows: the
+// separate statistics pass over the tensor just written (awr_channel_stats) disappears.
+struct prod_geom { int H, W, k, s, p, Ho, Wo, in_relu; };      // input map, window, output map
+template <int MODE>  // 0: sum x, sum x^2 ; 1: BN backward sums (g, g*xhat) ; 2: sum x only (bias grad, fp32 out) ; 3 / 4: produced rows (above)
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ msc, const float* __restrict__ msh, int64_t npix,
-                                                         int C, int Cw, int rows_per_block, int nslots, double* __restrict__ out64, float* __restrict__ out32) {
+                                                         int C, int Cw, int rows_per_block, int nslots, double* __restrict__ out64, float* __restrict__ out32,
+                                                         prod_geom pg = prod_geom(), float* __restrict__ pout = nullptr, uint8_t* __restrict__ parg = nullptr) {
     // blockIdx.y walks chunks of Cw <= 1024 channels (the 2048-channel maps of the Bottleneck ResNets): the row pitch stays C
     const int cb = blockIdx.y * Cw;
     if (Cw > C - cb) Cw = C - cb;
@@ -252,7 +257,97 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
         }
     };
-    if (active) {
+    if (MODE >= 3 && active) {
+        bool first = true;
+        float4 ks4 = make_float4(1, 1, 1, 1), kt4 = make_float4(0, 0, 0, 0);
+        if (MODE == 3 && msc) { ks4 = ld4(msc + cb + cg * 4); kt4 = ld4(msh + cb + cg * 4); }
+        auto consume = [&](int64_t r, float4 v) {      // write the produced row, accumulate its (shifted) sums
+            st4(pout + r * C + cb + cg * 4, v);
+            if (first) { c0 = v; first = false; }
+            v.x -= c0.x; v.y -= c0.y; v.z -= c0.z; v.w -= c0.w;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            ++nrows;
+        };
+        int64_t r = r0 + rg;
+        // fast paths, four rows per trip (8 / 16 independent 16-byte loads in flight per lane: the serial form below is latency-bound):
+        // the up-sampling add, and the 2x2 / stride-2 pool without padding (every Hourglass pool)
+        constexpr int U = 4;
+        if (MODE == 4 || (pg.k == 2 && pg.s == 2 && pg.p == 0)) {
+            for (; r + (int64_t)(U - 1) * rpp < r1; r += (int64_t)U * rpp) {
+                float4 w[U][4];
+                int64_t rr[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    rr[u] = r + (int64_t)u * rpp;
+                    const int ox = (int)(rr[u] % pg.Wo), oy = (int)((rr[u] / pg.Wo) % pg.Ho);
+                    const int64_t b = rr[u] / ((int64_t)pg.Wo * pg.Ho);
+                    if (MODE == 4) {
+                        w[u][0] = ld4(x + rr[u] * C + cb + cg * 4);
+                        w[u][1] = ld4(act + ((b * pg.H + (oy >> 1)) * pg.W + (ox >> 1)) * C + cb + cg * 4);
+                    } else {
+                        const float* base = x + ((b * pg.H + 2 * oy) * pg.W + 2 * ox) * C + cb + cg * 4;
+                        w[u][0] = ld4(base); w[u][1] = ld4(base + C); w[u][2] = ld4(base + (int64_t)pg.W * C); w[u][3] = ld4(base + (int64_t)pg.W * C + C);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (MODE == 4) {
+                        consume(rr[u], make_float4(w[u][0].x + w[u][1].x, w[u][0].y + w[u][1].y, w[u][0].z + w[u][1].z, w[u][0].w + w[u][1].w));
+                    } else {
+                        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        int am[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float4 q = w[u][t];
+                            if (msc) {
+                                q.x = q.x * ks4.x + kt4.x; q.y = q.y * ks4.y + kt4.y; q.z = q.z * ks4.z + kt4.z; q.w = q.w * ks4.w + kt4.w;
+                                if (pg.in_relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+                            }
+                            const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (qq[c] > m[c]) { m[c] = qq[c]; am[c] = t; }      // window code ky * 2 + kx = t; first maximum wins
+                        }
+                        if (parg) *reinterpret_cast<uchar4*>(parg + rr[u] * C + cb + cg * 4) = make_uchar4((uint8_t)am[0], (uint8_t)am[1], (uint8_t)am[2], (uint8_t)am[3]);
+                        consume(rr[u], make_float4(m[0], m[1], m[2], m[3]));
+                    }
+                }
+            }
+        }
+        for (; r < r1; r += rpp) {
+            const int ox = (int)(r % pg.Wo), oy = (int)((r / pg.Wo) % pg.Ho);
+            const int64_t b = r / ((int64_t)pg.Wo * pg.Ho);
+            float4 v;
+            if (MODE == 3) {
+                float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int am[4] = {0, 0, 0, 0};
+                for (int ky = 0; ky < pg.k; ++ky) {
+                    const int yy = oy * pg.s - pg.p + ky;
+                    if (yy < 0 || yy >= pg.H) continue;
+                    for (int kx = 0; kx < pg.k; ++kx) {
+                        const int xx = ox * pg.s - pg.p + kx;
+                        if (xx < 0 || xx >= pg.W) continue;
+                        float4 w = ld4(x + ((b * pg.H + yy) * pg.W + xx) * C + cb + cg * 4);
+                        if (msc) {      // pooled tensor = relu(x*scale+shift): the BatchNorm+ReLU output is never materialised (same arithmetic as maxpool_fwd_kernel)
+                            w.x = w.x * ks4.x + kt4.x; w.y = w.y * ks4.y + kt4.y; w.z = w.z * ks4.z + kt4.z; w.w = w.w * ks4.w + kt4.w;
+                            if (pg.in_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+                        }
+                        const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (ww[c] > m[c]) { m[c] = ww[c]; am[c] = ky * pg.k + kx; }      // first maximum wins, like ATen's max_pool2d
+                    }
+                }
+                v = make_float4(m[0], m[1], m[2], m[3]);
+                if (parg) *reinterpret_cast<uchar4*>(parg + r * C + cb + cg * 4) = make_uchar4((uint8_t)am[0], (uint8_t)am[1], (uint8_t)am[2], (uint8_t)am[3]);
+            } else {
+                const float4 u = ld4(x + r * C + cb + cg * 4), l = ld4(act + ((b * pg.H + (oy >> 1)) * pg.W + (ox >> 1)) * C + cb + cg * 4);
+                v = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
+            }
+            consume(r, v);
+        }
+    } else if (active) {
         // 4 rows per trip: up to 12 independent 16-byte loads in flight per lane (the loop is latency-bound otherwise)
         constexpr int U = 4;
         int64_t r = r0 + rg;
@@ -562,7 +657,8 @@ static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 // nslots: slot copies of the fp64 accumulator (0 = AWR_STAT_SLOTS).  The launch never has more than AWR_REDUCE_MAX_BLOCKS
 // workgroups: a caller that allocates that many copies gets one workgroup per copy (deterministic mode).
 static int col_reduce_launch(int mode, const float* x, const float* act, const float* y, const float* mean, const float* invstd,
-                             const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, int nslots, hipStream_t st) {
+                             const float* msc, const float* msh, int64_t npix, int C, double* out64, float* out32, int nslots, hipStream_t st,
+                             prod_geom pg = prod_geom(), float* pout = nullptr, uint8_t* parg = nullptr) {
     AWR_REQUIRE(C % 4 == 0 && C >= 4 && (C <= 1024 || C % 1024 == 0), "channel reduction: C=%d must be a multiple of 4 up to 1024, or a multiple of 1024", C);
     AWR_REQUIRE(npix > 0 && nslots >= 0, "channel reduction: empty tensor");
     if (nslots == 0) nslots = AWR_STAT_SLOTS;
@@ -577,6 +673,10 @@ static int col_reduce_launch(int mode, const float* x, const float* act, const f
         hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
     else if (mode == 1)
         hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
+    else if (mode == 3)
+        hipLaunchKernelGGL(col_reduce_kernel<3>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32, pg, pout, parg);
+    else if (mode == 4)
+        hipLaunchKernelGGL(col_reduce_kernel<4>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32, pg, pout, parg);
     else
         hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(grid, nchunk), dim3(256), 0, st, x, act, y, mean, invstd, msc, msh, npix, C, Cw, (int)rows, nslots, out64, out32);
     return check_launch("col_reduce_kernel");
@@ -789,6 +889,24 @@ int awr_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream), x, in_scale, in_shift, in_relu, B, H, W,
                        C, k, s, p, Ho, Wo, out, argmax);
     return check_launch("maxpool_fwd_kernel");
+}
+
+int awr_maxpool_fwd_stats(const float* x, const float* in_scale, const float* in_shift, int in_relu, int B, int H, int W, int C, int k, int s, int p,
+                          float* out, uint8_t* argmax, double* stats, int nslots, void* stream) {
+    AWR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "maxpool_fwd_stats: in_scale/in_shift must come together");
+    AWR_REQUIRE(x && out && stats && B > 0 && k >= 1 && k <= 15 && s >= 1 && p >= 0 && p < k, "maxpool_fwd_stats: bad arguments");
+    prod_geom pg;
+    pg.H = H; pg.W = W; pg.k = k; pg.s = s; pg.p = p; pg.Ho = (H + 2 * p - k) / s + 1; pg.Wo = (W + 2 * p - k) / s + 1; pg.in_relu = in_relu;
+    return col_reduce_launch(3, x, nullptr, nullptr, nullptr, nullptr, in_scale, in_shift, (int64_t)B * pg.Ho * pg.Wo, C, stats, nullptr, nslots, as_stream(stream),
+                             pg, out, argmax);
+}
+
+int awr_upsample2_add_stats(const float* up1, const float* low, int B, int Hl, int Wl, int C, float* out, double* stats, int nslots, void* stream) {
+    AWR_REQUIRE(up1 && low && out && stats && B > 0, "upsample2_add_stats: bad arguments");
+    prod_geom pg;
+    pg.H = Hl; pg.W = Wl; pg.k = 0; pg.s = 0; pg.p = 0; pg.Ho = 2 * Hl; pg.Wo = 2 * Wl; pg.in_relu = 0;
+    return col_reduce_launch(4, up1, low, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t)B * pg.Ho * pg.Wo, C, stats, nullptr, nslots, as_stream(stream),
+                             pg, out, nullptr);
 }
 
 int awr_maxpool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C, int k, int s, int p, float* dx, int accumulate,

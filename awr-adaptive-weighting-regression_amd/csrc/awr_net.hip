@@ -591,6 +591,8 @@ struct StatBuf {
     int nslots = 0;
 };
 
+struct FusedStats { double* sp = nullptr; int ns = 0; };      // set by bn_act when the BatchNorm takes the producer's statistics
+
 struct Tn {
     float* buf = nullptr;
     float* grad = nullptr;
@@ -609,6 +611,7 @@ struct Tn {
     // gradient reads g = d(loss)/d(bn(y)) (masked) and y itself and forms d(y) = a1 g + a2 (y - mean) + a3 on the fly (awr_conv_args.in_bnb_y);
     // d(y) is still written -- by an apply launch that travels with the weight gradient on its side stream
     bool conv_out = false;
+    struct FusedStats* fstats = nullptr;      // produced by a max-pool / up-sampling add that can accumulate the next BatchNorm's statistics itself
     bool half_ok = false;     // conv output whose data gradient may run as two half-batch parts (set by conv())
     bool half_dy = false;     // ... and whose BatchNorm backward writes d(y) half by half: the second half on the weight gradient's stream
     int conv_taps = 0;
@@ -669,6 +672,7 @@ struct awr_plan {
     std::vector<DualLayer*> dual_layers;
     std::deque<Tn> tensors;
     std::deque<awr_conv_args> cargs;
+    std::deque<awrnet::FusedStats> fstats;      // (deque: stable addresses, the forward launches and bn_act share them)
     std::deque<awr_wgrad_args> wargs;
     std::vector<void*> owned;
     std::vector<std::pair<void*, size_t>> zero_init;   // atomic accumulators that must be zero before the first real step
@@ -1210,7 +1214,12 @@ struct Builder {
             const float* xb = y->buf;
             double* sp = own.p;
             const int ns = own.nslots;
-            f("awr_channel_stats", [=](void* s) { return awr_channel_stats(xb, npix, C, sp, ns, s); });
+            if (y->fstats && !y->fstats->sp) {      // the max-pool / up-sampling add that wrote y accumulates them on the way (round 5): no pass of its own
+                y->fstats->sp = sp;
+                y->fstats->ns = ns;
+            } else {
+                f("awr_channel_stats", [=](void* s) { return awr_channel_stats(xb, npix, C, sp, ns, s); });
+            }
         }
         // several BNs may normalise the same tensor (hourglass): finalize zeroes the accumulator, so every BN gets its own
         y->stats = StatBuf();
@@ -1383,7 +1392,16 @@ struct Builder {
             const float *ls = x->lazy ? x->lz_scale : nullptr, *lt = x->lazy ? x->lz_shift : nullptr;
             const int lr = x->lazy && x->lz_relu ? 1 : 0;
             float* ob = y->buf;
-            f("awr_maxpool_fwd", [=](void* s) { return awr_maxpool_fwd(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, s); });
+            FusedStats* fs = nullptr;
+            if (P.training && env_or("AWR_FUSED_POOL_STATS", 1) && C % 4 == 0 && (C <= 1024 || C % 1024 == 0)) {
+                P.fstats.emplace_back();
+                fs = &P.fstats.back();
+                y->fstats = fs;
+            }
+            f("awr_maxpool_fwd", [=](void* s) {
+                return fs && fs->sp ? awr_maxpool_fwd_stats(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, fs->sp, fs->ns, s)
+                                    : awr_maxpool_fwd(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, s);
+            });
         }
         if (P.training) {
             P.nodes.push_back([=]() {
@@ -1407,7 +1425,15 @@ struct Builder {
         {
             const float *ub = up1->buf, *lb = low->buf;
             float* ob = y->buf;
-            f("awr_upsample2_add", [=](void* s) { return awr_upsample2_add(ub, lb, B, Hl, Wl, C, ob, s); });
+            FusedStats* fs = nullptr;
+            if (P.training && env_or("AWR_FUSED_POOL_STATS", 1) && C % 4 == 0 && (C <= 1024 || C % 1024 == 0)) {
+                P.fstats.emplace_back();
+                fs = &P.fstats.back();
+                y->fstats = fs;
+            }
+            f("awr_upsample2_add", [=](void* s) {
+                return fs && fs->sp ? awr_upsample2_add_stats(ub, lb, B, Hl, Wl, C, ob, fs->sp, fs->ns, s) : awr_upsample2_add(ub, lb, B, Hl, Wl, C, ob, s);
+            });
         }
         if (P.training) {
             P.nodes.push_back([=]() {

@@ -365,6 +365,12 @@ int awr_bn_fold_eval(int C, const float* gamma, const float* beta, const float* 
 /* per-channel sum / sum of squares of an NHWC tensor (for BNs whose input is not a conv output);
  * stats is [AWR_STAT_SLOTS][2][C] like the conv epilogue's */
 int awr_channel_stats(const float* x, int64_t npix, int C, double* stats, int nslots, void* stream);
+/* awr_maxpool_fwd / awr_upsample2_add that ALSO accumulate the per-channel sum and sum of squares of the tensor they write (the slot layout of
+ * awr_channel_stats): the BatchNorm that follows needs no statistics pass of its own over that tensor (model/hourglass.py:62-88: every pooled /
+ * up-sampled-and-added map enters a pre-activation residual) */
+int awr_maxpool_fwd_stats(const float* x, const float* in_scale, const float* in_shift, int in_relu, int B, int H, int W, int C, int k, int s, int p,
+                          float* out, uint8_t* argmax, double* stats, int nslots, void* stream);
+int awr_upsample2_add_stats(const float* up1, const float* low, int B, int Hl, int Wl, int C, float* out, double* stats, int nslots, void* stream);
 /* out = [relu]( x*scale[c] + shift[c] [+ res] ) */
 int awr_bn_apply(const float* x, const float* scale, const float* shift, const float* res, int relu,
                  float* out, int64_t npix, int C, void* stream);

@@ -1061,3 +1061,43 @@ def test_deterministic_wgrad_copies_survive_a_mode_switch(ops, L, dev, staging_a
         assert rel_err(grad.cpu(), ref) < 2e-6
     finally:
         L.call("awr_set_gemm_staging", 2)
+
+
+@pytest.mark.parametrize("k,s,p,B,H,C,lazy", [(2, 2, 0, 3, 16, 128, False), (2, 2, 0, 2, 8, 256, True), (3, 2, 1, 2, 14, 64, True), (2, 2, 0, 5, 12, 2048, False)])
+def test_maxpool_and_upsample_add_with_fused_statistics(L, dev, k, s, p, B, H, C, lazy):
+    """Round 5: awr_maxpool_fwd_stats / awr_upsample2_add_stats write exactly what awr_maxpool_fwd / awr_upsample2_add write (values and argmax bit for
+    bit) and leave, in the slot layout of awr_channel_stats, the per-channel sum and sum of squares of that tensor -- the statistics pass the next
+    BatchNorm would otherwise run over it (hourglass.py:62-88).  Incl. the un-materialised BatchNorm + ReLU on the pool's input, a padded 3x3 / 2
+    window, ragged row slabs and the 2048-channel chunking; nearly constant channels keep their variance (shifted sums)."""
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, H, H, C, generator=g) * 0.5 + 3.0).to(dev)                 # |mean| >> std on purpose
+    sc, sh = ((torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)) if lazy else (None, None)
+    Ho = (H + 2 * p - k) // s + 1
+    out0, out1 = torch.full((B, Ho, Ho, C), float("nan"), device=dev), torch.full((B, Ho, Ho, C), float("nan"), device=dev)
+    arg0, arg1 = torch.zeros(B, Ho, Ho, C, dtype=torch.uint8, device=dev), torch.zeros(B, Ho, Ho, C, dtype=torch.uint8, device=dev)
+    st_f, st_r = torch.zeros(16, 2, C, dtype=torch.float64, device=dev), torch.zeros(16, 2, C, dtype=torch.float64, device=dev)
+    L.call("awr_maxpool_fwd", L.ptr(x), L.ptr(sc), L.ptr(sh), int(lazy), B, H, H, C, k, s, p, L.ptr(out0), L.ptr(arg0), L.stream())
+    L.call("awr_maxpool_fwd_stats", L.ptr(x), L.ptr(sc), L.ptr(sh), int(lazy), B, H, H, C, k, s, p, L.ptr(out1), L.ptr(arg1), L.ptr(st_f), 0, L.stream())
+    L.call("awr_channel_stats", L.ptr(out0), B * Ho * Ho, C, L.ptr(st_r), 0, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and torch.equal(arg0, arg1)
+    ref = out0.double().reshape(-1, C)
+    for name, got in (("fused", st_f.sum(0)), ("separate", st_r.sum(0))):
+        assert float(((got[0] - ref.sum(0)).abs() / ref.sum(0).abs().clamp_min(1e-9)).max()) < 1e-6, name
+        assert float(((got[1] - (ref * ref).sum(0)).abs() / (ref * ref).sum(0)).max()) < 1e-6, name
+    # variance of a nearly constant channel: computed from the fused sums to 1e-4 relative
+    n = ref.shape[0]
+    var = st_f.sum(0)[1] / n - (st_f.sum(0)[0] / n) ** 2
+    assert float(((var - ref.var(0, unbiased=False)).abs() / ref.var(0, unbiased=False)).max()) < 1e-4
+    if k == 2 and not lazy and C <= 1024:      # up-sampling add at the same sizes: out = up1 + up(low)
+        up1, low = torch.randn(B, 2 * Ho, 2 * Ho, C, generator=g).to(dev), out0
+        o0, o1 = torch.empty_like(up1), torch.empty_like(up1)
+        s_f, s_r = torch.zeros(16, 2, C, dtype=torch.float64, device=dev), torch.zeros(16, 2, C, dtype=torch.float64, device=dev)
+        L.call("awr_upsample2_add", L.ptr(up1), L.ptr(low), B, Ho, Ho, C, L.ptr(o0), L.stream())
+        L.call("awr_upsample2_add_stats", L.ptr(up1), L.ptr(low), B, Ho, Ho, C, L.ptr(o1), L.ptr(s_f), 0, L.stream())
+        L.call("awr_channel_stats", L.ptr(o0), B * 4 * Ho * Ho, C, L.ptr(s_r), 0, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1)
+        r2 = o0.double().reshape(-1, C)
+        assert float(((s_f.sum(0)[0] - r2.sum(0)).abs()).max()) < 1e-6 * float(r2.abs().sum(0).max())
+        assert float(((s_f.sum(0)[1] - (r2 * r2).sum(0)).abs() / (r2 * r2).sum(0)).max()) < 1e-6

@@ -131,6 +131,14 @@ lazybnb)  # un-materialised BatchNorm backward inside the consuming data gradien
   done; done
   for v in 0 1; do AWR_LAZY_BNB=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 lazy_bnb=$v |" | tee -a $OUT/bench_ab.txt; done
   ;;
+poolstats) # round 5: max-pool / up-sampling add that accumulate the next BatchNorm's statistics (AWR_FUSED_POOL_STATS = 0 | 1)
+  timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_nets_gpu.py -m gpu -q --tb=short -x -k "fused_statistics or maxpool or upsample or hourglass or golden or deterministic or yardstick" 2>&1 | tail -4 | tee $OUT/tests.log
+  for i in 1 2 3; do for v in 0 1; do
+    AWR_FUSED_POOL_STATS=$v line "hg1 b64 pool_stats=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  for i in 1 2; do for v in 0 1; do AWR_FUSED_POOL_STATS=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 pool_stats=$v |" | tee -a $OUT/bench_ab.txt; done; done
+  AWR_FUSED_POOL_STATS=1 python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1.txt > /dev/null 2>&1; tail -13 $OUT/per_layer_hg1.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
