@@ -1409,12 +1409,14 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
     }
     if constexpr (FUSE2) {
-        // second GEMM exactly as in conv_gemm_body<FUSE2>: the tile (all BN channels of its BM pixels) -> bias / folded BatchNorm / ReLU in registers ->
-        // LDS as the A operand of the 1x1 conv3 (w2 [N][BN + N1x], register-staged 32-float slices), N = 2 BN in two unrolled passes
-        constexpr int P2 = BN + 4, ROWB2 = LDK * 4, RB2 = BN / 32;
+        // second GEMM: the tile (all BN channels of its BM pixels) -> bias / folded BatchNorm / ReLU in registers -> LDS as the A operand of the 1x1
+        // conv3 (w2 [N][BN + N1x]), N = 2 BN in two unrolled passes.  Its weight operand travels by LDS-DMA as well (round 5): 16-float stages,
+        // double-buffered in the region the epilogue's transpose tiles use afterwards; the block input's channels of a skip conv (N1x) come from
+        // global memory one stage ahead in two register sets.
+        constexpr int P2 = BN + 4, B2STAGE = BN * 64, RB2 = BN / 64;
         float* const A2 = smem;
         char* const B2 = smem_raw + (NBUF * STAGE > F2A ? NBUF * STAGE : F2A);
-        const int r0f = tid >> 3, kcf = (tid & 7) * 4;
+        static_assert(2 * B2STAGE <= F2B, "the two w2 stages fit the transpose-tile region");
         __syncthreads();                                         // the stage buffers are dead
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1429,11 +1431,12 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                     A2[(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * P2 + col] = v;
                 }
         }
-        const int K2 = BN + a.N1x, nsl = K2 / BK, nsl_lds = BN / BK;
-        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, OOB);
+        const int K2 = BN + a.N1x, nst = K2 / 16, nst_lds = BN / 16;      // 16-float stages of the second K extent; the first nst_lds read A2
+        const i32x4 rw_w2 = make_rsrc_words(a.w2, OOB);
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.N1x ? a.in2 : a.in, a.N1x ? (unsigned)M * (unsigned)a.N1x * 4u : 0u);
         const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 * TM + l31) * P2) * 4 + 16 * half;
-        const char* b2_frag = B2 + (wn * 32 * TN + l31) * ROWB2 + 16 * half;
+        const char* b2_row = B2 + (wn * 32 * TN + l31) * 64;
+        const unsigned ldsB = lds_addr(B2) + (unsigned)wave * 1024u;
         unsigned x_off[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1442,20 +1445,44 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         }
         awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
         e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
-        float4 rb2[RB2], xa[TM][4];
-        auto load_b2 = [&](int hf, int s2) {
-            const unsigned row0 = (unsigned)(hf * BN + r0f), k0 = (unsigned)(BK * s2 + kcf);
+        float4 xa[2][TM][2];
+        auto issue2 = [&](int hf, int st, int buf) {      // stage st of output half hf: rows r0 (+ 64 per pass) of w2, source chunk kc (the stage-1 roles)
 #pragma unroll
-            for (int i = 0; i < RB2; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * (unsigned)K2 + k0) * 4u);
+            for (int i = 0; i < RB2; ++i)
+                dma16(rw_w2, ldsB + (unsigned)(buf * B2STAGE) + i * 4096u, (((unsigned)(hf * BN + r0 + 64 * i)) * (unsigned)K2 + (unsigned)(16 * st + kc)) * 4u);
         };
-        auto load_x = [&](int s2) {
-            const unsigned kb = (unsigned)(BK * (s2 - nsl_lds)) * 4u;
+        auto load_x = [&](int st, int set) {
+            const unsigned kb = (unsigned)(16 * (st - nst_lds)) * 4u;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xa[i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
+                for (int q = 0; q < 2; ++q) xa[set][i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
         };
-        load_b2(0, 0);
+        auto compute2 = [&](int st, int buf, int set) {
+            const bool from_lds = st < nst_lds;      // (wave-uniform)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const int fo = buf * B2STAGE + (((2 * sb + half) ^ fswz) << 4);
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = from_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + 16 * st + 8 * sb) : xa[set][i][sb];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_row + fo + j * 32 * 64));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+            }
+        };
+        auto landed = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_wait();
+            __syncthreads();
+        };
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -1464,31 +1491,22 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int s2 = 0; s2 < nsl; ++s2) {
-                if (s2 >= nsl_lds) load_x(s2);
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < RB2; ++i) st4(reinterpret_cast<float*>(B2 + (r0f + 32 * i) * ROWB2) + kcf, rb2[i]);
-                __syncthreads();
-                if (s2 + 1 < nsl) load_b2(hf, s2 + 1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float4 fa[TM], fb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[i] = s2 < nsl_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + BK * s2 + 8 * s) : xa[i][s];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_frag + j * 32 * ROWB2) + 8 * s);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
+            __syncthreads();             // first pass: the intermediate tile is complete; second: the first pass's transpose tiles are dead
+            issue2(hf, 0, 0);
+            landed();
+            for (int st = 0; st < nst; st += 2) {      // (K2 is a multiple of 32: an even number of stages)
+                issue2(hf, st + 1, 1);
+                if (st + 1 >= nst_lds) load_x(st + 1, 1);
+                compute2(st, 0, 0);
+                landed();
+                const bool more = st + 2 < nst;
+                if (more) {
+                    issue2(hf, st + 2, 0);
+                    if (st + 2 >= nst_lds) load_x(st + 2, 0);
                 }
+                compute2(st + 1, 1, 1);
+                if (more) landed();
             }
-            if (hf == 0) load_b2(1, 0);
             gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
         }
         return;
