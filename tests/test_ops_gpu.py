@@ -1101,3 +1101,35 @@ def test_maxpool_and_upsample_add_with_fused_statistics(L, dev, k, s, p, B, H, C
         r2 = o0.double().reshape(-1, C)
         assert float(((s_f.sum(0)[0] - r2.sum(0)).abs()).max()) < 1e-6 * float(r2.abs().sum(0).max())
         assert float(((s_f.sum(0)[1] - (r2 * r2).sum(0)).abs() / (r2 * r2).sum(0)).max()) < 1e-6
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 4, 18), ("deconv", 64, 96, 4, 2, 1, 6, 10), ("conv", 96, 64, 1, 1, 0, 2, 12)])
+def test_conv_gemm_in_batch_parts_equals_the_whole_launch(ops, L, dev, kind, cin, cout, k, stride, pad, B, H):
+    """awr_conv_gemm_part: images are independent rows of the GEMM, so the launch issued as 2 (or B) equal batch parts writes the SAME BITS as the
+    whole launch -- input, output, residual and the fused-reduction operands all advance with the part; the statistics of the parts add up."""
+    import ctypes as C
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    x = rnd(B, cin, H, H, seed=1)
+    w = rnd(*((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)), seed=2, scale=0.05)
+    prob = spec.fwd_problem(H, H)
+    xin = ops.nhwc(x).to(dev)
+    if prob["Cin"] != cin:
+        xin = torch.nn.functional.pad(xin, (0, prob["Cin"] - cin))
+    xin = xin.contiguous()
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    res = rnd(B, prob["Hout"], prob["Wout"], prob["N"], seed=3).to(dev)
+    bias = rnd(prob["N"], seed=4).to(dev)
+    outs = []
+    for nparts in (1, 2, B):
+        out = torch.full((B, prob["Hout"], prob["Wout"], prob["N"]), float("nan"), device=dev)
+        st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64)
+        a = ops.make_conv_args(prob, B, xin, wp, out, bias=bias, res=res, relu_out=True, stats=st, T=spec.T)
+        for part in range(nparts):
+            L.call("awr_conv_gemm_part", C.byref(a), nparts, part, L.stream())
+        torch.cuda.synchronize()
+        outs.append((out.clone(), st.sum(0).float()))
+    for o, s_ in outs[1:]:
+        assert torch.equal(outs[0][0], o)
+        assert rel_err(s_.cpu(), outs[0][1].cpu()) < 1e-6
+    with pytest.raises(L.AwrError):
+        L.call("awr_conv_gemm_part", C.byref(a), 3 if B % 3 else 5, 0, L.stream())      # the batch is not divisible by the part count
