@@ -1038,8 +1038,78 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // bounce rows), 2 = swapped and, for the PLAIN epilogue, stored straight from the accumulators (no LDS in the epilogue at all)
 // FUSE2 (round 5): the fused conv pair of conv_gemm_body (a.w2: conv2 3x3 -> bn3 -> ReLU -> conv3 1x1 + skip in one launch, inference) with the FIRST GEMM on
 // LDS-DMA staging -- that GEMM is 80 % of the pair's work and was the last big launch family still on the register-staged kernel.
-template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false>
+// POOL (FUSE2 only, round 5): the pair also writes the 2x2 / stride-2 max-pool of its output (awr_conv_args.pool_out).  A workgroup tile is then a 2D patch --
+// two image rows x BM / 2 columns (tile2d_pixel) -- so the two M-waves hold vertically adjacent row segments and the four pixels of every window meet in
+// the epilogue's own LDS tiles: the separate pooling pass that re-reads the full-resolution tensor (1.07 GB at 128x128 x 128 channels x batch 128)
+// disappears.
+template <int BM>
+__device__ __forceinline__ int tile2d_pixel(const awr_conv_args& a, int m) {
+    constexpr int CX = BM / 2;
+    const int t = m / BM, r = m - t * BM;
+    const int tpr = a.Wq / CX, tx = t % tpr, q = t / tpr, hy = a.Hq >> 1;
+    const int y2 = q % hy, b = q / hy;
+    return (b * a.Hq + 2 * y2 + r / CX) * a.Wq + tx * CX + (r % CX);
+}
+// epilogue of one output-channel half (hf) of the pair's second GEMM with the pool: bias2 (+ identity skip) -> full-resolution rows as usual, the final
+// values written back into the wave's transpose tile, and -- once both M-waves of a column are there -- the 2x2 windows (row pair = the two M-waves, column
+// pair = neighbouring tile rows) reduced in the SAME comparison order as maxpool_fwd_kernel (first maximum wins) and stored to pool_out.
+template <int TM, int TN>
+__device__ __forceinline__ void pair_pool_epilogue(const awr_conv_args& e, f32x16 (&acc)[TM][TN], float* smem, int M, int tile_m, int hf) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, CX = BM / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int c4 = lane & 7, rbase = lane >> 3;
+    float* const tbuf = smem + wave * (32 * LDK);
+    const unsigned obytes = (unsigned)((size_t)e.B * e.Hout * e.Wout * e.N * 4u);
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(e.out, obytes), rs_res = make_rsrc(e.res ? e.res : e.out, e.res ? obytes : 0u),
+                                 rs_pool = make_rsrc(e.pool_out, obytes / 4u);
+    // the pooled pixel this lane serves after the barrier: lanes of the two M-waves of a column = 128 = 16 pooled pixels x 8 channel quads
+    const int pl = wm * 64 + lane, ppx = pl >> 3, pc4 = pl & 7;
+    const int t = tile_m, tpr = e.Wq / CX, tx = t % tpr, q = t / tpr;      // q = b * (Hq / 2) + row pair: the pooled map's row index over the batch
+    const float* const t0 = smem + wn * (32 * LDK);                        // transpose tiles of the wm = 0 / wm = 1 waves of this column
+    const float* const t1 = smem + (2 + wn) * (32 * LDK);
+    __syncthreads();                    // every wave is done with the staged w2 slices
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n0 = hf * BN + wn * 32 * TN + j * 32 + 4 * c4;
+        const float4 bias = e.bias ? ld4(e.bias + n0) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * half) * LDK + l31] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int row = rbase + 8 * qq, m = tile_m * BM + wm * 32 * TM + i * 32 + row;
+                float4 v = ld4(tbuf + row * LDK + 4 * c4);
+                const unsigned off = m < M ? (unsigned)tile2d_pixel<BM>(e, m) * (unsigned)e.N * 4u + (unsigned)n0 * 4u : OOB;
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                if (e.res) {
+                    const float4 rr = buf_ld4(rs_res, off);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                buf_st4(rs_out, off, v);
+                st4(tbuf + row * LDK + 4 * c4, v);       // the final value, for the windows
+            }
+            __syncthreads();                              // both row segments of the column are final
+            {
+                const float4 a0 = ld4(t0 + (2 * ppx) * LDK + 4 * pc4), a1 = ld4(t0 + (2 * ppx + 1) * LDK + 4 * pc4),
+                             b0 = ld4(t1 + (2 * ppx) * LDK + 4 * pc4), b1 = ld4(t1 + (2 * ppx + 1) * LDK + 4 * pc4);
+                float4 mx = a0;                           // window order (ky, kx) = (0,0) (0,1) (1,0) (1,1); `>` keeps the first maximum
+                mx.x = a1.x > mx.x ? a1.x : mx.x; mx.y = a1.y > mx.y ? a1.y : mx.y; mx.z = a1.z > mx.z ? a1.z : mx.z; mx.w = a1.w > mx.w ? a1.w : mx.w;
+                mx.x = b0.x > mx.x ? b0.x : mx.x; mx.y = b0.y > mx.y ? b0.y : mx.y; mx.z = b0.z > mx.z ? b0.z : mx.z; mx.w = b0.w > mx.w ? b0.w : mx.w;
+                mx.x = b1.x > mx.x ? b1.x : mx.x; mx.y = b1.y > mx.y ? b1.y : mx.y; mx.z = b1.z > mx.z ? b1.z : mx.z; mx.w = b1.w > mx.w ? b1.w : mx.w;
+                const int xp = tx * (CX / 2) + i * 16 + ppx;                              // pooled column; the pooled row over the batch is q
+                const int pn0 = hf * BN + wn * 32 * TN + j * 32 + 4 * pc4;
+                const bool ok = tile_m * BM < M;
+                buf_st4(rs_pool, ok ? ((unsigned)(q * (e.Wq / 2) + xp) * (unsigned)e.N + (unsigned)pn0) * 4u : OOB, mx);
+            }
+            __syncthreads();                              // the tiles are rewritten by the next (i, j)
+        }
+    }
+}
+template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false, bool POOL = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
+    static_assert(!POOL || FUSE2, "POOL belongs to the fused pair");
     static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2 || NBUF == 4), "stage shape");
     static_assert(AFF != 4 || (KB == 16 && NBUF == 2), "the in-LDS affine pass belongs to the shipped stage shape");
     static_assert(NBUF != 4 || (KB == 16 && !ACCB && !FUSE2), "deep pipeline: 16-float stages, ordered accumulation");
@@ -1080,7 +1150,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
         const int m = tile_m * BM + r0 + RPP * i;
         if (m < M) {
             int qx, qy, b;
-            decode_row(a, m, qx, qy, b);
+            decode_row(a, POOL ? tile2d_pixel<BM>(a, m) : m, qx, qy, b);
             a_iy[i] = qy * a.si;
             a_ix[i] = qx * a.si;
             a_img[i] = (unsigned)b * a.Hin * a.Win;
@@ -1441,7 +1511,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-            x_off[i] = m < M ? ((unsigned)m * (unsigned)a.N1x + 4u * half) * 4u : OOB;
+            x_off[i] = m < M ? ((unsigned)(POOL ? tile2d_pixel<BM>(a, m) : m) * (unsigned)a.N1x + 4u * half) * 4u : OOB;
         }
         awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
         e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
@@ -1507,7 +1577,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
                 compute2(st + 1, 1, 1);
                 if (more) landed();
             }
-            gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
+            if constexpr (POOL) pair_pool_epilogue<TM, TN>(e, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
+            else gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
         }
         return;
     }
@@ -1523,9 +1594,9 @@ template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM =
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
     conv_gemm_dma_body<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, SW>(a);
 }
-template <int TM, int TN>
+template <int TM, int TN, bool POOL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_pair_kernel(const awr_conv_args a) {
-    conv_gemm_dma_body<TM, TN, 16, 2, 0, false, 1, false, false, 0, true>(a);
+    conv_gemm_dma_body<TM, TN, 16, 2, 0, false, 1, false, false, 0, true, POOL>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2850,6 +2921,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
         b.B = a->B / nchunk;
         b.in = a->in + in_img * b.B * c;
         if (a->in_split) b.in_split = static_cast<const char*>(a->in_split) + in_img * b.B * c * 6;
+        if (a->pool_out) b.pool_out = a->pool_out + out_img / 4 * b.B * c;
         b.out = a->out + out_img * b.B * c;
         if (a->res) b.res = a->res + out_img * b.B * c;
         if (a->bnr_y) b.bnr_y = a->bnr_y + out_img * b.B * c;
@@ -2920,6 +2992,7 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
     AWR_REQUIRE(!a->bnr2_y || (a->bnr_y && a->bnr2_coef && a->stats2), "conv_gemm: a second fused reduction (bnr2_y) needs bnr_y, bnr2_coef and stats2");
     AWR_REQUIRE((a->in_scale == nullptr) == (a->in_shift == nullptr), "conv_gemm: in_scale/in_shift must come together");
     AWR_REQUIRE((a->out_scale == nullptr) == (a->out_shift == nullptr), "conv_gemm: out_scale/out_shift must come together");
+    AWR_REQUIRE(!a->pool_out || a->w2, "conv_gemm: pool_out belongs to the fused pair (w2)");
     AWR_REQUIRE(!a->in2 || a->w2 || (g_products == 1 && a->nphase == 1 && a->ph[0].ntaps == 1 && a->T == 1 && a->Cin1 > 0 && a->Cin1 < a->Cin && a->Cin1 % BK == 0),
                 "conv_gemm: a second input tensor needs the FP32-MFMA mode, one tap and 0 < Cin1 < Cin, Cin1 %% 32 == 0");
     for (int p = 0; p < a->nphase; ++p) {
@@ -2939,6 +3012,15 @@ static int conv_gemm_one(const awr_conv_args* a, void* stream) {
         const dim3 grid2((unsigned)((M + (a->N1 == 64 && a->tile_m == 2 ? 127 : 63)) / (a->N1 == 64 && a->tile_m == 2 ? 128 : 64)), 1);
         // first GEMM on LDS-DMA staging (round 5) whenever its input needs no arithmetic; AWR_DMA=0 / AWR_FUSE2_DMA=0: the register-staged pair
         static const int pair_dma = env_int("AWR_FUSE2_DMA", 1);
+        if (a->pool_out) {      // the pair also writes the 2x2 max-pool of its output: 2D workgroup tiles (two image rows x BM / 2 columns)
+            const int bm = (a->N1 == 64 && a->tile_m == 2) ? 128 : 64;
+            AWR_REQUIRE(pair_dma && g_staging != 0 && !a->in_scale && !a->relu_in && a->Hq % 2 == 0 && a->Wq % (bm / 2) == 0 && a->si == 1,
+                        "conv_gemm: pool_out needs the LDS-DMA pair, a plain input, an even map height and a width that is a multiple of %d", bm / 2);
+            if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<1, 2, true>), grid2, dim3(256), 0, as_stream(stream), *a);
+            else if (a->tile_m == 2) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<2, 1, true>), grid2, dim3(256), 0, as_stream(stream), *a);
+            else hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<1, 1, true>), grid2, dim3(256), 0, as_stream(stream), *a);
+            return check_launch("conv_gemm_dma_pair_kernel<pool>");
+        }
         if (pair_dma && g_staging != 0 && !a->in_scale && !a->relu_in) {
             if (a->N1 == 128) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<1, 2>), grid2, dim3(256), 0, as_stream(stream), *a);
             else if (a->tile_m == 2) hipLaunchKernelGGL((conv_gemm_dma_pair_kernel<2, 1>), grid2, dim3(256), 0, as_stream(stream), *a);

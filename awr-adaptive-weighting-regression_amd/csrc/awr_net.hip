@@ -611,6 +611,7 @@ struct Tn {
     // gradient reads g = d(loss)/d(bn(y)) (masked) and y itself and forms d(y) = a1 g + a2 (y - mean) + a3 on the fly (awr_conv_args.in_bnb_y);
     // d(y) is still written -- by an apply launch that travels with the weight gradient on its side stream
     bool conv_out = false;
+    awr_conv_args* pair_args = nullptr;       // written by a fused inference pair (conv_pair): a 2x2 max-pool of it can ride in that launch (pool_out)
     struct FusedStats* fstats = nullptr;      // produced by a max-pool / up-sampling add that can accumulate the next BatchNorm's statistics itself
     bool half_ok = false;     // conv output whose data gradient may run as two half-batch parts (set by conv())
     bool half_dy = false;     // ... and whose BatchNorm backward writes d(y) half by half: the second half on the weight gradient's stream
@@ -984,6 +985,7 @@ struct Builder {
         a->res = res ? res->buf : nullptr;
         if (dual) { a->in2 = xin->buf; a->N1x = n1x; }
         if (n1 == 64) a->tile_m = env_or("AWR_FUSE2_TM64", 2), a->tile_n = 1;      // 128x64 tile (what the tuner picks for this conv on its own)
+        y->pair_args = a;
         const std::string tail = dual ? "conv3+skip_layer" : c3->name.substr(c3->name.rfind('.', c3->name.rfind('.') - 1) + 1);
         const std::string name = "awr_conv_gemm:" + c2->name + "+" + tail;
         Op& op = f(name, [a](void* s) { return awr_conv_gemm(a, s); });
@@ -1398,10 +1400,19 @@ struct Builder {
                 fs = &P.fstats.back();
                 y->fstats = fs;
             }
-            f("awr_maxpool_fwd", [=](void* s) {
-                return fs && fs->sp ? awr_maxpool_fwd_stats(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, fs->sp, fs->ns, s)
-                                    : awr_maxpool_fwd(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, s);
-            });
+            // inference: a 2x2 / stride-2 pool of a fused pair's output is written by the pair itself (awr_conv_args.pool_out: 2D workgroup tiles, the
+            // windows reduced in the epilogue) -- no pass that re-reads the full-resolution tensor.  AWR_PAIR_POOL=0: the separate pass (A/B hook)
+            awr_conv_args* pa = x->pair_args;
+            const int pbm = pa && pa->N1 == 64 && pa->tile_m == 2 ? 128 : 64;
+            if (!P.training && pa && !pa->pool_out && k == 2 && s_ == 2 && p == 0 && !x->lazy && H % 2 == 0 && W % (pbm / 2) == 0 && env_or("AWR_PAIR_POOL", 1) &&
+                awr_get_gemm_staging() != 0 && env_or("AWR_FUSE2_DMA", 1) && !pa->in_scale && !pa->relu_in) {
+                pa->pool_out = ob;
+            } else {
+                f("awr_maxpool_fwd", [=](void* s) {
+                    return fs && fs->sp ? awr_maxpool_fwd_stats(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, fs->sp, fs->ns, s)
+                                        : awr_maxpool_fwd(xb, ls, lt, lr, B, H, W, C, k, s_, p, ob, arg, s);
+                });
+            }
         }
         if (P.training) {
             P.nodes.push_back([=]() {

@@ -243,6 +243,9 @@ typedef struct awr_conv_args {
     const void* in_split;   /* optional (split-operand mode): the PRE-CUT image of `in` -- [pixel][Cin / 32][h | m | l][32] bf16, 6 bytes per element, written */
                             /* by awr_split_act (or a producer's epilogue): both operands then travel global -> LDS by DMA and the K loop holds no cutting */
                             /* arithmetic.  Excludes in_scale / relu_in (the producer applies them before it cuts), in2, in_bnb_y, split-K */
+    float* pool_out;        /* optional, fused pair only (w2): also write MaxPool2d(2, 2) of the pair's output, (B, Hout / 2, Wout / 2, N) -- the workgroup */
+                            /* tiles become 2D patches (two image rows x 32 / 64 columns) so that every window meets in the epilogue; needs an even map */
+                            /* height and a width that is a multiple of the patch width.  model/hourglass.py:65-70: every level's input feeds up1 AND a pool */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).

@@ -954,10 +954,12 @@ def test_inference_fused_conv_pairs(amd, dev, golden_dir, net, monkeypatch):
     J, ks = int(g["J"]), float(g["ks"])
     man = O.manifest_for(net, J)
     outs = {}
-    for fused in (True, False):
+    npool = {}
+    for fused in (True, "separate_pool", False):
         if fused:
             monkeypatch.setenv("AWR_FUSE2_MIN_WGS", "1")
             monkeypatch.delenv("AWR_NO_FUSE2", raising=False)
+            monkeypatch.setenv("AWR_PAIR_POOL", "0" if fused == "separate_pool" else "1")
         else:
             monkeypatch.setenv("AWR_NO_FUSE2", "1")
         m = make_net(amd, net, J, O.procedural_state(man, seed=0))
@@ -965,9 +967,15 @@ def test_inference_fused_conv_pairs(amd, dev, golden_dir, net, monkeypatch):
         inf = InferEngine(m, img.shape[0], 128, ks, autotune=False)
         names = inf.plan.op_names("fwd")
         npair = sum(1 for n in names if "+conv3" in n)
+        npool[fused] = sum(1 for n in names if n == "awr_maxpool_fwd")
         assert (npair >= 12 and sum(1 for n in names if "+conv3+skip_layer" in n) >= 2) if fused else (npair == 0), names
         jt = inf(img.to(dev)).cpu()
         outs[fused] = (jt, inf.plan.dense_map(m.nstage - 1).cpu())
+    # round 5: the 2x2 max-pool of a pair's output rides in the pair's launch where the map is wide enough for the 2D workgroup tiles (pool_out):
+    # fewer pooling passes, and -- every pixel accumulates in the same k order whichever tile holds it, the windows compare in maxpool_fwd's
+    # order -- the SAME BITS as the plan with the separate passes
+    assert npool[True] < npool["separate_pool"] == npool[False], npool
+    assert torch.equal(outs[True][0], outs["separate_pool"][0]) and torch.equal(outs[True][1], outs["separate_pool"][1])
     oracle = O.backbone_forward(net, O.procedural_state(man, seed=0), img, training=False)
     gaps = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=0), img, ks, False)
     s = len(oracle) - 1

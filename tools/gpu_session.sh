@@ -139,6 +139,14 @@ poolstats) # round 5: max-pool / up-sampling add that accumulate the next BatchN
   for i in 1 2; do for v in 0 1; do AWR_FUSED_POOL_STATS=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 pool_stats=$v |" | tee -a $OUT/bench_ab.txt; done; done
   AWR_FUSED_POOL_STATS=1 python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1.txt > /dev/null 2>&1; tail -13 $OUT/per_layer_hg1.txt
   ;;
+pairpool) # round 5: the 2x2 max-pool of a fused pair's output written by the pair itself (AWR_PAIR_POOL = 0 | 1)
+  timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_nets_gpu.py tests/test_full_size_gpu.py tests/test_abi.py -m gpu -q --tb=short -k "pair or fused_conv or config3 or config_3 or abi" 2>&1 | tail -6 | tee $OUT/tests.log
+  for i in 1 2 3; do for v in 0 1; do
+    AWR_PAIR_POOL=$v line "hg1 infer b128 pair_pool=$v" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  AWR_PAIR_POOL=1 python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 --per-layer $OUT/per_layer_hg1_infer_b128.txt > /dev/null 2>&1
+  head -14 $OUT/per_layer_hg1_infer_b128.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
