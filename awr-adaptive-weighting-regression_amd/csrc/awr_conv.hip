@@ -2814,7 +2814,11 @@ static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, i
         int minsteps = 1 << 30;
         for (int p = 0; p < a->nphase; ++p) minsteps = a->ph[p].ntaps * (a->Cin / 16) < minsteps ? a->ph[p].ntaps * (a->Cin / 16) : minsteps;
         static const int deep_wgs = env_int("AWR_DEEP_MAX_WGS", 384);
-        if (deep_on && aff != 2 && a->accum == 0 && (int64_t)grid.x * grid.y <= deep_wgs && minsteps >= 8) {
+        // AWR_DEEP_1X1 (study hook, results unchanged): single-tap launches of ANY size take the deep form -- a 1x1 conv at 64x64 x 64 images streams
+        // its whole A operand from HBM once (2-3.5 TB/s needed at MFMA speed) with one 4 KB stage per resident workgroup in flight
+        bool single_tap = env_int("AWR_DEEP_1X1", 0) != 0;
+        for (int p = 0; p < a->nphase && single_tap; ++p) single_tap = a->ph[p].ntaps == 1;
+        if (deep_on && aff != 2 && a->accum == 0 && ((int64_t)grid.x * grid.y <= deep_wgs || single_tap) && minsteps >= 8) {
             if (aff == 3) launch_dma_em<TM, TN, 16, 4, 3>(a, grid, st, epre, em);
             else if (aff == 1) launch_dma_em<TM, TN, 16, 4, 1>(a, grid, st, epre, em);
             else launch_dma_em<TM, TN, 16, 4, 0>(a, grid, st, epre, em);

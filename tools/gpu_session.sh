@@ -147,6 +147,17 @@ pairpool) # round 5: the 2x2 max-pool of a fused pair's output written by the pa
   AWR_PAIR_POOL=1 python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 --per-layer $OUT/per_layer_hg1_infer_b128.txt > /dev/null 2>&1
   head -14 $OUT/per_layer_hg1_infer_b128.txt
   ;;
+deep1x1)  # round 5, second session: the deep pipeline for single-tap (1x1) launches of ANY size (AWR_DEEP_1X1 = 0 | 1) -- bytes in flight per CU against HBM latency
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward" 2>&1 | tail -3 | tee $OUT/ops.log
+  for e in 0 1; do AWR_DEEP_1X1=$e timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | grep "1x1\|batch" | tee $OUT/fwdset_deep1x1_$e.txt; done
+  for i in 1 2 3; do for e in 0 1; do
+    AWR_DEEP_1X1=$e line "hg1 b64 deep1x1=$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_1X1=$e line "r18 b64 deep1x1=$e" | tee -a $OUT/bench_ab.txt
+    AWR_DEEP_1X1=$e line "hg1 infer b128 deep1x1=$e" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  for e in 0 1; do AWR_DEEP_1X1=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 deep1x1=$e |" | tee -a $OUT/bench_ab.txt; done
+  for e in 0 1; do AWR_DEEP_1X1=$e python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1_deep1x1_$e.txt > /dev/null 2>&1; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
