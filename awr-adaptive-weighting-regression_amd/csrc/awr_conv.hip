@@ -87,6 +87,10 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // four consecutive k of one LDS row: three 8-byte stores (h, m, l planes)
+#ifndef AWR_DMA_PROBE
+#define AWR_DMA_PROBE 0  // memory-system probes of the LDS-DMA GEMM (study builds, tools/gpu_session.sh probe1x1; results are WRONG, timing only): every instruction
+#endif                   // still issues, the memory system sees less -- bit 0: A-operand requests beyond the first stage go nowhere (zeros), bit 1: the same for
+                         // the weight operand, bit 2: the epilogue's output stores are dropped (out-of-range offsets), bit 3: its operand loads as well
 #ifndef AWR_PROBE
 #define AWR_PROBE 0      // bottleneck probes of the FP32 K loop (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores /
 #endif                   // 2nd barrier, 3 = both, 4 = both + no LDS fragment reads (MFMA only); 6 = split-mode weight-gradient staging without
@@ -172,12 +176,15 @@ __device__ __forceinline__ void decode_row(const awr_conv_args& a, int m, int& q
         b = t / a.Hq;
     }
 }
+#ifndef AWR_ST_AUX
+#define AWR_ST_AUX 0     // cache policy of the GEMM epilogues' output stores (study builds: 2 = nt, non-temporal -- tools/gpu_session.sh ntstore)
+#endif
 struct epi_rows { float4 v[4]; };
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 u;
     __builtin_memcpy(&u, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 0);      // buffer_store_dwordx4 ... offen: an out-of-range offset is dropped
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, AWR_ST_AUX);      // buffer_store_dwordx4 ... offen: an out-of-range offset is dropped
 }
 // Byte offset of (row m of the GEMM, column 0) in the output tensor, OOB for rows beyond M.  Everything the epilogue reads or writes sits at
 // that offset + 4 n in tensors of the output's shape (< 4 GB): one 32-bit add per access instead of a 64-bit multiply-add, no branch
@@ -296,9 +303,10 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 float4 v = ld4(tbuf + row * LDK + 4 * c4);
                 const bool valid = nok && orow[i][q] != OOB;
                 const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
+                const unsigned off_ld = ((AWR_DMA_PROBE & 8) && a.B > 0) ? OOB : off, off_st = ((AWR_DMA_PROBE & 4) && a.B > 0) ? OOB : off;      // (probe builds)
                 if constexpr (OAFF) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                 if (res_on) {
-                    const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off);
+                    const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off_ld);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (shifted && i == 0 && q == 0) {      // (wave-uniform) the shift: row 0 of the wave's tile, held by lanes 0..7
@@ -307,9 +315,9 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 }
                 if (bnr_on) {
                     // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
-                    const float4 yy = EPRE ? pre->v[q] : buf_ld4(rs_y, off);
+                    const float4 yy = EPRE ? pre->v[q] : buf_ld4(rs_y, off_ld);
                     if (act_on) {      // the activation had a residual added before the ReLU: mask from the stored tensor
-                        const float4 aa = buf_ld4(rs_act, off);
+                        const float4 aa = buf_ld4(rs_act, off_ld);
                         v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
                     } else {
                         v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
@@ -320,7 +328,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                     s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
                     if (bnr2_on) {
-                        const float4 y2 = buf_ld4(rs_y2, off);
+                        const float4 y2 = buf_ld4(rs_y2, off_ld);
                         s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
                         s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
                     }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     cnt += valid ? 1 : 0;
                 }
                 if (a.relu_out) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                buf_st4(rs_out, off, v);
+                buf_st4(rs_out, off_st, v);
             }
             __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
             if constexpr (EPRE) {                  // the next tile's rows, in flight across its LDS bounce
@@ -1285,10 +1293,13 @@ __device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
     };
     // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
     // (`live` = false: a stage beyond the K extent, requested by the last trip of the pipelined loop -- every source out of range, zeros)
+    [[maybe_unused]] int probe_reqs = 0;
     auto issue = [&](int c0, int buf, bool live = true) {
         const unsigned cb = (unsigned)c0 * 4u;
         const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(AROWS * ROWB);
-        const unsigned tm_ = live ? tapmask : 0u;
+        const bool first_req = (AWR_DMA_PROBE & 3) ? (a.B < 0 || probe_reqs++ == 0) : true;      // (probe builds: only the first stage's requests reach memory)
+        const unsigned tm_ = (live && ((AWR_DMA_PROBE & 1) == 0 || first_req)) ? tapmask : 0u;
+        if ((AWR_DMA_PROBE & 2) && !first_req) live = false;
         if (DUAL && c0 >= cin1) {        // (wave-uniform) this stage comes from the second tensor
             const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
 #pragma unroll

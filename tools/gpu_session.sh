@@ -158,6 +158,13 @@ deep1x1)  # round 5, second session: the deep pipeline for single-tap (1x1) laun
   for e in 0 1; do AWR_DEEP_1X1=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 deep1x1=$e |" | tee -a $OUT/bench_ab.txt; done
   for e in 0 1; do AWR_DEEP_1X1=$e python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1_deep1x1_$e.txt > /dev/null 2>&1; done
   ;;
+probe1x1) # round 5, second session: memory-system probes of the LDS-DMA GEMM on the 1x1 shapes (study builds variants/libawr_probe<v>.so, -DAWR_DMA_PROBE=v:
+          # bit 0 = A-operand requests beyond the first stage go nowhere, bit 1 = the same for the weights, bit 2 = the epilogue's stores are dropped; results WRONG, timing only)
+  for v in 0 1 2 3 4 7; do
+    echo "== AWR_DMA_PROBE=$v"
+    AWR_LIB_PATH=$GRAFT_REPO_ROOT/variants/libawr_probe$v.so timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | grep "1x1\|hg 3x3\|layer1"
+  done | tee $OUT/probe1x1.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
