@@ -51,7 +51,7 @@ class ConvArgs(C.Structure):
                 ("ph", Phase * 4), ("w_split", C.c_void_p), ("stat_slots", C.c_int), ("stat_slot_base", C.c_int), ("in2", C.c_void_p), ("Cin1", C.c_int),
                 ("partial", C.c_void_p), ("split_k", C.c_int), ("split_max", C.c_int), ("bnr_act", C.c_void_p),
                 ("bnr2_y", C.c_void_p), ("bnr2_coef", C.c_void_p), ("stats2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p),
-                ("N1", C.c_int), ("N1x", C.c_int), ("in_bnb_y", C.c_void_p), ("in_bnb_coef", C.c_void_p), ("accum", C.c_int), ("in_split", C.c_void_p), ("pool_out", C.c_void_p)]
+                ("N1", C.c_int), ("N1x", C.c_int), ("in_bnb_y", C.c_void_p), ("in_bnb_coef", C.c_void_p), ("accum", C.c_int), ("in_split", C.c_void_p), ("pool_out", C.c_void_p), ("out_nt", C.c_int)]
 
 
 class PackJob(C.Structure):

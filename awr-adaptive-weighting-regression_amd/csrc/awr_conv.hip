@@ -54,6 +54,15 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     __builtin_memcpy(&f, &v, 16);
     return f;
 }
+#ifndef AWR_EPI_LD_AUX
+#define AWR_EPI_LD_AUX 0     // cache policy of the epilogues' operand loads (residual / y / stored activation: read once) -- study builds: 2 = nt
+#endif
+__device__ __forceinline__ float4 buf_ld4_epi(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AWR_EPI_LD_AUX);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
 constexpr unsigned OOB = 0xFFFFFFFFu;
 
 // max(x, 0) as ONE v_med3_f32 (median of x, 0, +inf; a NaN gives 0 like fmaxf): fmaxf costs a canonicalising v_max in front of the
@@ -186,6 +195,19 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_
     __builtin_memcpy(&u, &v, 16);
     __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, AWR_ST_AUX);      // buffer_store_dwordx4 ... offen: an out-of-range offset is dropped
 }
+// streaming (non-temporal) forms: `buffer_store_dwordx4 ... nt` / `buffer_load_dwordx4 ... nt` -- awr_conv_args.out_nt
+__device__ __forceinline__ void buf_st4_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 u;
+    __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 2);
+}
+__device__ __forceinline__ float4 buf_ld4_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 2);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
 // Byte offset of (row m of the GEMM, column 0) in the output tensor, OOB for rows beyond M.  Everything the epilogue reads or writes sits at
 // that offset + 4 n in tensors of the output's shape (< 4 GB): one 32-bit add per access instead of a 64-bit multiply-add, no branch
 // around ragged rows -- the epilogue's integer arithmetic was ~1 100 VALU instructions per wave (profiles/r03_pmc_1x1.txt), a third of a
@@ -216,7 +238,10 @@ __device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const unsigned
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));      // < 4 GB (checked at launch)
     const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) R.v[q] = buf_ld4(rs, (n0 < a.N && orow[i][q] != OOB) ? orow[i][q] + (unsigned)n0 * 4u : OOB);
+    for (int q = 0; q < 4; ++q) {
+        const unsigned off = (n0 < a.N && orow[i][q] != OOB) ? orow[i][q] + (unsigned)n0 * 4u : OOB;
+        R.v[q] = a.out_nt == 2 ? buf_ld4_nt(rs, off) : buf_ld4_epi(rs, off);
+    }
 }
 
 // EM (compile-time epilogue variant; run-time-uniform feature flags make the compiler keep every path's registers alive): 0 = every feature
@@ -239,6 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
     const bool res_on = EM != 3 && a.res != nullptr;
     float* tbuf = smem + wave * (32 * LDK);
     const int c4 = lane & 7, rbase = lane >> 3;
+    const bool nt = a.out_nt == 2;      // (uniform) streaming stores / operand loads: the launcher resolved the automatic policy
     unsigned orow[TM][4];
     if (orow_in) {
 #pragma unroll
@@ -306,7 +332,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 const unsigned off_ld = ((AWR_DMA_PROBE & 8) && a.B > 0) ? OOB : off, off_st = ((AWR_DMA_PROBE & 4) && a.B > 0) ? OOB : off;      // (probe builds)
                 if constexpr (OAFF) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
                 if (res_on) {
-                    const float4 rr = EPRE ? pre->v[q] : buf_ld4(rs_res, off_ld);
+                    const float4 rr = EPRE ? pre->v[q] : (nt ? buf_ld4_nt(rs_res, off_ld) : buf_ld4_epi(rs_res, off_ld));
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (shifted && i == 0 && q == 0) {      // (wave-uniform) the shift: row 0 of the wave's tile, held by lanes 0..7
@@ -315,9 +341,9 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                 }
                 if (bnr_on) {
                     // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
-                    const float4 yy = EPRE ? pre->v[q] : buf_ld4(rs_y, off_ld);
+                    const float4 yy = EPRE ? pre->v[q] : (nt ? buf_ld4_nt(rs_y, off_ld) : buf_ld4_epi(rs_y, off_ld));
                     if (act_on) {      // the activation had a residual added before the ReLU: mask from the stored tensor
-                        const float4 aa = buf_ld4(rs_act, off_ld);
+                        const float4 aa = (nt ? buf_ld4_nt(rs_act, off_ld) : buf_ld4_epi(rs_act, off_ld));
                         v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
                     } else {
                         v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
@@ -328,7 +354,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
                     s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
                     if (bnr2_on) {
-                        const float4 y2 = buf_ld4(rs_y2, off_ld);
+                        const float4 y2 = (nt ? buf_ld4_nt(rs_y2, off_ld) : buf_ld4_epi(rs_y2, off_ld));
                         s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
                         s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
                     }
@@ -340,7 +366,7 @@ __device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_
                     cnt += valid ? 1 : 0;
                 }
                 if (a.relu_out) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                buf_st4(rs_out, off_st, v);
+                if (nt) buf_st4_nt(rs_out, off_st, v); else buf_st4(rs_out, off_st, v);
             }
             __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
             if constexpr (EPRE) {                  // the next tile's rows, in flight across its LDS bounce
@@ -2983,7 +3009,20 @@ int awr_conv_gemm_part(const awr_conv_args* a, int nparts, int part, void* strea
     return awr_conv_gemm(&b, stream);
 }
 
-static int conv_gemm_one(const awr_conv_args* a, void* stream) {
+static int conv_gemm_one(const awr_conv_args* a_in, void* stream) {
+    // output-store policy (awr_conv_args.out_nt): 0 = automatic -> streaming (`buffer_store ... nt`, the epilogue's operand loads too) when the output tensor is
+    // at least as large as the 256 MB Infinity Cache -- its consumer fetches it from HBM either way -- and the K extent is short (<= 512: the launches whose
+    // 32 KB tile per workgroup follows 4 ... 32 stages of operand traffic; isolated 1x1 launches +5-12 %, long-K launches unmoved).  Measured per step
+    // (profiles/r05_nt_policy.txt): config 5 288 -> 283 ms, ResNet18 batch 256 and config 3 -0.3 %, batch-64 steps within noise; with EVERY store streaming
+    // ResNet18 loses 0.5 % (its 67-134 MB activations otherwise reach their consumer from the cache).  AWR_NT_MIN_MB (0 = never) / AWR_NT_MAX_K: the A/B knobs
+    awr_conv_args a_res = *a_in;
+    const awr_conv_args* a = &a_res;
+    AWR_REQUIRE(a_in->out_nt >= 0 && a_in->out_nt <= 2, "conv_gemm: out_nt=%d", a_in->out_nt);
+    if (a_res.out_nt == 0) {
+        static const int64_t min_mb = env_int("AWR_NT_MIN_MB", 256), max_k = env_int("AWR_NT_MAX_K", 512);
+        const int64_t obytes = (int64_t)a_res.B * a_res.Hout * a_res.Wout * a_res.N * 4, kext = (int64_t)a_res.Cin * a_res.ph[0].ntaps;
+        a_res.out_nt = (min_mb > 0 && obytes >= (min_mb << 20) && kext <= max_k) ? 2 : 1;
+    }
     AWR_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "conv_gemm: Cin=%d must be a positive multiple of %d", a->Cin, BK);
     AWR_REQUIRE(a->accum == 0 || a->accum == 1, "conv_gemm: accum=%d", a->accum);
     AWR_REQUIRE(!a->in_bnb_y || (a->in_bnb_coef && !a->in_scale && !a->relu_in && !a->in2 && !a->w2 && g_products == 1 && g_staging != 0 &&

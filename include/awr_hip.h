@@ -246,6 +246,9 @@ typedef struct awr_conv_args {
     float* pool_out;        /* optional, fused pair only (w2): also write MaxPool2d(2, 2) of the pair's output, (B, Hout / 2, Wout / 2, N) -- the workgroup */
                             /* tiles become 2D patches (two image rows x 32 / 64 columns) so that every window meets in the epilogue; needs an even map */
                             /* height and a width that is a multiple of the patch width.  model/hourglass.py:65-70: every level's input feeds up1 AND a pool */
+    int out_nt;             /* cache policy of the output stores and of the epilogue's operand loads (res / bnr_y / bnr_act): 0 = automatic, 1 = cached, */
+                            /* 2 = streaming (`buffer_store ... nt`: a short-K launch's 32 KB tile per workgroup does not evict the operand lines the K loops */
+                            /* of its neighbours still want -- DESIGN.md 4.2) */
 } awr_conv_args;
 
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).

@@ -70,7 +70,7 @@ def test_struct_layout_matches_header(lib):
     import ctypes as C
     # awr_phase: 3 ints + 16 packed taps = 76 bytes; awr_conv_args: 12 pointers + 17 ints + 4 phases + pad + w_split
     assert C.sizeof(lib.Phase) == 76
-    assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 8 + 3 * 8 + 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8   # padding before w_split; stat_slots, stat_slot_base; in2; Cin1 + padding; partial; split_k, split_max; bnr_act; bnr2_y, bnr2_coef, stats2; w2, bias2; N1, N1x; in_bnb_y, in_bnb_coef; accum + padding; in_split; pool_out
+    assert C.sizeof(lib.ConvArgs) == 12 * 8 + 17 * 4 + 4 * 76 + 4 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 8 + 3 * 8 + 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 8   # padding before w_split; stat_slots, stat_slot_base; in2; Cin1 + padding; partial; split_k, split_max; bnr_act; bnr2_y, bnr2_coef, stats2; w2, bias2; N1, N1x; in_bnb_y, in_bnb_coef; accum + padding; in_split; pool_out; out_nt + padding
     assert lib.ConvArgs.w_split.offset == 472 and lib.ConvArgs.stat_slots.offset == 480
     assert C.sizeof(lib.PackJob) == 3 * 8 + 6 * 4 + 8 + 2 * 4 and C.sizeof(lib.UnpackJob) == 2 * 8 + 4 * 4 + 8 + 2 * 4
     assert C.sizeof(lib.WgradArgs) == 8 * 8 + 16 * 4 + 32 + 8 + 8 and lib.WgradArgs.dy.offset == 8 * 8 + 16 * 4 and lib.WgradArgs.split_stride.offset == 160

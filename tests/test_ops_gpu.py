@@ -1133,3 +1133,36 @@ def test_conv_gemm_in_batch_parts_equals_the_whole_launch(ops, L, dev, kind, cin
         assert rel_err(s_.cpu(), outs[0][1].cpu()) < 1e-6
     with pytest.raises(L.AwrError):
         L.call("awr_conv_gemm_part", C.byref(a), 3 if B % 3 else 5, 0, L.stream())      # the batch is not divisible by the part count
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,B,H", [("conv", 64, 96, 3, 1, 1, 4, 18), ("deconv", 64, 96, 4, 2, 1, 6, 10), ("conv", 96, 64, 1, 1, 0, 2, 12),
+                                                             ("conv", 128, 256, 1, 1, 0, 3, 16)])
+def test_streaming_output_stores_write_the_same_bits(ops, L, dev, kind, cin, cout, k, stride, pad, B, H):
+    """awr_conv_args.out_nt: 1 = cached, 2 = streaming (`buffer_store ... nt`, the epilogue's residual loads `nt` too), 0 = the library's size / K-extent rule.
+    A cache policy: every form writes the SAME BITS and the same statistics, with the residual + ReLU + statistics epilogue and on the short-K
+    operand-prefetch form (the two 1x1 shapes); an unknown policy is refused."""
+    import ctypes as C
+    spec = ops.ConvSpec(kind, cin, cout, k, stride, pad)
+    x = rnd(B, cin, H, H, seed=1)
+    w = rnd(*((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)), seed=2, scale=0.05)
+    prob = spec.fwd_problem(H, H)
+    xin = ops.nhwc(x).to(dev).contiguous()
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    res = rnd(B, prob["Hout"], prob["Wout"], prob["N"], seed=3).to(dev)
+    bias = rnd(prob["N"], seed=4).to(dev)
+    outs = []
+    for policy in (1, 2, 0):
+        out = torch.full((B, prob["Hout"], prob["Wout"], prob["N"]), float("nan"), device=dev)
+        st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64)
+        a = ops.make_conv_args(prob, B, xin, wp, out, bias=bias, res=res, relu_out=True, stats=st, T=spec.T)
+        a.out_nt = policy
+        L.call("awr_conv_gemm", C.byref(a), L.stream())
+        torch.cuda.synchronize()
+        outs.append((out.clone(), st.sum(0).float()))
+    assert not torch.isnan(outs[0][0]).any()
+    for o, s_ in outs[1:]:
+        assert torch.equal(outs[0][0], o)
+        assert rel_err(s_.cpu(), outs[0][1].cpu()) < 1e-6
+    a.out_nt = 3
+    with pytest.raises(L.AwrError):
+        L.call("awr_conv_gemm", C.byref(a), L.stream())

@@ -165,6 +165,35 @@ probe1x1) # round 5, second session: memory-system probes of the LDS-DMA GEMM on
     AWR_LIB_PATH=$GRAFT_REPO_ROOT/variants/libawr_probe$v.so timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | grep "1x1\|hg 3x3\|layer1"
   done | tee $OUT/probe1x1.txt
   ;;
+ntstore)  # round 5, second session: cache policy of the GEMM epilogues' output stores / operand loads (study builds variants/libawr_<v>.so: st2 = stores nt,
+          # st3 = stores sc0 nt, st2ld2 = stores nt + epilogue operand loads nt) against the shipped library
+  for v in shipped st2 st3 st2ld2; do
+    echo "== $v"
+    L=""; [ $v != shipped ] && L=$GRAFT_REPO_ROOT/variants/libawr_$v.so
+    AWR_LIB_PATH=$L timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | grep "1x1\|hg 3x3\|layer1\|layer3\|deconv 256->256 @32"
+  done | tee $OUT/fwdset.txt
+  for i in 1 2 3; do for v in shipped st2 st3 st2ld2; do
+    L=""; [ $v != shipped ] && L=$GRAFT_REPO_ROOT/variants/libawr_$v.so
+    AWR_LIB_PATH=$L line "r18 b64 $v" | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "hg1 b64 $v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "hg1 infer b128 $v" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
+ntpolicy) # round 5, second session: streaming output stores by size / K extent (awr_conv_args.out_nt = 0 -> AWR_NT_MIN_MB, AWR_NT_MAX_K; 0 MB = never)
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward or prologue or dgrad_with" 2>&1 | tail -3 | tee $OUT/ops.log
+  for i in 1 2; do for cfg in "0 0" "64 100000" "128 100000" "256 100000" "128 512" "256 512" "500 100000"; do
+    set -- $cfg
+    export AWR_NT_MIN_MB=$1 AWR_NT_MAX_K=$2
+    line "r18 b64 nt_min_mb=$1 max_k=$2" | tee -a $OUT/bench_ab.txt
+    line "hg1 b64 nt_min_mb=$1 max_k=$2" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    line "hg1 infer b128 nt_min_mb=$1 max_k=$2" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+    line "r18 b256 nt_min_mb=$1 max_k=$2" --batch 256 --steps 8 | tee -a $OUT/bench_ab.txt
+  done; done
+  for cfg in "0 0" "128 100000" "256 512" "500 100000" "0 0" "128 100000"; do
+    set -- $cfg
+    AWR_NT_MIN_MB=$1 AWR_NT_MAX_K=$2 python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 nt_min_mb=$1 max_k=$2 |" | tee -a $OUT/bench_ab.txt
+  done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
