@@ -194,6 +194,15 @@ ntpolicy) # round 5, second session: streaming output stores by size / K extent 
     AWR_NT_MIN_MB=$1 AWR_NT_MAX_K=$2 python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 nt_min_mb=$1 max_k=$2 |" | tee -a $OUT/bench_ab.txt
   done
   ;;
+ntfinal)  # streaming-store rule as shipped (default) against off (AWR_NT_MIN_MB=0): the large-tensor shapes, three interleaved repetitions
+  timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "streaming or batch_parts or bit_identical" 2>&1 | tail -3 | tee $OUT/ops.log
+  for i in 1 2 3; do for v in 0 256; do
+    AWR_NT_MIN_MB=$v python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 nt_min_mb=$v |" | tee -a $OUT/bench_ab.txt
+    AWR_NT_MIN_MB=$v line "r18 b256 nt_min_mb=$v" --batch 256 --steps 8 | tee -a $OUT/bench_ab.txt
+    AWR_NT_MIN_MB=$v line "r18 b64 nt_min_mb=$v" | tee -a $OUT/bench_ab.txt
+    AWR_NT_MIN_MB=$v line "hg1 b64 nt_min_mb=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
