@@ -1166,3 +1166,41 @@ def test_streaming_output_stores_write_the_same_bits(ops, L, dev, kind, cin, cou
     a.out_nt = 3
     with pytest.raises(L.AwrError):
         L.call("awr_conv_gemm", C.byref(a), L.stream())
+
+
+@pytest.mark.parametrize("tile", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_statistics_from_the_accumulators_match_the_row_layout_form(ops, L, dev, tile):
+    """EM 5 (round 5): a statistics launch whose stored value is accumulator + bias on tiles wholly inside M sums x - c and (x - c)^2 in the ACCUMULATOR
+    layout (a lane owns one channel, its registers 16 rows) instead of behind the LDS bounce.  Same output bits; sum and sum of squares agree with the
+    row-layout form (AWR_FAST_STATS=0) and with float64 sums of the stored tensor -- on a ragged N (96 of a 128-column tile), with a bias that puts the
+    mean 100 standard deviations from zero (the shift is what keeps the variance)."""
+    import ctypes as C
+    B, H, cin, cout = 2, 16, 64, 96            # M = 512: a multiple of both tile heights
+    spec = ops.ConvSpec("conv", cin, cout, 3, 1, 1)
+    x, w = rnd(B, cin, H, H, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    bias = (rnd(cout, seed=3) + 100.0).to(dev)
+    prob = spec.fwd_problem(H, H)
+    xin = ops.nhwc(x).to(dev).contiguous()
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    got = {}
+    L.call("awr_debug_force_tile", *tile)
+    try:
+        for fast in ("0", "1"):
+            os.environ["AWR_FAST_STATS"] = fast
+            out = torch.full((B, H, H, prob["N"]), float("nan"), device=dev)
+            st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64)
+            a = ops.make_conv_args(prob, B, xin, wp, out, bias=bias, stats=st, T=spec.T)
+            L.call("awr_conv_gemm", C.byref(a), L.stream())
+            torch.cuda.synchronize()
+            got[fast] = (out.clone(), st.sum(0).clone())
+    finally:
+        os.environ.pop("AWR_FAST_STATS", None)
+        L.call("awr_debug_force_tile", 0, 0)
+    assert torch.equal(got["0"][0], got["1"][0])
+    ref = got["1"][0].double().reshape(-1, prob["N"])
+    n = ref.shape[0]
+    for k in ("0", "1"):
+        s1, s2 = got[k][1][0], got[k][1][1]
+        assert float((s1 - ref.sum(0)).abs().max()) < 1e-7 * float(ref.abs().sum(0).max())
+        var, var_ref = s2 / n - (s1 / n) ** 2, ref.var(0, unbiased=False)
+        assert float(((var - var_ref).abs() / var_ref).max()) < 1e-4      # mean ~ 100, std ~ 1: the shifted sums keep five digits of the variance

@@ -203,6 +203,32 @@ ntfinal)  # streaming-store rule as shipped (default) against off (AWR_NT_MIN_MB
     AWR_NT_MIN_MB=$v line "hg1 b64 nt_min_mb=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
   done; done
   ;;
+faststats) # round 5, second session: BatchNorm statistics taken from the accumulators (EM 5, AWR_FAST_STATS = 0 | 1)
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "statistics or bit_identical or every_tile or conv_forward or prologue or streaming" 2>&1 | tail -3 | tee $OUT/ops.log
+  for e in 0 1; do AWR_FAST_STATS=$e timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | tee $OUT/fwdset_faststats$e.txt; done
+  for i in 1 2 3; do for e in 0 1; do
+    AWR_FAST_STATS=$e line "r18 b64 fast_stats=$e" | tee -a $OUT/bench_ab.txt
+    AWR_FAST_STATS=$e line "hg1 b64 fast_stats=$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_FAST_STATS=$e line "r18 b256 fast_stats=$e" --batch 256 --steps 8 | tee -a $OUT/bench_ab.txt
+  done; done
+  for e in 0 1 0 1; do AWR_FAST_STATS=$e python tools/check_hg2_256.py 128 2>&1 | tail -1 | sed "s|^|config5 fast_stats=$e |" | tee -a $OUT/bench_ab.txt; done
+  timeout 1200 python -m pytest tests/test_nets_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -3 | tee $OUT/nets.log
+  ;;
+faststats2) # EM 5 second form (sums of the STORED value): golden / full-size suites under both settings, low-batch steps
+  for e in 1 0; do echo "== AWR_FAST_STATS=$e"; AWR_FAST_STATS=$e timeout 900 python -m pytest tests/test_nets_gpu.py tests/test_full_size_gpu.py -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -8; done | tee $OUT/suites.log
+  timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "statistics" 2>&1 | tail -2 | tee $OUT/ops.log
+  for i in 1 2 3; do for e in 0 1; do
+    AWR_FAST_STATS=$e line "r18 b4 fast_stats=$e" --batch 4 | tee -a $OUT/bench_ab.txt
+    AWR_FAST_STATS=$e line "r18 b16 fast_stats=$e" --batch 16 | tee -a $OUT/bench_ab.txt
+    AWR_FAST_STATS=$e line "hg1 b16 fast_stats=$e" --net hourglass_1 --batch 16 | tee -a $OUT/bench_ab.txt
+    AWR_FAST_STATS=$e line "hg1 b64 fast_stats=$e" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
+faststats3) # EM 5 third form (four short fp32 chains per tile, fp64 from there): the parity suites as shipped + accuracy sweep
+  timeout 1200 python -m pytest tests/test_nets_gpu.py tests/test_full_size_gpu.py -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -30 | tee $OUT/suites.log
+  timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "statistics" 2>&1 | tail -2 | tee $OUT/ops.log
+  python tools/probes/stats_paths.py 2>&1 | grep -v amdgpu.ids | grep "tile=(0, 0)" | tee $OUT/stats_paths.txt
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
