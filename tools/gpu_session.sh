@@ -229,6 +229,21 @@ faststats3) # EM 5 third form (four short fp32 chains per tile, fp64 from there)
   timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "statistics" 2>&1 | tail -2 | tee $OUT/ops.log
   python tools/probes/stats_paths.py 2>&1 | grep -v amdgpu.ids | grep "tile=(0, 0)" | tee $OUT/stats_paths.txt
   ;;
+epirows)  # epilogue rows restructured (one store-policy branch per tile, a row's operands requested together): in-tree library against variants/libawr_old.so
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -x -k "bit_identical or every_tile or conv_forward or prologue or dgrad_with or streaming or statistics or batch_parts" 2>&1 | tail -3 | tee $OUT/ops.log
+  for i in 1 2 3; do for v in old new; do
+    L=""; [ $v = old ] && L=$GRAFT_REPO_ROOT/variants/libawr_old.so
+    AWR_LIB_PATH=$L line "r18 b64 $v" | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "hg1 b64 $v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "hg1 infer b128 $v" --net hourglass_1 --mode infer --batch 128 | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "r18 b16 $v" --batch 16 | tee -a $OUT/bench_ab.txt
+    AWR_LIB_PATH=$L line "r18 b256 $v" --batch 256 --steps 8 | tee -a $OUT/bench_ab.txt
+  done; done
+  for v in old new; do L=""; [ $v = old ] && L=$GRAFT_REPO_ROOT/variants/libawr_old.so
+    AWR_LIB_PATH=$L python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --per-layer $OUT/per_layer_r18_$v.txt > /dev/null 2>&1
+    AWR_LIB_PATH=$L python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1_$v.txt > /dev/null 2>&1
+  done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
