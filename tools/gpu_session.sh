@@ -244,6 +244,18 @@ epirows)  # epilogue rows restructured (one store-policy branch per tile, a row'
     AWR_LIB_PATH=$L python bench.py --steps 5 --warmup 2 $QUIET --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_hg1_$v.txt > /dev/null 2>&1
   done
   ;;
+evidence) # final evidence of the session: timelines of the final binary, PMC traffic of the Hourglass-1 step with the streaming-store rule on / off
+  bash tools/gpu_trace.sh r05 --no-hourglass-train --no-accurate-mode > /dev/null 2>&1
+  bash tools/gpu_trace.sh r05_hg1 --no-hourglass-train --no-accurate-mode --net hourglass_1 > /dev/null 2>&1
+  cp gpurun_out/timeline_r05.txt gpurun_out/timeline_r05_hg1.txt $OUT/
+  rm -f gpurun_out/kernel_trace_r05.csv gpurun_out/kernel_trace_r05_hg1.csv
+  for v in 0 256; do
+    AWR_NT_MIN_MB=$v EXTRA="--net hourglass_1" bash tools/gpu_pmc.sh hg1_nt$v > /dev/null 2>&1
+    cp gpurun_out/pmc_summary_hg1_nt$v.json $OUT/
+    rm -rf gpurun_out/pmc_sq_hg1_nt$v gpurun_out/pmc_fetch_hg1_nt$v gpurun_out/pmc_write_hg1_nt$v
+  done
+  ls -la $OUT
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
