@@ -256,6 +256,20 @@ evidence) # final evidence of the session: timelines of the final binary, PMC tr
   done
   ls -la $OUT
   ;;
+kernarg)  # where the runtime keeps kernel arguments (the 620-byte awr_conv_args every wave s_loads in its prologue): HIP_FORCE_DEV_KERNARG = unset | 0 | 1
+  for v in unset 0 1; do
+    if [ $v = unset ]; then unset HIP_FORCE_DEV_KERNARG; else export HIP_FORCE_DEV_KERNARG=$v; fi
+    echo "== HIP_FORCE_DEV_KERNARG=$v"
+    timeout 600 python tools/microbench_gemm.py fwdset 2>&1 | grep -v amdgpu.ids | grep "hg 1x1\|hg 3x3\|layer1"
+  done | tee $OUT/fwdset.txt
+  for i in 1 2 3; do for v in unset 0 1; do
+    if [ $v = unset ]; then unset HIP_FORCE_DEV_KERNARG; else export HIP_FORCE_DEV_KERNARG=$v; fi
+    line "r18 b64 kernarg=$v" | tee -a $OUT/bench_ab.txt
+    line "hg1 b64 kernarg=$v" --net hourglass_1 | tee -a $OUT/bench_ab.txt
+    line "r18 b4 kernarg=$v" --batch 4 | tee -a $OUT/bench_ab.txt
+    line "r18 infer b4 kernarg=$v" --mode infer --batch 4 | tee -a $OUT/bench_ab.txt
+  done; done
+  ;;
 tests)    # the whole GPU suite
   timeout 1700 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E        +" | tail -15 | tee $OUT/tests.log
   ;;
