@@ -37,14 +37,15 @@ def get_deterministic():
 def set_gemm_accum(mode):
     """Process-wide accumulation order of the forward / data-gradient GEMMs of plans built afterwards (include/awr_hip.h:
     awr_set_gemm_accum): "ordered" / 0 = one k-ordered chain per output element (fastest, the default), "blocked" / 1 = the chain restarts
-    every 128 k into a second accumulator set -- a convolution's rounding error falls to torch-CPU's (the parity mode)."""
+    every 128 k into a second accumulator set -- a convolution's rounding error falls to torch-CPU's (the parity mode), "auto" / 2 = blocked
+    only on the launches with a long K extent (TrainEngine's own default, whatever the process-wide mode is)."""
     from . import _lib as L
-    L.call("awr_set_gemm_accum", {"ordered": 0, "blocked": 1}.get(mode, mode))
+    L.call("awr_set_gemm_accum", {"ordered": 0, "blocked": 1, "auto": 2}.get(mode, mode))
 
 
 def get_gemm_accum():
     from . import _lib as L
-    return ("ordered", "blocked")[int(L.lib.awr_get_gemm_accum())]
+    return ("ordered", "blocked", "auto")[int(L.lib.awr_get_gemm_accum())]
 
 
 def __getattr__(name):

@@ -80,6 +80,15 @@ class WgradArgs(C.Structure):
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16), ("split_stride", C.c_int64), ("max_split", C.c_int)]
 
 
+class NyuSample(C.Structure):
+    """awr_nyu_sample (include/awr_hip.h): one image of a device-side NYU batch."""
+    _fields_ = [("frame", C.c_int64), ("ustart", C.c_int32), ("vstart", C.c_int32), ("cw", C.c_int32), ("ch", C.c_int32),
+                ("rw", C.c_int32), ("rh", C.c_int32), ("ox", C.c_int32), ("oy", C.c_int32), ("ifx", C.c_double), ("ify", C.c_double),
+                ("zstart", C.c_double), ("zend", C.c_double), ("op", C.c_int32), ("norm32", C.c_int32), ("m", C.c_double * 9),
+                ("zstart2", C.c_double), ("zend2", C.c_double), ("lo", C.c_double), ("far", C.c_double), ("center_z", C.c_double),
+                ("half", C.c_double)]
+
+
 _I, _F, _L, _P, _D = C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_double
 _PP = C.POINTER(C.c_void_p)
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)      # awr_bucket_cb
@@ -117,6 +126,9 @@ _SIGS = {
     "awr_get_gemm_staging": ([], C.c_int),
     "awr_set_gemm_accum": ([_I], C.c_int),
     "awr_get_gemm_accum": ([], C.c_int),
+    "awr_set_gemm_accum_auto_k": ([_I], C.c_int),
+    "awr_get_gemm_accum_auto_k": ([], C.c_int),
+    "awr_resolve_gemm_accum": ([_I, _I], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "awr_stem_stats": ([_P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
     "awr_stem_conv": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
@@ -184,6 +196,12 @@ _SIGS = {
     "awr_dp_broadcast": ([_P, _P, _L, _I, _P], C.c_int),
     "awr_dp_wait": ([_P, _P], C.c_int),
     "awr_plan_set_dp": ([_P, _P], C.c_int),
+    # NYU data path (csrc/awr_nyu.hip)
+    "awr_nyu_crop": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P], C.c_int),
+    "awr_nyu_warp": ([_P, _I, _I, _P, _I, _F, _I, _I, _I, _P, _P], C.c_int),
+    "awr_nyu_normalize": ([_P, _P, _P, _I, _L, _P, _P], C.c_int),
+    "awr_nyu_augment": ([_P, _P, _P, _I, _I, _P, _P, _P], C.c_int),
+    "awr_nyu_batch": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P], C.c_int),
 }
 
 EXPORTS = tuple(_SIGS)

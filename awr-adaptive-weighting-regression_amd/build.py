@@ -24,6 +24,7 @@ SOURCES = {
     "awr_stem.hip": [],
     "awr_net.hip": [],        # host-only: network-level plan builder / runner
     "awr_dp.hip": [],         # host-only: RCCL communicators through dlopen (no link-time dependency)
+    "awr_nyu.hip": ["-ffp-contract=off"],     # NYU data path: numpy's / OpenCV's arithmetic, no fused multiply-adds
 }
 
 
@@ -46,19 +47,26 @@ def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "awr_hip.h"))
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        if force or _stale(obj, [path] + headers):
-            cmd = [hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics",
-                   "-c", path, "-o", obj] + extra
+        deps = [path] + headers + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
+        if force or _stale(obj, deps):
+            jobs.append([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+                         "-munsafe-fp-atomics", "-c", path, "-o", obj] + extra)
+        objs.append(obj)
+    if jobs:            # translation units are independent: compile them side by side (the GEMM files dominate the wall time)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[awr build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:

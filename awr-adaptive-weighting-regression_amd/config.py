@@ -24,8 +24,11 @@ _OPTIM = dict(loss_type="MyL1Loss", dense_weight=1.0, coord_weight=0, lr=1e-3, o
 _MI355X = dict(use_hipgraph=False,    # True: replay each step as one hipGraph (measured slower than eager two-stream issue at every batch size)
                world_size=1,          # data-parallel ranks (one process per GPU, RCCL)
                gemm_products=1,       # 1 = FP32 MFMA, 6 = split-operand mode
-               parity_infer=True)     # scoring passes (Trainer.test = test.py:67-86) run their GEMMs with blocked accumulation: a conv's rounding
-                                      # error at torch-CPU's level for a few % of throughput; False = the throughput mode
+               parity_infer=False,    # True: scoring passes (Trainer.test = test.py:67-86) run their GEMMs with blocked accumulation.  Eval-mode plans gain
+                                      # nothing measurable from it (1.851e-4 mm from the oracle either way, profiles/r05_parity_report.json) and pay ~3 %
+               accum="auto",          # accumulation order of the training GEMMs: "auto" | "ordered" | "blocked" (TrainEngine)
+               device_loader=True)    # NYU datasets built from this config keep their decoded frames in HBM and crop / augment / normalise on the
+                                      # GPU (awr_amd.nyu_device: bit-identical to the host loader nyu_data.NYU, which False selects)
 
 
 class Config(object):

@@ -2983,6 +2983,7 @@ static int g_wgrad_split = env_int("AWR_WGRAD_SPLIT", 1);
 static inline int wg_products() { return (g_products == 6 && g_wgrad_split) ? 6 : 1; }
 static int g_staging = env_int("AWR_DMA", 2);
 static int g_accum = env_int("AWR_ACCUM", 0);
+static int g_accum_auto_k = 1024;       // accum = 2 (auto): launches whose K extent reaches this many terms accumulate blocked
 
 extern "C" {
 
@@ -3016,12 +3017,25 @@ int awr_set_gemm_staging(int mode) {
 int awr_get_gemm_staging(void) { return g_staging; }
 
 int awr_set_gemm_accum(int mode) {
-    AWR_REQUIRE(mode == 0 || mode == 1, "gemm_accum: 0 (ordered) or 1 (blocked: restart every 128 k)");
+    AWR_REQUIRE(mode >= 0 && mode <= 2, "gemm_accum: 0 (ordered), 1 (blocked: restart every 128 k) or 2 (auto: blocked where the K extent is long)");
     g_accum = mode;
     return AWR_OK;
 }
 
 int awr_get_gemm_accum(void) { return g_accum; }
+
+int awr_set_gemm_accum_auto_k(int min_k) {
+    AWR_REQUIRE(min_k >= 256, "gemm_accum_auto_k: the threshold is a K extent >= 256 (shorter extents are one block anyway)");
+    g_accum_auto_k = min_k;
+    return AWR_OK;
+}
+
+int awr_get_gemm_accum_auto_k(void) { return g_accum_auto_k; }
+
+int awr_resolve_gemm_accum(int k_extent, int plain_launch) {
+    if (g_accum != 2) return g_accum;
+    return (plain_launch && g_products == 1 && g_staging != 0 && k_extent >= g_accum_auto_k) ? 1 : 0;
+}
 
 static int conv_gemm_one(const awr_conv_args* a, void* stream);
 

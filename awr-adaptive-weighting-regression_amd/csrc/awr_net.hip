@@ -337,8 +337,12 @@ static void fill_conv_args(awr_conv_args& a, const Prob& p, int B, const float* 
     a.B = B; a.Hin = p.Hin; a.Win = p.Win; a.Cin = p.Cin;
     a.Hq = p.Hq; a.Wq = p.Wq; a.Hout = p.Hout; a.Wout = p.Wout; a.N = p.N;
     a.so = p.so; a.si = p.si; a.T = T;
-    a.accum = awr_get_gemm_accum();      // (the mode of the process when the plan is built, like the deterministic mode)
     a.nphase = (int)p.phases.size();
+    {   // the accumulation order is captured when the plan is built, like the deterministic mode; AUTO resolves per launch by its K extent
+        size_t taps = 0;
+        for (auto& ph : p.phases) taps = std::max(taps, ph.taps.size());
+        a.accum = awr_resolve_gemm_accum((int)taps * p.Cin, 1);
+    }
     for (int i = 0; i < a.nphase; ++i) {
         a.ph[i].py = p.phases[i].py;
         a.ph[i].px = p.phases[i].px;
@@ -947,7 +951,7 @@ struct Builder {
         const Spec &s2 = c2->spec, &s3 = c3->spec;
         const int64_t wgs = ((int64_t)x->B * x->H * x->W + 63) / 64;
         const int n1 = s2.cout;
-        if (off || P.training || awr_get_gemm_accum() != 0 || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
+        if (off || P.training || awr_resolve_gemm_accum(s2.T() * s2.cin_pad, 1) != 0 || awr_resolve_gemm_accum(s3.cin_pad, 1) != 0 || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
             (n1 != 128 && n1 != 64) || s3.cin != n1 || s3.cout != 2 * n1 || wgs < min_wgs || x->lazy || (dual && no_dual))
             return nullptr;
         if (dual && (dual->sk->spec.k != 1 || dual->sk->spec.stride != 1 || dual->sk->spec.cout != s3.cout || dual->sk->spec.cin_pad % 32 != 0 ||

@@ -88,17 +88,25 @@ def center2transmat(center, csize, dsize, paras=PARAS):
     return np.dot(t2, np.dot(sc, t1)).astype(np.float32)
 
 
+def crop_geometry(center, csize, dsize, paras=PARAS):
+    """The geometry of Loader.crop (loader.py:31-47): the window in the frame, its extent after the nearest-neighbour resize and where
+    that lands in the dsize crop.  Shared by the host crop below and by the device path's parameter blocks (awr_amd.nyu_device)."""
+    dsize = np.asarray(dsize)
+    bounds = center2bounds(center, csize, paras)
+    w, h = bounds[1] - bounds[0], bounds[3] - bounds[2]
+    scale = min(dsize[0] / w, dsize[1] / h)
+    size = (int(w * scale), int(h * scale))
+    us, vs = (dsize - np.asarray(size)) / 2.0
+    return bounds, size, (us, vs)
+
+
 def crop(img, center, csize, dsize, paras=PARAS):
     """loader.py:19-51."""
     dsize = np.asarray(dsize)
-    ustart, uend, vstart, vend, zstart, zend = center2bounds(center, csize, paras)
+    (ustart, uend, vstart, vend, zstart, zend), size, (us, vs) = crop_geometry(center, csize, dsize, paras)
     cropped = bounds2crop(img, ustart, uend, vstart, vend, zstart, zend)
-    w, h = uend - ustart, vend - vstart
-    scale = min(dsize[0] / w, dsize[1] / h)
-    size = (int(w * scale), int(h * scale))
     cropped = resize_nearest(cropped, size)
     res = np.zeros(dsize, dtype=np.float32)
-    us, vs = (dsize - np.asarray(size)) / 2.0
     res[int(vs):int(vs + size[1]), int(us):int(us + size[0])] = cropped
     return res, center2transmat(center, csize, dsize, paras)
 
@@ -230,6 +238,20 @@ class Augmenter:
     def _uvd(self, xyz):
         return xyz2uvd(xyz, self.paras, self.flip)
 
+    # The four places where augmentation touches PIXELS are methods, so that awr_amd.nyu_device can run the SAME control flow and label
+    # arithmetic while recording what the device kernels need instead of resampling on the host.
+    def depth_max(self, img):
+        return img.max()                                   # loader.py:76
+
+    def fringe_floor(self, img):
+        return np.min(img[img > 0]) - 1                    # loader.py:116 / :175: nv_val
+
+    def warp_affine(self, img, M, dsize, border):
+        return warp_affine(img, M, dsize, border=border)
+
+    def normalize(self, depth_max, img, center, cube):
+        return normalize(depth_max, img, center, cube)
+
     def recrop(self, img, center, cube, M, M_inv, dsize, thresh_z=True, bg=0.0, nv_val=0.0):
         """loader.py:123-137: re-sample the crop for a new centre / cube, clean the interpolation fringe, clamp to the cube."""
         img = warp_perspective(img, np.dot(M, M_inv), dsize, border=float(bg))
@@ -250,7 +272,7 @@ class Augmenter:
         if not np.allclose(center[2], 0.0) or np.allclose(new_center[2], 0.0):
             new_M = center2transmat(new_center, cube, np.array(img.shape), self.paras)
             img = self.recrop(img, new_center, cube, new_M, np.linalg.inv(M), img.shape, thresh_z=True, bg=pad_value,
-                              nv_val=np.min(img[img > 0]) - 1)
+                              nv_val=self.fringe_floor(img))
         else:
             new_M = M
         jt_xyz = jt_xyz + self._xyz(center) - self._xyz(new_center)
@@ -262,7 +284,7 @@ class Augmenter:
             return img, jt_xyz
         rot = np.mod(rot, 360)
         rotM = rotation_matrix_2d((img.shape[1] // 2, img.shape[0] // 2), -rot, 1)
-        img = warp_affine(img, rotM, (img.shape[1], img.shape[0]), border=pad_value)
+        img = self.warp_affine(img, rotM, (img.shape[1], img.shape[0]), pad_value)
         center_xyz = self._xyz(center)
         jt_uvd = rotate_pts(self._uvd(jt_xyz + center_xyz), center, rot)
         return img, self._xyz(jt_uvd) - center_xyz
@@ -274,21 +296,21 @@ class Augmenter:
         new_cube = cube * scale
         if not np.allclose(center[2], 0.0):
             new_M = center2transmat(center, new_cube, np.array(img.shape), self.paras)
-            img = self.recrop(img, center, new_cube, new_M, np.linalg.inv(M), img.shape, bg=pad_value, nv_val=np.min(img[img > 0]) - 1)
+            img = self.recrop(img, center, new_cube, new_M, np.linalg.inv(M), img.shape, bg=pad_value, nv_val=self.fringe_floor(img))
         else:
             new_M = M
         return img, new_cube, new_M
 
     def augment(self, img, jt_xyz, center, cube, M, op, trans, scale, rot):
         """loader.py:75-86."""
-        depth_max = img.max()
+        depth_max = self.depth_max(img)
         if op == "trans":
             img, jt_xyz, center, M = self.translate(img, jt_xyz, center, cube, M, trans)
         elif op == "rot":
             img, jt_xyz = self.rotate(img, jt_xyz, center, rot)
         elif op == "scale":
             img, cube, M = self.scale(img, center, cube, M, scale)
-        return normalize(depth_max, img, center, cube), jt_xyz, cube, center, M
+        return self.normalize(depth_max, img, center, cube), jt_xyz, cube, center, M
 
 
 class NYU(torch.utils.data.Dataset):

@@ -63,9 +63,11 @@ class GradSync:
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
-                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, accum=None, _share=None):
-        """accum: None (process-wide mode) | "ordered" | "blocked" -- accumulation order of the forward / data-gradient GEMMs of this engine's
-        plan (awr_amd.set_gemm_accum): "blocked" is the parity mode (a conv's rounding error at torch-CPU's level, a few % slower)."""
+                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, accum="auto", _share=None):
+        """accum: "auto" (default) | "ordered" | "blocked" | None (the process-wide mode, awr_amd.set_gemm_accum) -- accumulation order of the
+        forward / data-gradient GEMMs of this engine's plan.  "blocked" is the parity mode (a conv's rounding error at torch-CPU's level, a few %
+        slower); "auto" blocks only the launches with a long K extent (include/awr_hip.h: awr_set_gemm_accum), where an ordered chain's error
+        is largest and blocking is cheapest; "ordered" is one chain per output element everywhere."""
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -83,6 +85,7 @@ class TrainEngine:
         # of in one launch at the tail of the step was measured slower: 14.28-14.32 vs 14.00-14.05 ms, profiles/r03_summary.md)
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
                                  n_buckets=n_buckets if self.dp else 1, accum=accum)
+        self._accum = accum
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data
         # parallel: one more stream that finished gradient buckets (scatter + all-reduce) are handed to
         self.plan.set_streams(wgrad_streams, comm=(wgrad_streams > 0 and self.dp))
@@ -266,7 +269,7 @@ class TrainEngine:
         if eng is None:
             eng = TrainEngine(self.net, b, self.H, self.ks, self.cw, self.dw, self.lr, self.wd, self.opt, self.momentum,
                               process_group=self.sync.pg, use_graph=False, n_buckets=self._n_buckets, autotune=False,
-                              wgrad_streams=0, _share=self)
+                              wgrad_streams=0, accum=self._accum, _share=self)
             self._children[b] = eng
         eng.lr, eng.step_count = self.lr, self.step_count
         return eng
@@ -405,8 +408,15 @@ class InferEngine:
         about the last digits of the joints, not about the last few per cent of throughput."""
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         self.parity = bool(parity)
+        if self.parity and (int(L.lib.awr_get_gemm_products()) != 1 or int(L.lib.awr_get_gemm_staging()) == 0):
+            # the blocked kernel exists for FP32-MFMA + LDS-DMA staging only: a scoring pass in the split-operand mode (config.gemm_products = 6)
+            # or with register staging runs ordered and says so, instead of failing at its first launch (ADVICE r5)
+            import warnings
+            warnings.warn("InferEngine(parity=True): blocked accumulation is not available with gemm_products = %d / staging = %d; "
+                          "scoring with ordered accumulation" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging()))
+            self.parity = False
         net.eval()
-        self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if parity else None)
+        self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if self.parity else None)
         if self.plan.n_side == 0:          # forward branches (ResNet downsample projections, Hourglass skip residuals) run beside the main chain
             self.plan.set_streams(4)
         self._autotune, self._compiled = bool(autotune), False
@@ -530,10 +540,22 @@ class Trainer:
             root = os.path.join(config.data_dir, config.dataset)
             if not os.path.isdir(os.path.join(root, "test")):
                 raise FileNotFoundError("NYU data not found under %s (expects train/ test/ center_*_refined.txt, dataloader/nyu_loader.py:38-49)" % root)
+            kw = dict(img_size=config.img_size, cube=config.cube, jt_num=config.jt_num)
+            self._render = {}
+            if getattr(config, "device_loader", False):
+                # frames decoded once into a uint16 memmap, resident in HBM for the run; datasets yield 200-byte parameter blocks and the
+                # image batch is produced by one kernel launch per step (nyu_device.py)
+                from . import nyu_device as DV
+                NYU = DV.DeviceNYU
+                for phase in ("train", "test"):
+                    if os.path.isdir(os.path.join(root, phase)):
+                        store = DV.FrameStore(DV.build_frame_cache(root, phase))
+                        self._render[phase] = DV.Renderer(store, config.img_size, config.batch_size)
             if os.path.isdir(os.path.join(root, "train")):
-                train_data = NYU(root, "train", img_size=config.img_size, aug_para=config.augment_para, cube=config.cube, jt_num=config.jt_num)
-            test_data = NYU(root, "test", img_size=config.img_size, cube=config.cube, jt_num=config.jt_num)
+                train_data = NYU(root, "train", aug_para=config.augment_para, **kw)
+            test_data = NYU(root, "test", **kw)
         self.trainData, self.testData, self.pg = train_data, test_data, process_group
+        self._render = getattr(self, "_render", {})
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         self.work_dir = os.path.join(config.output_dir, config.dataset, "checkpoint_" + config.exp_id)
         self.result_dir = os.path.join(self.work_dir, "results")
@@ -561,7 +583,7 @@ class Trainer:
             set_gemm_products(config.gemm_products)
         self.engine = TrainEngine(self.net, config.batch_size, config.img_size, config.kernel_size, config.coord_weight, config.dense_weight,
                                   config.lr, config.weight_decay, config.optimizer, process_group=process_group,
-                                  use_graph=getattr(config, "use_hipgraph", False))
+                                  use_graph=getattr(config, "use_hipgraph", False), accum=getattr(config, "accum", "auto"))
         if config.load_model and os.path.exists(config.load_model):
             self._msg("loading model from {}".format(config.load_model))
             pth = torch.load(config.load_model, map_location="cpu", weights_only=False)     # trusted project artefact (best_records may hold numpy scalars)
@@ -581,6 +603,16 @@ class Trainer:
         if stdout:
             print(msg)
         print(msg, file=self.log)
+
+    def _images(self, first, phase):
+        """First element of a batch -> (B, 1, S, S) float32 on the GPU: host-loader images are copied, device-loader parameter blocks
+        (uint8, nyu_device.BLOCK_BYTES each) are rendered from the HBM-resident frames by one kernel launch."""
+        if first.dtype == torch.uint8:
+            r = self._render.get(phase)
+            if r is None:
+                raise L.AwrError("the dataset yields device-loader parameter blocks but no frame store was built for phase %r" % phase)
+            return r(first)
+        return first.cuda(non_blocking=True).float()
 
     def _loader(self, data, shuffle, epoch=0):
         """train.py:109: DataLoader(batch_size, shuffle=True, num_workers) -- drop_last=False like the reference: the ragged last
@@ -617,7 +649,7 @@ class Trainer:
                 torch.distributed.all_reduce(t, group=self.pg)
                 return (t[:3] / t[3]).tolist()
             for ii, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(self._loader(self.trainData, True, epoch)):
-                losses, jt_pred = eng.step(img.cuda(non_blocking=True), jt_uvd_gt.cuda(non_blocking=True))
+                losses, jt_pred = eng.step(self._images(img, "train"), jt_uvd_gt.cuda(non_blocking=True))
                 lsum += losses                                      # device-side meter: no loss.item() per iteration
                 lcnt += 1
                 pend.append((jt_pred.clone(), jt_xyz_gt, center_xyz, M, cube))
@@ -662,9 +694,9 @@ class Trainer:
         import numpy as np
         cfg = self.config
         world = torch.distributed.get_world_size(self.pg) if self.pg is not None else 1
-        # scoring is the pass the parity mode exists for: blocked accumulation unless the config opts out (config.parity_infer)
+        # config.parity_infer = True scores with blocked accumulation (eval-mode plans measure no gain from it: off by default since round 6)
         inf = self._last_infer = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False,
-                                             parity=bool(getattr(cfg, "parity_infer", True)))
+                                             parity=bool(getattr(cfg, "parity_infer", False)))
         ev = self.EvalUtil(self.testData.img_size, self.testData.paras, self.testData.flip, self.testData.jt_num)
         n, bs = len(self.testData), cfg.batch_size
         mine = [b for b in range((n + bs - 1) // bs) if b % world == self.rank]
@@ -674,7 +706,9 @@ class Trainer:
         pad = None
         for k, (img, jt_xyz_gt, jt_uvd_gt, center_xyz, M, cube) in enumerate(loader):
             nb = img.shape[0]
-            x = img.cuda(non_blocking=True).float()
+            x = self._images(img, "test")
+            if img.dtype == torch.uint8:                             # device loader: the host only ever saw parameter blocks
+                img = x[:1].cpu() if (getattr(cfg, "vis_freq", 0) and (mine[k] + 1) % cfg.vis_freq == 0 and self._vis is not None) else None
             if nb < bs:                                              # ragged last batch: fill the static plan's batch with zeros, drop them after
                 if pad is None:
                     pad = torch.zeros((bs,) + tuple(x.shape[1:]), device=x.device)

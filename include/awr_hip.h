@@ -284,10 +284,19 @@ int awr_get_wgrad_products(void);
 int awr_set_gemm_staging(int mode);
 int awr_get_gemm_staging(void);
 /* Accumulation order of the forward / data-gradient GEMMs of plans created from now on (process-wide; default 0, or $AWR_ACCUM):
- * 0 = ordered, 1 = blocked (awr_conv_args.accum).  Blocked costs a second accumulator set (one resident wave per SIMD on the wider tiles)
- * and brings a convolution's rounding error down to torch-CPU's: the parity mode (InferEngine(parity=True), TrainEngine(accum="blocked")). */
+ * 0 = ordered, 1 = blocked (awr_conv_args.accum), 2 = AUTO: a launch is blocked when its K extent (taps x input channels of its longest
+ * phase) reaches awr_get_gemm_accum_auto_k() terms (default 1 024: ResNet18's layer2-4 3x3 convolutions and every transposed-convolution
+ * phase) and it is a plain launch the blocked kernel exists for (FP32-MFMA, LDS-DMA staging, no fused pair / split-K), ordered otherwise.
+ * The rounding error of an ordered chain grows with its length while the cost of blocking (a second accumulator set: one resident wave
+ * per SIMD on the wider tiles) falls with the tile count, so AUTO buys most of blocked's accuracy for a fraction of its cost: TrainEngine's
+ * default.  Blocked brings a convolution's rounding error down to torch-CPU's: the parity mode (InferEngine(parity=True),
+ * TrainEngine(accum="blocked")).  awr_resolve_gemm_accum: what a launch of that K extent gets under the current mode (what plan
+ * builders store in awr_conv_args.accum, which itself only takes 0 / 1). */
 int awr_set_gemm_accum(int mode);
 int awr_get_gemm_accum(void);
+int awr_set_gemm_accum_auto_k(int min_k);
+int awr_get_gemm_accum_auto_k(void);
+int awr_resolve_gemm_accum(int k_extent, int plain_launch);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).
@@ -545,6 +554,57 @@ int awr_dp_wait(awr_dp* dp, void* stream);
  * NULL detaches.  Replaces the bucket callback while set.  Lifetime: the plan keeps the pointer, not a reference -- detach (NULL) before
  * awr_dp_destroy; a backward that finds its communicator destroyed fails with AWR_ERR_ARG instead of calling into it. */
 int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
+
+/* ------------------------------------------------------------------------------------------
+ * NYU data path on the device (csrc/awr_nyu.hip).  Replaces the IMAGE work of the reference's per-sample loader --
+ * Loader.crop (dataloader/loader.py:19-51: center2bounds window, bounds2crop zero padding + cube clamp :190-208, cv2.resize
+ * INTER_NEAREST, paste), Loader.augment (:75-86) with recrop = cv2.warpPerspective + fringe clean-up + cube clamp (:123-137) or
+ * cv2.warpAffine (:140-160), and Loader.normalize (:88-101) -- for a whole batch per launch.  The host keeps what is tiny and
+ * sequential: the RandomState draws, the 3x3 matrices in float64 / float32 exactly as numpy computes them, the label arithmetic
+ * (awr_amd.nyu_device builds one awr_nyu_sample per image).  Results are bit-identical to awr_amd.nyu_data (the numpy restatement,
+ * itself bit-exact against the reference everywhere except cv2's three resamplers, which no cv2-produced vector pins: README).
+ *   frames: the decoded depth frames of the dataset, resident in HBM ([n_frames][fh][fw], uint16 millimetres = G*256 + B of the
+ *           PNG, dataloader/nyu_loader.py:71-74; or float32); a sample addresses its frame by index.
+ *   All per-pixel coordinate arithmetic is IEEE double / float without contraction (the file is built with -ffp-contract=off).
+ * -----------------------------------------------------------------------------------------*/
+#define AWR_NYU_NONE 0
+#define AWR_NYU_PERSPECTIVE 1       /* translate / scale: recrop through a homography (loader.py:103-137, :163-179) */
+#define AWR_NYU_AFFINE 2            /* rotate (loader.py:140-160) */
+#define AWR_NYU_U16 0
+#define AWR_NYU_F32 1
+typedef struct awr_nyu_sample {
+    int64_t frame;              /* row of the frame store */
+    int32_t ustart, vstart;     /* crop window origin in the frame; may be negative (zero padding, loader.py:196-200) */
+    int32_t cw, ch;             /* window extent uend - ustart, vend - vstart */
+    int32_t rw, rh;             /* extent after cv2.resize(..., INTER_NEAREST) (loader.py:37-40) */
+    int32_t ox, oy;             /* where the resized window is pasted into the dsize x dsize crop (loader.py:43-47) */
+    double ifx, ify;            /* resizeNN's inverse scale factors 1. / (rw / cw), 1. / (rh / ch) (two divisions, in this order) */
+    double zstart, zend;        /* depth range of the cube: below -> zstart, above -> 0, zero stays zero (loader.py:202-206) */
+    int32_t op;                 /* AWR_NYU_NONE / _PERSPECTIVE / _AFFINE */
+    int32_t norm32;             /* normalisation arithmetic: 0 = float64 (numpy's promotion for a float64 centre or cube), 1 = float32 */
+    double m[9];                /* destination -> source map: _PERSPECTIVE inv(M_new . inv(M)) row-major; _AFFINE the inverted 2x3 in m[0..5] */
+    double zstart2, zend2;      /* cube clamp of the recrop (loader.py:131-135) */
+    double lo, far, center_z, half;   /* normalize: x in {depth_max, 0} -> far; clip(lo, far); (x - center_z) / half (loader.py:88-101) */
+} awr_nyu_sample;
+
+/* Loader.crop (loader.py:19-51) for B samples: crop (B, dsize, dsize) float32; stats (B, 2) float32 = {max of the crop (augment's
+ * depth_max, loader.py:76), smallest positive value (recrop's nv_val + 1, loader.py:116; +inf if none)}.  One workgroup per sample. */
+int awr_nyu_crop(const void* frames, int frame_type, int fh, int fw, const awr_nyu_sample* samples, int B, int dsize, float* crop,
+                 float* stats, void* stream);
+/* The resamplers alone, cv2.warpPerspective / cv2.warpAffine with INTER_LINEAR + BORDER_CONSTANT (OpenCV's fixed-point rule: source
+ * coordinates in 1/32 pixel, 10-bit affine increments): dst (B, dh, dw) from src (B, sh, sw); m (B, 9) doubles as awr_nyu_sample.m. */
+int awr_nyu_warp(const float* src, int sh, int sw, const double* m, int op, float border, int B, int dh, int dw, float* dst, void* stream);
+/* Loader.normalize (loader.py:88-101) alone: out[b] = normalize(depth_max[b], img[b], centre, cube) over n pixels per sample */
+int awr_nyu_normalize(const float* img, const float* depth_max, const awr_nyu_sample* samples, int B, int64_t n, float* out, void* stream);
+/* Loader.augment's image half (loader.py:75-86) from materialised crops: warp per `op`, fringe clean-up against stats, cube clamp,
+ * normalize -> out (B, 1, dsize, dsize).  status[b] (optional) = 1 where a recrop found no positive pixel (the reference raises). */
+int awr_nyu_augment(const float* crop, const float* stats, const awr_nyu_sample* samples, int B, int dsize, float* out, int* status,
+                    void* stream);
+/* The production entry: crop + augment + normalize in ONE launch, one workgroup per sample, the crop staged in LDS (never written to
+ * HBM) when dsize * dsize floats fit (dsize <= 160); larger crops go through `scratch` (B * (dsize * dsize + 2) floats, else may be
+ * NULL) with the two kernels above.  Test-time samples (nyu_loader.py:59-60) are op = AWR_NYU_NONE. */
+int awr_nyu_batch(const void* frames, int frame_type, int fh, int fw, const awr_nyu_sample* samples, int B, int dsize, float* out,
+                  int* status, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

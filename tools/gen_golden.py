@@ -240,6 +240,46 @@ def main():
                 out[tag + "_param_smp%d" % (it + 1)] = psmp
         np.savez_compressed(os.path.join(GOLD, "%s_train.npz" % net), **out)
 
+    # ---- a well-conditioned training-mode fixture: batch 8, weights with the reference's init_weights distributions, -----
+    # seeded inputs; held to the PLAIN north_star bar (1e-3 mm mean, 5e-3 max) in every accumulation mode.  KB-sized: the inputs are
+    # regenerated from their seeds by the test (a checksum guards the generators), outputs are sampled.
+    print("[resnet_18 training mode, batch 8, reference init distributions]")
+    net, J, B, ks = "resnet_18", 14, 8, 1.0
+    img, jt_gt = O.synth_batch(B, 128, J, seed=31)
+    man_ = O.manifest_for(net, J)
+    pkeys = O.params_of(None, man_)
+    out = {"J": J, "ks": np.float32(ks), "B": B, "img_seed": 31, "w_seed": 21, "img_sum": np.float64(img.double().sum()),
+           "w_sum": np.float64(sum(float(v.double().abs().sum()) for v in O.reference_init_state(net, J, seed=21).values())), "pkeys": np.array(pkeys)}
+    for cw, dw in [(0.0, 1.0), (1.0, 1.0)]:
+        tag = "c%d" % int(cw)
+        ref = build_ref_net(net, J, get_deconv_net, PoseNet)
+        ref.load_state_dict(O.reference_init_state(net, J, seed=21), strict=True)
+        ref.train()
+        gt = fm.joint2offset(jt_gt, img, ks, 64)
+        pred = ref(img)
+        jt = fm.offset2joint_softmax(pred, img, ks)
+        l_coord, l_dense = cw * crit(jt, jt_gt), dw * crit(pred, gt)
+        loss = l_coord + l_dense
+        loss.backward()
+        named = dict(ref.named_parameters())
+        sd = O.reference_init_state(net, J, seed=21)
+        lo, lco, ldo, grads, jt_o = O.train_step(net, sd, {"step": 0, "m": {}, "v": {}}, img, jt_gt, ks, cw, dw, lr=1e-3)
+        check("%s b8 %s loss" % (net, tag), lo, loss.detach(), 1e-6 * max(1.0, float(loss)))
+        check("%s b8 %s joints" % (net, tag), jt_o, jt.detach(), 2e-6)
+        idx = sample_idx(pred.numel(), 4096, 77)
+        out[tag + "_loss0"] = np.float32(loss.detach())
+        out[tag + "_lcoord0"] = np.float32(torch.as_tensor(l_coord).detach())
+        out[tag + "_jt0"] = jt.detach().numpy()
+        out["pred_idx"] = idx
+        out[tag + "_pred_val"] = pred.detach().reshape(-1).numpy()[idx]
+        out[tag + "_grad_l2"] = np.array([float(named[k].grad.double().norm()) for k in pkeys])
+        out[tag + "_grad_smp"] = np.array([float(named[k].grad.reshape(-1)[sample_idx(named[k].numel(), 1, 40 + i)[0]]) for i, k in enumerate(pkeys)], dtype=np.float32)
+    rsd = ref.state_dict()
+    bn_keys = [k for k in rsd if k.endswith("running_mean") or k.endswith("running_var")]
+    out["bn_keys"] = np.array(bn_keys)
+    out["bn_smp"] = np.array([float(rsd[k].reshape(-1)[sample_idx(rsd[k].numel(), 1, 90 + i)[0]]) for i, k in enumerate(bn_keys)], dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLD, "resnet_18_train_b8.npz"), **out)
+
     # ---- BASELINE config 5 shape: Hourglass-2, J = 21, 256x256 (train.py:116-121 semantics at the stress shape) ----------
     print("[config 5: hourglass_2, J=21, 256x256]")
     net, J, H, B, ks, cw, dw = "hourglass_2", 21, 256, 2, 0.4, 1.0, 1.0
