@@ -36,9 +36,9 @@ def get_deterministic():
 
 def set_gemm_accum(mode):
     """Process-wide accumulation order of the forward / data-gradient GEMMs of plans built afterwards (include/awr_hip.h:
-    awr_set_gemm_accum): "ordered" / 0 = one k-ordered chain per output element (fastest, the default), "blocked" / 1 = the chain restarts
-    every 128 k into a second accumulator set -- a convolution's rounding error falls to torch-CPU's (the parity mode), "auto" / 2 = blocked
-    only on the launches with a long K extent (TrainEngine's own default, whatever the process-wide mode is)."""
+    awr_set_gemm_accum): "ordered" / 0 = one k-ordered chain per output element (fastest), "blocked" / 1 = the chain restarts every 128 k into
+    a second accumulator set -- a convolution's rounding error falls to torch-CPU's (the parity mode), "auto" / 2 (the default) = blocked only
+    on the forward launches of TRAINING plans with a long K extent, everything else ordered."""
     from . import _lib as L
     L.call("awr_set_gemm_accum", {"ordered": 0, "blocked": 1, "auto": 2}.get(mode, mode))
 

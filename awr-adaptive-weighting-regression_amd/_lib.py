@@ -111,23 +111,22 @@ _SIGS = {
     "awr_pack_weights_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_unpack_wgrads_batched": ([_P, _I, _L, _P], C.c_int),
     "awr_conv_gemm": ([C.POINTER(ConvArgs), _P], C.c_int),
-    "awr_conv_gemm_part": ([C.POINTER(ConvArgs), _I, _I, _P], C.c_int),
     "awr_maxpool_fwd_stats": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "awr_upsample2_add_stats": ([_P, _P, _I, _I, _I, _I, _P, _P, _I, _P], C.c_int),
     "awr_conv_wgrad": ([C.POINTER(WgradArgs), _P], C.c_int),
     "awr_conv_wgrad_algo_ok": ([C.POINTER(WgradArgs), _I], C.c_int),
     "awr_debug_force_tile": ([_I, _I], C.c_int),
+    "awr_debug_set_knob": ([C.c_char_p, _I], C.c_int),
     "awr_set_gemm_products": ([_I], C.c_int),
     "awr_split_weight": ([_P, _P, _L, _P], C.c_int),
-    "awr_split_act": ([_P, _P, _P, _I, _L, _I, _P, _P], C.c_int),
     "awr_get_gemm_products": ([], C.c_int),
     "awr_get_wgrad_products": ([], C.c_int),
     "awr_set_gemm_staging": ([_I], C.c_int),
     "awr_get_gemm_staging": ([], C.c_int),
     "awr_set_gemm_accum": ([_I], C.c_int),
     "awr_get_gemm_accum": ([], C.c_int),
-    "awr_set_gemm_accum_auto_k": ([_I], C.c_int),
-    "awr_get_gemm_accum_auto_k": ([], C.c_int),
+    "awr_set_gemm_accum_auto": ([_I, _I], C.c_int),
+    "awr_get_gemm_accum_auto": ([C.POINTER(_I), C.POINTER(_I)], C.c_int),
     "awr_resolve_gemm_accum": ([_I, _I], C.c_int),
     "awr_stem_im2col": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "awr_stem_stats": ([_P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
@@ -204,7 +203,17 @@ _SIGS = {
     "awr_nyu_batch": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P], C.c_int),
 }
 
-EXPORTS = tuple(_SIGS)
+# entry points of study builds only (hipcc -DAWR_STUDY, AWR_BUILD_STUDY=1 for awr_amd.build): measured-and-rejected forms that the default
+# library neither contains nor exports (tests/test_abi.py checks that); HAS_STUDY says which kind of library is loaded
+_STUDY_SIGS = {
+    "awr_conv_gemm_part": ([C.POINTER(ConvArgs), _I, _I, _P], C.c_int),
+    "awr_split_act": ([_P, _P, _P, _I, _L, _I, _P, _P], C.c_int),
+}
+STUDY_EXPORTS = tuple(_STUDY_SIGS)
+HAS_STUDY = all(hasattr(lib, n) for n in _STUDY_SIGS)
+if HAS_STUDY:
+    _SIGS.update(_STUDY_SIGS)
+EXPORTS = tuple(k for k in _SIGS if k not in _STUDY_SIGS)
 MISSING = []                           # header/library mismatch; tests/test_abi.py requires this to be empty
 for _name, (_args, _ret) in _SIGS.items():
     try:

@@ -20,7 +20,12 @@ ARCH = "gfx950"
 SOURCES = {
     "awr_head.hip": ["-ffp-contract=off"],
     "awr_elem.hip": [],
-    "awr_conv.hip": [],
+    "awr_gemm_t22.hip": [],   # LDS-DMA implicit GEMM, one workgroup-tile shape per file (they dominate the build: compiled side by side)
+    "awr_gemm_t21.hip": [],
+    "awr_gemm_t12.hip": [],
+    "awr_gemm_t11.hip": [],
+    "awr_conv.hip": [],       # conv dispatch, register-staged GEMM, fused pairs
+    "awr_wgrad.hip": [],      # weight gradients
     "awr_stem.hip": [],
     "awr_net.hip": [],        # host-only: network-level plan builder / runner
     "awr_dp.hip": [],         # host-only: RCCL communicators through dlopen (no link-time dependency)
@@ -42,7 +47,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force=False, verbose=True):
+def build_lib(force=False, verbose=True, study=None):
+    """study (default: $AWR_BUILD_STUDY == "1"): compile with -DAWR_STUDY -- the measured-and-rejected forms of earlier rounds (pre-cut
+    split-operand GEMM, half-batch BatchNorm-backward wavefront) and their entry points.  The default library has none of them."""
+    study = (os.environ.get("AWR_BUILD_STUDY") == "1") if study is None else bool(study)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -56,7 +64,7 @@ def build_lib(force=False, verbose=True):
         deps = [path] + headers + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
         if force or _stale(obj, deps):
             jobs.append([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                         "-munsafe-fp-atomics", "-c", path, "-o", obj] + extra)
+                         "-munsafe-fp-atomics", "-c", path, "-o", obj] + extra + (["-DAWR_STUDY"] if study else []))
         objs.append(obj)
     if jobs:            # translation units are independent: compile them side by side (the GEMM files dominate the wall time)
         from concurrent.futures import ThreadPoolExecutor

@@ -1,2950 +1,39 @@
-// FP32-MFMA implicit-GEMM convolution family for gfx950 (CDNA4).
-//
-// One gather-GEMM kernel covers conv forward (any k, stride 1/2), transposed-conv forward
-// (4 sub-pixel phases), and both kinds of data gradient; a second kernel covers the weight
-// gradients (split-K over pixels).  Design points (see DESIGN.md "conv kernels"):
-//   * exact-f32 v_mfma_f32_32x32x2_f32 (157.3 TF peak; bit-equal to an fmaf chain) -- the parity
-//     path of north_star (1e-3 mm) cannot use bf16.
-//   * 64-lane wavefronts: a workgroup is 4 waves in a 2x2 grid, each wave owns TMxTN 32x32
-//     accumulator tiles (TM,TN in {1,2}) -> 64..128-wide tiles chosen per layer so that small
-//     spatial layers still fill 256 CUs.
-//   * operands are staged global -> registers -> LDS as K-contiguous rows (NHWC makes every
-//     (pixel, tap) a contiguous Cin run; packed weights are [n][tap][Cin]); rows are padded to
-//     36 floats so the ds_read_b128 fragment reads are bank-conflict free.  Each lane reads a
-//     float4 = 4 consecutive k for its half-wave, feeding 4 back-to-back MFMAs.
-//   * the next K-slice's global loads are issued before the current slice's MFMAs, so HBM/L2
-//     latency hides under the 64-cycle MFMAs.
-//   * fused prologue (per-input-channel affine + ReLU = the previous BatchNorm) and epilogue
-//     (bias, folded BN, residual add, ReLU, per-channel sum / sum-of-squares for the next
-//     BatchNorm) remove whole HBM passes.
-//   * XCD-aware workgroup remap: consecutive tiles of one row-panel land on the same XCD's L2.
-#include <stdlib.h>
+// Convolution family, main translation unit: process-wide modes, the forward / data-gradient dispatch (awr_conv_gemm), the register-staged
+// GEMM, split-K and fused-pair launches.  Kernels: csrc/awr_conv_kernels.inc; the LDS-DMA GEMM instantiations: csrc/awr_gemm_t*.hip;
+// weight gradients: csrc/awr_wgrad.hip.
+#include <string.h>
 
-#include <type_traits>
-
-#include "awr_common.h"
+#define AWR_CONV_MAIN_TU
+#include "awr_conv_kernels.inc"
+#include "awr_conv_modes.h"
 
 namespace awr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;        // K-slice (floats)
-constexpr int LDK = BK + 4;   // padded LDS row (floats) : 144 B, conflict-free for ds_read_b128
-#ifndef AWR_WBK
-#define AWR_WBK 32
-#endif
-constexpr int WBK = AWR_WBK;  // K-slice of the fp32 weight-gradient kernel (pixels)
-
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    // bijective "each XCD gets a contiguous chunk" remap (hardware places block b on XCD b % 8)
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-}
-
-// Buffer addressing (T8): a 128-bit resource + a 32-bit byte offset per lane.  Out-of-range offsets return 0
-// in hardware, which is exactly the zero padding / ragged-tile behaviour the gather needs: an invalid row
-// simply gets offset 0xFFFFFFFF -- no branch, no select, and (crucially) no s_waitcnt before the MFMAs.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);   // buffer_load_dwordx4 ... offen
-    static_assert(sizeof(v) == 16, "b128");
-    float4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-#ifndef AWR_EPI_LD_AUX
-#define AWR_EPI_LD_AUX 0     // cache policy of the epilogues' operand loads (residual / y / stored activation: read once) -- study builds: 2 = nt
-#endif
-__device__ __forceinline__ float4 buf_ld4_epi(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AWR_EPI_LD_AUX);
-    float4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-constexpr unsigned OOB = 0xFFFFFFFFu;
-
-// max(x, 0) as ONE v_med3_f32 (median of x, 0, +inf; a NaN gives 0 like fmaxf): fmaxf costs a canonicalising v_max in front of the
-// real one -- 32 of the ~115 VALU instructions per weight-gradient slice with a fused BatchNorm loader
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
-__device__ __forceinline__ float4 affine_relu(float4 v, float4 sc, float4 sh, int relu) {
-    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-    if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// Split-operand mode (NP = 6 or 9): exact fp32 products on the 16x faster bf16 matrix pipe.
-// ------------------------------------------------------------------------------------------
-// Every fp32 value is cut into three bf16 pieces by truncation: h = top 8 significand bits, m = the next 8, l = the last 8,
-// x == h + m + l EXACTLY (both subtractions are exact in fp32).  A product x*y is then the sum of nine bf16 x bf16 products,
-// each of which the matrix pipe forms exactly and accumulates in fp32: NP = 9 issues all nine (the fp32 product is
-// reproduced exactly, the only rounding left is the fp32 accumulation every fp32 GEMM has); NP = 6 drops m*l, l*m, l*l
-// (relative weight <= 2^-23 of the product).  9 x 32 cycles (v_mfma_f32_32x32x16_bf16 covers 16 k) replace 8 x 64 cycles of
-// v_mfma_f32_32x32x2_f32: 1.8x (NP = 9) / 2.7x (NP = 6) the FP32-MFMA rate.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDR = 3 * BK * 2 + 16;   // LDS row in split mode (bytes): [h | m | l] x 32 bf16 + 16 pad = 208 -> conflict-free b128 reads
-
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xFFFF0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));      // <= 8 significant bits: its low half-word is already zero
-}
-// upper half-words of two fp32 bit patterns -> one dword holding two bf16 (lo = a, hi = b)
-__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
-// four consecutive k of one LDS row: three 8-byte stores (h, m, l planes)
-#ifndef AWR_DMA_PROBE
-#define AWR_DMA_PROBE 0  // memory-system probes of the LDS-DMA GEMM (study builds, tools/gpu_session.sh probe1x1; results are WRONG, timing only): every instruction
-#endif                   // still issues, the memory system sees less -- bit 0: A-operand requests beyond the first stage go nowhere (zeros), bit 1: the same for
-                         // the weight operand, bit 2: the epilogue's output stores are dropped (out-of-range offsets), bit 3: its operand loads as well
-#ifndef AWR_PROBE
-#define AWR_PROBE 0      // bottleneck probes of the FP32 K loop (tools/probe_gemm.sh): 1 = no global loads in the loop, 2 = no LDS stores /
-#endif                   // 2nd barrier, 3 = both, 4 = both + no LDS fragment reads (MFMA only); 6 = split-mode weight-gradient staging without
-                         // the split arithmetic.  Results are wrong by construction; never shipped.
-__device__ __forceinline__ void store_split4(char* row_k, float4 v) {
-    if (AWR_PROBE == 6) {      // probe: the three stores without the split arithmetic
-        *reinterpret_cast<uint2*>(row_k) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-        *reinterpret_cast<uint2*>(row_k + 2 * BK) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
-        *reinterpret_cast<uint2*>(row_k + 4 * BK) = make_uint2(__float_as_uint(v.y), __float_as_uint(v.z));
-        return;
-    }
-    unsigned h[4], m[4], l[4];
-    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
-    *reinterpret_cast<uint2*>(row_k) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-    *reinterpret_cast<uint2*>(row_k + 2 * BK) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-    *reinterpret_cast<uint2*>(row_k + 4 * BK) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
-}
-__device__ __forceinline__ bf16x8 ld_frag(const char* p) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
-    bf16x8 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-// the TM x TN accumulator tiles of one wave advance by 16 k: NP products per tile, tiles interleaved so that dependent
-// MFMAs on one accumulator are TM*TN issues apart
+// (plain functions, not lambdas, for the initialisers: hipcc 7.2 initialised a second namespace-scope `static int g = []() { ... }();` of one
+// translation unit with the FIRST lambda's body -- DESIGN.md 5, side finding of round 3)
+int g_force_tm = 0, g_force_tn = 0, g_products = env_int("AWR_GEMM_PRODUCTS", 1);
+// Split-operand mode, weight gradients.  AWR_WGRAD_SPLIT=0 (round-5 study, profiles/r05_split_mode_studies.txt) runs them on the FP32-MFMA kernels instead
+// (kernel row, LDS-DMA per tap: exact fp32 products as well, and FASTER in isolation than the split-operand kernel whose staged rows are transposed and
+// cut in registers) -- and the step gets SLOWER: 10.77-10.91 -> 11.39-11.46 ms (a weight gradient runs beside the bf16 data-gradient chain; an FP32-MFMA
+// launch holds the matrix pipe three times as long per product).  Default: the split-operand weight gradient.
+int g_wgrad_split = env_int("AWR_WGRAD_SPLIT", 1);
+int g_staging = env_int("AWR_DMA", 2);
+int g_accum = env_int("AWR_ACCUM", 2);      // auto
+int g_accum_auto_k = 576;       // accum = 2 (auto): launches whose K extent reaches this many terms accumulate blocked ...
+int g_accum_auto_dgrad = 0;      // ... forward launches only (0) or data gradients too (1)
+// launch-path knobs, read ONCE (a getenv per launch is neither cheap nor safe against a concurrent setenv); tests and same-box A/Bs flip them
+// through awr_debug_set_knob
+int g_knob_deep = env_int("AWR_DEEP", 1), g_knob_deep_1x1 = env_int("AWR_DEEP_1X1", 0), g_knob_fast_stats = env_int("AWR_FAST_STATS", 1);
+// the LDS-DMA GEMM, one instantiation per workgroup-tile shape (csrc/awr_gemm_t*.hip)
 template <int TM, int TN>
-__device__ __forceinline__ void load_split_frags(const char* a_frag, const char* b_frag, bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) fa[i][s] = ld_frag(a_frag + i * 32 * LDR + s * 2 * BK);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) fb[j][s] = ld_frag(b_frag + j * 32 * LDR + s * 2 * BK);
-}
-struct no_filler {
-    __device__ __forceinline__ void operator()(int) const {}
-};
-// One 16-k step of a wave's TM x TN accumulator tiles: NP product groups of TM*TN independent MFMAs.  `filler(q)` is VALU work
-// the caller wants issued in the shadow of group q; the scheduling fence after each group keeps the compiler from hoisting
-// all of it to the front (which costs its registers for the whole step and leaves the later MFMAs uncovered).
-template <int TM, int TN, int NP, class F = no_filler>
-__device__ __forceinline__ void mfma_split16(const bf16x8 (&fa)[TM][3], const bf16x8 (&fb)[TN][3], f32x16 (&acc)[TM][TN], F filler = F()) {
-    constexpr int PA[9] = {2, 0, 1, 1, 0, 0, 2, 1, 2}, PB[9] = {0, 2, 1, 0, 1, 0, 1, 2, 2};   // small terms first, then h*h; 6..8 = dropped at NP=6
-    constexpr int ORD6[9] = {0, 1, 2, 3, 4, 5, 5, 5, 5}, ORD9[9] = {8, 6, 7, 0, 1, 2, 3, 4, 5};
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = NP == 9 ? ORD9[q] : ORD6[q];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][j], 0, 0, 0);
-        filler(q);
-        if constexpr (!std::is_same<F, no_filler>::value) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Epilogue shared by the f32 and the split-operand kernels.
-// ------------------------------------------------------------------------------------------
-// The MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) gives each lane ONE column: storing
-// from it means 16 four-byte stores per tile per lane.  Each wave instead bounces its 32x32 tile through a private
-// 32x36 LDS tile and leaves with float4 rows: 4 sixteen-byte stores per lane, every store instruction covering eight
-// full 128-byte lines; bias / folded-BN affine / residual (also loaded as float4) / statistics / ReLU are applied on
-// the way out.  (The single-K-slice layers -- im2col'd stem, 1x1 convs on the 128x128 maps -- are store-bound.)
-// The rows of the ONE operand tensor an epilogue reads (a residual, or the y of a fused BatchNorm-backward reduction) that this lane needs
-// for accumulator tile (i, j): four 16-byte requests through a buffer resource whose out-of-range offset (ragged rows, padded columns)
-// returns zeros.  EPRE launches issue tile (0, 0)'s BEFORE the K loop and every later tile's right after the previous tile has been consumed.
-// GEMM row m -> (qx, qy, image): shifts and masks when both map sides are powers of two (every reference map is), else two integer
-// divisions -- ~25 VALU instructions each, per staged row in the prologue and per row in a strided epilogue
-__device__ __forceinline__ void decode_row(const awr_conv_args& a, int m, int& qx, int& qy, int& b) {
-    if (((a.Wq & (a.Wq - 1)) | (a.Hq & (a.Hq - 1))) == 0) {      // (uniform)
-        const int ws = __builtin_ctz(a.Wq), hs = __builtin_ctz(a.Hq);
-        qx = m & (a.Wq - 1);
-        const int t = m >> ws;
-        qy = t & (a.Hq - 1);
-        b = t >> hs;
-    } else {
-        qx = m % a.Wq;
-        const int t = m / a.Wq;
-        qy = t % a.Hq;
-        b = t / a.Hq;
-    }
-}
-#ifndef AWR_ST_AUX
-#define AWR_ST_AUX 0     // cache policy of the GEMM epilogues' output stores (study builds: 2 = nt, non-temporal -- tools/gpu_session.sh ntstore)
-#endif
-struct epi_rows { float4 v[4]; };
-__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 u;
-    __builtin_memcpy(&u, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, AWR_ST_AUX);      // buffer_store_dwordx4 ... offen: an out-of-range offset is dropped
-}
-// streaming (non-temporal) forms: `buffer_store_dwordx4 ... nt` / `buffer_load_dwordx4 ... nt` -- awr_conv_args.out_nt
-__device__ __forceinline__ void buf_st4_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 u;
-    __builtin_memcpy(&u, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 2);
-}
-__device__ __forceinline__ float4 buf_ld4_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 2);
-    float4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-// Byte offset of (row m of the GEMM, column 0) in the output tensor, OOB for rows beyond M.  Everything the epilogue reads or writes sits at
-// that offset + 4 n in tensors of the output's shape (< 4 GB): one 32-bit add per access instead of a 64-bit multiply-add, no branch
-// around ragged rows -- the epilogue's integer arithmetic was ~1 100 VALU instructions per wave (profiles/r03_pmc_1x1.txt), a third of a
-// four-slice launch's issue cycles.
-template <int TM>
-__device__ __forceinline__ void epi_row_offsets(const awr_conv_args& a, const awr_phase& ph, int M, int tile_m, unsigned (&orow)[TM][4]) {
-    constexpr int BM = 64 * TM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, rbase = lane >> 3;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = tile_m * BM + wm * 32 * TM + i * 32 + rbase + 8 * q;
-            int opix = m;
-            if (a.so != 1) {
-                int qx, qy, b;
-                decode_row(a, m, qx, qy, b);
-                opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
-            }
-            orow[i][q] = m < M ? (unsigned)opix * (unsigned)a.N * 4u : OOB;
-        }
-}
-template <int TM, int TN>
-__device__ __forceinline__ void epi_fetch(const awr_conv_args& a, const unsigned (&orow)[TM][4], int tile_n, int i, int j, epi_rows& R) {
-    constexpr int BN = 64 * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave & 1, c4 = lane & 7;
-    const float* const one = a.res ? a.res : a.bnr_y;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));      // < 4 GB (checked at launch)
-    const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned off = (n0 < a.N && orow[i][q] != OOB) ? orow[i][q] + (unsigned)n0 * 4u : OOB;
-        R.v[q] = a.out_nt == 2 ? buf_ld4_nt(rs, off) : buf_ld4_epi(rs, off);
-    }
-}
-
-// EM (compile-time epilogue variant; run-time-uniform feature flags make the compiler keep every path's registers alive): 0 = every feature
-// behind its run-time flag, 1 = PLAIN (bias / affine / residual / ReLU only), 2 = STATS (the next BatchNorm's sum, sum of squares),
-// 3 = BNR (fused BatchNorm-backward reduction, nothing else), 4 = BNR with bnr_act / res / bnr2_y behind their run-time flags.  The launcher
-// picks the variant from the same flags.
-// SW (round 5): the accumulators come from a matrix instruction issued with its operand roles SWAPPED -- D = W_frag x A_frag^T, so lane l31 holds one
-// PIXEL and its registers 4g .. 4g+3 are four consecutive CHANNELS (8g + 4 half + 0..3): the tile goes to the bounce buffer as four 16-byte rows per
-// lane instead of sixteen 4-byte columns (same [pixel][channel] image, same reads, same results bit for bit).
-template <int TM, int TN, bool EPRE = false, int EM = 0, bool SW = false>
-__device__ __forceinline__ void gemm_epilogue(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], float* smem, int M,
-                                              int tile_m, int tile_n, epi_rows* pre = nullptr, const unsigned (*orow_in)[4] = nullptr) {
-    constexpr int BN = 64 * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    __syncthreads();                    // every wave is done with the staged slices
-    // EM == 5 (round 5): STATS of a launch whose stored value is accumulator + bias (no residual, no output affine) on tiles that lie wholly inside M --
-    // the sums are taken from the ACCUMULATORS, where a lane owns one channel and its registers are 16 of the tile's rows: sixteen subtract / add / fma
-    // per 32x32 tile, one cross-half exchange and one fp64 conversion per lane and column tile instead of the row-layout accumulation behind the bounce
-    // (64 VALU per tile, three shuffle rounds over eight values, four fp64 conversions and eight atomic instructions per lane quad)
-    constexpr bool FAST = EM == 5;
-    const bool stats_on = (EM == 0 || EM >= 2) && a.stats != nullptr, bnr_on = (EM == 0 || EM == 3 || EM == 4) && a.bnr_y != nullptr;
-    const bool act_on = EM != 3 && bnr_on && a.bnr_act != nullptr, bnr2_on = EM != 3 && bnr_on && a.bnr2_y != nullptr, stats2_on = EM != 3 && bnr_on && a.stats2 != nullptr;
-    const bool res_on = EM != 3 && !FAST && a.res != nullptr;
-    float* tbuf = smem + wave * (32 * LDK);
-    const int c4 = lane & 7, rbase = lane >> 3;
-    const bool nt = a.out_nt == 2;      // (uniform) streaming stores / operand loads: the launcher resolved the automatic policy
-    unsigned orow[TM][4];
-    if (orow_in) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) orow[i][q] = orow_in[i][q];
-    } else {
-        epi_row_offsets<TM>(a, ph, M, tile_m, orow);
-    }
-    const unsigned obytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u);      // < 4 GB (checked at launch)
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out, obytes), rs_res = make_rsrc(a.res ? a.res : a.out, a.res ? obytes : 0u),
-                                 rs_y = make_rsrc(a.bnr_y ? a.bnr_y : a.out, a.bnr_y ? obytes : 0u),
-                                 rs_act = make_rsrc(a.bnr_act ? a.bnr_act : a.out, a.bnr_act ? obytes : 0u),
-                                 rs_y2 = make_rsrc(a.bnr2_y ? a.bnr2_y : a.out, a.bnr2_y ? obytes : 0u);
-    // BatchNorm statistics (sum x, sum x^2) are accumulated SHIFTED by the first row of the wave's tile, c: a channel that is
-    // almost constant (std << |mean|: dead or saturated channels, constant image background) would otherwise lose its variance to
-    // the rounding of x^2 -- every term rounds the same way, the error does not average out -- and 1/sqrt(var + eps) amplifies
-    // that into the normalised activations and the gradients.  x - c is exact for nearly equal values; the sums return to the
-    // unshifted form in fp64 once per wave: sum x = s1 + n c, sum x^2 = s2 + 2 c s1 + n c^2.
-    const bool shifted = stats_on && !bnr_on;
-    float4 cs1[TN], cs2[TN], cs3[TN], csh[TN];      // cs3: sum g * xhat of a second BatchNorm sharing the masked gradient (a.bnr2_y)
-    int ccnt[TN];
-    [[maybe_unused]] double ff1[FAST ? TN : 1], ff2[FAST ? TN : 1];      // EM == 5: this lane's channel -- sum (x - c), sum (x - c)^2 (fp64 from one 32x32 tile on)
-    [[maybe_unused]] float ffc[FAST ? TN : 1];                           // ... and the shift c
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * c4;
-        const bool nok = n0 < a.N;                                        // N % 4 == 0: the whole float4 is in or out
-        const unsigned colb = (unsigned)n0 * 4u;
-        const float4 z4 = make_float4(0, 0, 0, 0), o4 = make_float4(1, 1, 1, 1);
-        // bias and folded-BatchNorm affine as ONE fused multiply-add per element, applied unconditionally: (v + b) s + t = v s + (b s + t);
-        // without either it is v * 1 + 0 (exact), with a bias only v * 1 + b (exact) -- two packed instructions per row instead of the twelve
-        // (two adds, two fmas, eight selects on the uniform flags) the compiler made of the two optional steps
-        constexpr bool OAFF = EM < 3 || FAST;      // (the reduction epilogues belong to data gradients: no bias, no folded BatchNorm -- their eight registers stay free)
-        float4 osc = (OAFF && a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
-        float4 osh = (OAFF && a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
-        if (OAFF && a.bias && nok) {
-            const float4 bias = ld4(a.bias + n0);
-            osh.x = bias.x * osc.x + osh.x; osh.y = bias.y * osc.y + osh.y; osh.z = bias.z * osc.z + osh.z; osh.w = bias.w * osc.w + osh.w;
-        }
-        float4 ksc = o4, ksh = z4, kmu = z4, kis = o4;       // fused BatchNorm-backward reduction coefficients
-        float4 kmu2 = z4, kis2 = o4;
-        if (bnr_on && nok) {
-            ksc = ld4(a.bnr_coef + n0); ksh = ld4(a.bnr_coef + a.N + n0);
-            kmu = ld4(a.bnr_coef + 2 * a.N + n0); kis = ld4(a.bnr_coef + 3 * a.N + n0);
-            if (bnr2_on) { kmu2 = ld4(a.bnr2_coef + 2 * a.N + n0); kis2 = ld4(a.bnr2_coef + 3 * a.N + n0); }
-        }
-        float4 s1 = z4, s2 = z4, s3 = z4, cshift = z4;
-        int cnt = 0;
-        [[maybe_unused]] double f1 = 0.0, f2 = 0.0;
-        [[maybe_unused]] float fc = 0.f;
-        [[maybe_unused]] const int fcol = tile_n * BN + wn * 32 * TN + j * 32 + l31;
-        [[maybe_unused]] const float fbias = (FAST && a.bias && fcol < a.N) ? a.bias[fcol] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if constexpr (FAST) {
-                // the STORED value (accumulator + bias, rounded once, as the row-layout path forms it) minus the shift: row 0 of the wave's tile, this
-                // lane's channel (held by the lower half-wave)
-                if (i == 0) fc = __shfl(acc[0][j][0] + fbias, l31, 64);
-                // four chains of four rows, combined pairwise, then fp64: shorter fp32 chains than the row-layout form's (the gradient yardstick is
-                // sensitive to the statistics' last bits at its two-image batches)
-                float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = (acc[i][j][r] + fbias) - fc;
-                    g1[r >> 2] += d;
-                    g2[r >> 2] += d * d;
-                }
-                f1 += (double)((g1[0] + g1[1]) + (g1[2] + g1[3]));
-                f2 += (double)((g2[0] + g2[1]) + (g2[2] + g2[3]));
-            }
-            if constexpr (SW) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    st4(tbuf + l31 * LDK + 8 * g + 4 * half, make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * half) * LDK + l31] = acc[i][j][r];
-            }
-            __builtin_amdgcn_wave_barrier();       // LDS ops of one wave execute in order; keep the compiler from reordering
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = rbase + 8 * q;
-                float4 v = ld4(tbuf + row * LDK + 4 * c4);
-                const bool valid = nok && orow[i][q] != OOB;
-                const unsigned off = valid ? orow[i][q] + colb : OOB;      // (loads at OOB return zeros, stores at OOB are dropped)
-                const unsigned off_ld = ((AWR_DMA_PROBE & 8) && a.B > 0) ? OOB : off, off_st = ((AWR_DMA_PROBE & 4) && a.B > 0) ? OOB : off;      // (probe builds)
-                if constexpr (OAFF) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-                if (res_on) {
-                    const float4 rr = EPRE ? pre->v[q] : (nt ? buf_ld4_nt(rs_res, off_ld) : buf_ld4_epi(rs_res, off_ld));
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                if (!FAST && shifted && i == 0 && q == 0) {      // (wave-uniform) the shift: row 0 of the wave's tile, held by lanes 0..7
-                    const float4 t = valid ? v : z4;
-                    cshift.x = __shfl(t.x, c4, 64); cshift.y = __shfl(t.y, c4, 64); cshift.z = __shfl(t.z, c4, 64); cshift.w = __shfl(t.w, c4, 64);
-                }
-                if (bnr_on) {
-                    // v is the gradient w.r.t. relu(bn(y)): mask it with the re-derived ReLU and reduce for the BN backward
-                    const float4 yy = EPRE ? pre->v[q] : (nt ? buf_ld4_nt(rs_y, off_ld) : buf_ld4_epi(rs_y, off_ld));
-                    if (act_on) {      // the activation had a residual added before the ReLU: mask from the stored tensor
-                        const float4 aa = (nt ? buf_ld4_nt(rs_act, off_ld) : buf_ld4_epi(rs_act, off_ld));
-                        v.x = aa.x > 0.f ? v.x : 0.f; v.y = aa.y > 0.f ? v.y : 0.f; v.z = aa.z > 0.f ? v.z : 0.f; v.w = aa.w > 0.f ? v.w : 0.f;
-                    } else {
-                        v.x = yy.x * ksc.x + ksh.x > 0.f ? v.x : 0.f; v.y = yy.y * ksc.y + ksh.y > 0.f ? v.y : 0.f;
-                        v.z = yy.z * ksc.z + ksh.z > 0.f ? v.z : 0.f; v.w = yy.w * ksc.w + ksh.w > 0.f ? v.w : 0.f;
-                    }
-                    if (!valid) v = z4;      // ragged rows / padded columns contribute nothing to the sums
-                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                    s2.x += v.x * ((yy.x - kmu.x) * kis.x); s2.y += v.y * ((yy.y - kmu.y) * kis.y);
-                    s2.z += v.z * ((yy.z - kmu.z) * kis.z); s2.w += v.w * ((yy.w - kmu.w) * kis.w);
-                    if (bnr2_on) {
-                        const float4 y2 = (nt ? buf_ld4_nt(rs_y2, off_ld) : buf_ld4_epi(rs_y2, off_ld));
-                        s3.x += v.x * ((y2.x - kmu2.x) * kis2.x); s3.y += v.y * ((y2.y - kmu2.y) * kis2.y);
-                        s3.z += v.z * ((y2.z - kmu2.z) * kis2.z); s3.w += v.w * ((y2.w - kmu2.w) * kis2.w);
-                    }
-                } else if (!FAST && stats_on) {
-                    const float vm = valid ? 1.f : 0.f;
-                    const float4 d = make_float4((v.x - cshift.x) * vm, (v.y - cshift.y) * vm, (v.z - cshift.z) * vm, (v.w - cshift.w) * vm);
-                    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
-                    s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
-                    cnt += valid ? 1 : 0;
-                }
-                if (a.relu_out) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                if (nt) buf_st4_nt(rs_out, off_st, v); else buf_st4(rs_out, off_st, v);
-            }
-            __builtin_amdgcn_wave_barrier();       // the tile is reused by the next (i, j)
-            if constexpr (EPRE) {                  // the next tile's rows, in flight across its LDS bounce
-                if (i + 1 < TM) epi_fetch<TM, TN>(a, orow, tile_n, i + 1, j, *pre);
-                else if (j + 1 < TN) epi_fetch<TM, TN>(a, orow, tile_n, 0, j + 1, *pre);
-            }
-        }
-        if constexpr (FAST) { ff1[j] = f1; ff2[j] = f2; ffc[j] = fc; }
-        cs1[j] = s1;
-        cs2[j] = s2;
-        cs3[j] = s3;
-        csh[j] = cshift;
-        ccnt[j] = cnt;
-    }
-    if constexpr (FAST) {
-        if (stats_on) {
-            double e1[TN], e2[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const double p1 = ff1[j] + __shfl_xor(ff1[j], 32, 64), p2 = ff2[j] + __shfl_xor(ff2[j], 32, 64);      // the two half-waves hold 16 rows each
-                // x = (x - c) + c: back to the unshifted sums in fp64, once per lane
-                const double cc = (double)ffc[j], cnt = 32.0 * TM;
-                e1[j] = p1 + cnt * cc;
-                e2[j] = p2 + 2.0 * cc * p1 + cnt * cc * cc;
-            }
-            __syncthreads();                 // all transpose tiles are dead: reuse the LDS for the cross-wave combine
-            double* red = reinterpret_cast<double*>(smem);      // [wn * TN + j][stat][lane 0..31]
-            if (wm == 1 && lane < 32) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    red[((wn * TN + j) * 2 + 0) * 32 + lane] = e1[j];
-                    red[((wn * TN + j) * 2 + 1) * 32 + lane] = e2[j];
-                }
-            }
-            __syncthreads();
-            if (wm == 0 && lane < 32) {
-                const unsigned nslots = a.stat_slots > 0 ? (unsigned)a.stat_slots : (unsigned)AWR_STAT_SLOTS;
-                const size_t slot = (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
-                double* st = a.stats + slot;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = tile_n * BN + wn * 32 * TN + j * 32 + lane;
-                    if (n < a.N) {
-                        atomicAdd(st + n, e1[j] + red[((wn * TN + j) * 2 + 0) * 32 + lane]);
-                        atomicAdd(st + a.N + n, e2[j] + red[((wn * TN + j) * 2 + 1) * 32 + lane]);
-                    }
-                }
-            }
-        }
-    } else if (stats_on) {
-        // Lanes with equal (lane & 7) hold partial sums of the same 4 columns: fold lane bits 3..5 (all lanes of a wave share the
-        // shift, so the shifted fp32 sums combine in one basis), leave the shifted form in fp64, combine the two M-waves of the
-        // workgroup in LDS, then ONE fp64 atomic per column and statistic, spread over AWR_STAT_SLOTS accumulator copies (thousands
-        // of workgroups hit the same C channels; without the slots the atomics serialise in L2 and cost more than the GEMM
-        // epilogue itself).  (The BatchNorm-backward sums -- sum g, sum g*xhat -- have no such cancellation: plain sums.)
-        double d1[TN][4], d2[TN][4], d3[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float* p1 = &cs1[j].x;
-            float* p2 = &cs2[j].x;
-            float* p3 = &cs3[j].x;
-            int cnt = ccnt[j];
-#pragma unroll
-            for (int o = 8; o <= 32; o <<= 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p1[e] += __shfl_xor(p1[e], o, 64);
-                    p2[e] += __shfl_xor(p2[e], o, 64);
-                    if (stats2_on) p3[e] += __shfl_xor(p3[e], o, 64);
-                }
-                cnt += __shfl_xor(cnt, o, 64);
-            }
-            const float* pc = &csh[j].x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double c = shifted ? (double)pc[e] : 0.0, n = (double)cnt;
-                d1[j][e] = (double)p1[e] + n * c;
-                d2[j][e] = (double)p2[e] + 2.0 * c * (double)p1[e] + n * c * c;
-                d3[j][e] = (double)p3[e];
-            }
-        }
-        __syncthreads();                 // all transpose tiles are dead: reuse the LDS for the cross-wave combine
-        double* red = reinterpret_cast<double*>(smem);      // [wn * TN + j][stat][lane 0..7][4]; third statistic behind the first two
-        double* red3 = red + 2 * TN * 2 * 8 * 4;
-        if (wm == 1 && lane < 8) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e] = d1[j][e];
-                    red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e] = d2[j][e];
-                    if (stats2_on) red3[((wn * TN + j) * 8 + lane) * 4 + e] = d3[j][e];
-                }
-        }
-        __syncthreads();
-        if (wm == 0 && lane < 8) {
-            // slot copies: AWR_STAT_SLOTS by default; with a.stat_slots >= the launch's workgroup count every workgroup owns its
-            // slot (one add onto zero is exact: the deterministic mode)
-            const unsigned nslots = a.stat_slots > 0 ? (unsigned)a.stat_slots : (unsigned)AWR_STAT_SLOTS;
-            const size_t slot = (size_t)(((unsigned)a.stat_slot_base + blockIdx.y * gridDim.x + blockIdx.x) % nslots) * 2 * a.N;
-            double* st = a.stats + slot;
-            double* st2 = stats2_on ? a.stats2 + slot : nullptr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 4 * lane;
-                if (n0 < a.N) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double t1 = d1[j][e] + red[(((wn * TN + j) * 2 + 0) * 8 + lane) * 4 + e];
-                        atomicAdd(st + n0 + e, t1);
-                        atomicAdd(st + a.N + n0 + e, d2[j][e] + red[(((wn * TN + j) * 2 + 1) * 8 + lane) * 4 + e]);
-                        if (st2) {      // the second BatchNorm sees the same masked gradient: same sum g, its own sum g * xhat
-                            atomicAdd(st2 + n0 + e, t1);
-                            atomicAdd(st2 + a.N + n0 + e, d3[j][e] + red3[((wn * TN + j) * 8 + lane) * 4 + e]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// The PLAIN epilogue of a swapped-operand launch WITHOUT the LDS bounce (round 5): a lane's registers 4g .. 4g+3 are 16 contiguous bytes of its pixel's
-// NHWC row, so the tile leaves as four buffer_store_dwordx4 per lane (the two half-waves complete 32-byte runs, the four instructions of a tile a 128-byte
-// line per pixel); bias / folded BatchNorm / residual / ReLU are applied on the way.  No LDS, no barrier in front, one row offset per tile row instead of four.
-template <int TM>
-__device__ __forceinline__ void epi_row_offsets_direct(const awr_conv_args& a, const awr_phase& ph, int M, int tile_m, unsigned (&orow)[TM]) {
-    constexpr int BM = 64 * TM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, l31 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-        int opix = m;
-        if (a.so != 1) {
-            int qx, qy, b;
-            decode_row(a, m, qx, qy, b);
-            opix = (b * a.Hout + qy * a.so + ph.py) * a.Wout + qx * a.so + ph.px;
-        }
-        orow[i] = m < M ? (unsigned)opix * (unsigned)a.N * 4u : OOB;
-    }
-}
-template <int TM, int TN>
-__device__ __forceinline__ void epi_fetch_direct(const awr_conv_args& a, const unsigned (&orow)[TM], int tile_n, int i, int j, epi_rows& R) {
-    constexpr int BN = 64 * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave & 1, half = lane >> 5;
-    const float* const one = a.res ? a.res : a.bnr_y;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(one, (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 8 * g + 4 * half;
-        R.v[g] = buf_ld4(rs, (n0 < a.N && orow[i] != OOB) ? orow[i] + (unsigned)n0 * 4u : OOB);
-    }
-}
-template <int TM, int TN, bool EPRE = false>
-__device__ __forceinline__ void gemm_epilogue_direct(const awr_conv_args& a, const awr_phase& ph, f32x16 (&acc)[TM][TN], int M, int tile_m, int tile_n,
-                                                     epi_rows* pre = nullptr, const unsigned* orow_in = nullptr) {
-    constexpr int BN = 64 * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave & 1, half = lane >> 5;
-    unsigned orow[TM];
-    if (orow_in) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) orow[i] = orow_in[i];
-    } else {
-        epi_row_offsets_direct<TM>(a, ph, M, tile_m, orow);
-    }
-    const unsigned obytes = (unsigned)((size_t)a.B * a.Hout * a.Wout * a.N * 4u);      // < 4 GB (checked at launch)
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out, obytes), rs_res = make_rsrc(a.res ? a.res : a.out, a.res ? obytes : 0u);
-    const bool res_on = a.res != nullptr;
-    const float4 z4 = make_float4(0, 0, 0, 0), o4 = make_float4(1, 1, 1, 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = tile_n * BN + wn * 32 * TN + j * 32 + 8 * g + 4 * half;
-                const bool nok = n0 < a.N;
-                float4 osc = (a.out_scale && nok) ? ld4(a.out_scale + n0) : o4;
-                float4 osh = (a.out_shift && nok) ? ld4(a.out_shift + n0) : z4;
-                if (a.bias && nok) {
-                    const float4 bias = ld4(a.bias + n0);
-                    osh.x = bias.x * osc.x + osh.x; osh.y = bias.y * osc.y + osh.y; osh.z = bias.z * osc.z + osh.z; osh.w = bias.w * osc.w + osh.w;
-                }
-                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                const unsigned off = (nok && orow[i] != OOB) ? orow[i] + (unsigned)n0 * 4u : OOB;
-                v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w;
-                if (res_on) {
-                    const float4 rr = EPRE ? pre->v[g] : buf_ld4(rs_res, off);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                if (a.relu_out) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                buf_st4(rs_out, off, v);
-            }
-            if constexpr (EPRE) {                  // the next tile's rows
-                if (i + 1 < TM) epi_fetch_direct<TM, TN>(a, orow, tile_n, i + 1, j, *pre);
-                else if (j + 1 < TN) epi_fetch_direct<TM, TN>(a, orow, tile_n, 0, j + 1, *pre);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// out[pix(m), n] = sum_{tap, c} in[gather(m, tap), c] * w[n][wt(tap)][c]
-// ------------------------------------------------------------------------------------------
-// NP = 0: operands stay fp32 in LDS, v_mfma_f32_32x32x2_f32.  NP = 6 / 9: split-operand mode (above).
-// AFF (split mode only): the fused input affine / ReLU is compiled in (two instantiations instead of a run-time branch around the
-// MFMA block: a branch there makes the register allocator keep both arms' accumulator copies alive).
-// DUAL (fp32 mode, single tap): the K extent is the concatenation of TWO input tensors at the same pixel -- channels [0, Cin1) come
-// from `in` (with the fused input affine, if any), [Cin1, Cin) from `in2` (plain) -- i.e. out = W_a . a + W_x . x in one launch:
-// the hourglass residual's conv3 + skip_layer (hourglass.py:44-59) without writing and re-reading the skip branch's output.
-// SPLIT (fp32 mode): blockIdx.z owns a contiguous range of the K slices and stores its raw partial tile to a.partial (copy
-// blockIdx.z); splitk_reduce_kernel finishes the job.
-// FUSE2 (fp32 mode, 64x128 tile, a.w2 set): TWO convolutions back to back.  The conv described by (in, w, taps) has exactly 128 output
-// channels, so the workgroup's 64x128 tile holds ALL channels of its 64 pixels: instead of storing it, bias / folded BatchNorm / ReLU are
-// applied in registers, the tile goes to LDS as the A operand of a second, 1x1 GEMM (w2: [N][128]) whose result gets the ordinary epilogue
-// (bias2, residual) -- the hourglass residual's conv2 (3x3) -> bn3 -> ReLU -> conv3 (1x1) + skip (hourglass.py:44-59) in one launch at
-// inference: the 128-channel intermediate is never written or re-read (0.54 GB per full-resolution residual at batch 128).
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false, bool EPRE = false>
-__device__ __forceinline__ void conv_gemm_body(const awr_conv_args& a) {
-    static_assert(!FUSE2 || (NP == 0 && !DUAL && !SPLIT), "FUSE2: FP32-MFMA mode");
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int RA = BM / 32, RB = BN / 32;   // float4 rows per thread for the A / B slices
-    constexpr int ROWB = NP ? LDR : LDK * 4;    // LDS row pitch in bytes
-    // one LDS array (a second __shared__ object would also cost scheduling freedom): A slices, B slices; the epilogue
-    // reuses it as 4 per-wave 32x36 transpose tiles (needs 18 432 B = exactly the 64x64 fp32 configuration).
-    // FUSE2: [intermediate tile BM x (BN + 4) (over the dead phase-1 slices)][w2 K-slices BN x 36, then the transpose tiles]
-    __shared__ __attribute__((aligned(16))) char smem_raw[FUSE2 ? BM * (BN + 4) * 4 + (BN * LDK * 4 > 4 * 32 * LDK * 4 ? BN * LDK * 4 : 4 * 32 * LDK * 4)
-                                                                : (BM + BN) * ROWB];
-    float* const smem = reinterpret_cast<float*>(smem_raw);
-    char* const As = smem_raw;
-    char* const Bs = smem_raw + BM * ROWB;
-
-    const awr_phase& ph = a.ph[blockIdx.y];
-    const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = FUSE2 ? 1 : (a.N + BN - 1) / BN;      // (FUSE2: a.N is the second conv's channel count; the first has BN)
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kc = (tid & 7) * 4;       // this thread's 4 consecutive k inside the slice
-    // first row it stages (then +32, +64, ...).  Split mode: the 8-byte LDS stores of a 16-lane group cover two rows; with rows
-    // r, r+1 (208-byte pitch = 52 banks) they collide on 4 of 32 banks (PMC: 6.5 M conflict cycles per launch, though no
-    // measurable time: LDS stores are paced by the VGPR -> LDS transfer); rows r, r+4 sit exactly 16 banks apart, so bits 0 and
-    // 2 of the row index are swapped.
-    const int r0 = NP ? (((tid >> 3) & 0x1a) | (((tid >> 3) & 1) << 2) | (((tid >> 3) >> 2) & 1)) : (tid >> 3);
-
-    // decode the A rows this thread stages (fixed for the whole K loop); byte offsets are 32-bit (tensors < 4 GB)
-    int a_iy[RA], a_ix[RA];
-    unsigned a_img[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = tile_m * BM + r0 + 32 * i;
-        if (m < M) {
-            int qx, qy, b;
-            decode_row(a, m, qx, qy, b);
-            a_iy[i] = qy * a.si;
-            a_ix[i] = qx * a.si;
-            a_img[i] = (unsigned)b * a.Hin * a.Win;
-        } else {
-            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
-            a_ix[i] = 0;
-            a_img[i] = 0;
-        }
-    }
-    const int cin1 = DUAL ? a.Cin1 : a.Cin;         // channels (= pixel pitch) of `in`; DUAL: `in2` holds the other a.Cin - cin1
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u);
-    const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(DUAL ? a.in2 : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, OOB);
-    unsigned w_off[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + 32 * i) * a.T * a.Cin + kc) * 4u;
-    // split mode: the weight slice of a row is 192 contiguous bytes of the pre-split image = 12 sixteen-byte pieces that go
-    // to LDS verbatim (no arithmetic): piece q = tid + 256 i -> row q / 12, piece q % 12
-    constexpr int RB3 = NP ? 3 * TN : 1;
-    const __amdgpu_buffer_rsrc_t rs_w3 = make_rsrc(a.w_split, OOB);
-    unsigned w3_off[RB3], w3_lds[RB3];
-    if constexpr (NP != 0) {
-#pragma unroll
-        for (int i = 0; i < RB3; ++i) {
-            // 12 sixteen-byte pieces per row: pieces 0-7 as one 8-lane store group per row (a full 32-bank line), pieces 8-11 as
-            // groups of two rows that are 4 rows (= 16 banks) apart -> every 16-byte LDS store group touches 32 distinct banks
-            int row, piece;
-            if (i < 2 * TN) {
-                const int q = tid + 256 * i;
-                row = q >> 3;
-                piece = q & 7;
-            } else {
-                const int q = tid + 256 * (i - 2 * TN), g = q >> 3, t = q & 7;
-                row = (((g >> 2) << 3) | (g & 3)) + 4 * (t >> 2);
-                piece = 8 + (t & 3);
-            }
-            w3_off[i] = (unsigned)(tile_n * BN + row) * a.T * (a.Cin / BK) * (6u * BK) + 16u * piece;
-            w3_lds[i] = (unsigned)(row * ROWB + 16 * piece);
-        }
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int cslices = a.Cin / BK;
-    const int ksteps = ph.ntaps * cslices;
-    float4 ra[RA], rb[NP ? RB3 : RB];
-    unsigned okmask = 0;     // which staged A rows were in bounds (the fused prologue must keep padding at 0)
-    int c0_staged = 0;
-
-    // Per tap (every Cin/32 K-slices): bounds test + base byte offset of each staged row.  Per K-slice: one add
-    // per row.  Keeping the per-slice VALU work tiny matters: the two waves that share a SIMD's MFMA pipe drift
-    // into lock-step, so every VALU cycle spent between MFMA bursts is a cycle the matrix pipe idles.
-    unsigned a_off[RA], a_off2[DUAL ? RA : 1], tapmask = 0, wtap = 0;
-    auto set_tap = [&](int tap) {
-        const int tp = ph.tap[tap];
-        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
-        tapmask = 0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * cin1 + kc) * 4u;
-            if constexpr (DUAL) a_off2[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * (a.Cin - cin1) + kc) * 4u;
-            tapmask |= ok ? (1u << i) : 0u;
-        }
-        wtap = NP ? (unsigned)wt * (a.Cin / BK) * (6u * BK) : (unsigned)wt * a.Cin * 4u;
-    };
-    // issue the global loads of one K-slice; nothing here waits for memory
-    auto load_slice = [&](int c0) {
-        const unsigned cb = (unsigned)c0 * 4u;
-        if (DUAL && c0 >= cin1) {            // wave-uniform: this K-slice comes from the second tensor
-            const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in2, (tapmask & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
-        } else {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
-        }
-        if constexpr (NP == 0) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i) rb[i] = buf_ld4(rs_w, w_off[i] + (wtap + cb));
-        } else {
-            const unsigned sb = wtap + (unsigned)(c0 / BK) * (6u * BK);
-#pragma unroll
-            for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
-        }
-        okmask = tapmask;
-        c0_staged = c0;
-    };
-    // registers -> LDS, applying the fused input affine + ReLU (the previous BatchNorm) on the way
-    auto store_slice = [&]() {
-        if (a.in_scale && (!DUAL || c0_staged < cin1)) {
-            // (requesting the coefficients together with the slice's data, one slice ahead, was measured on the same box: the 8 extra
-            // registers cost a wave of occupancy, the step went from 14.1 to 14.6 ms)
-            const float4 sc = ld4(a.in_scale + c0_staged + kc), sh = ld4(a.in_shift + c0_staged + kc);
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                if (okmask & (1u << i)) ra[i] = affine_relu(ra[i], sc, sh, a.relu_in);
-        } else if (a.relu_in && (!DUAL || c0_staged < cin1)) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                ra[i].x = relu1(ra[i].x); ra[i].y = relu1(ra[i].y); ra[i].z = relu1(ra[i].z); ra[i].w = relu1(ra[i].w);
-            }
-        }
-        if constexpr (NP == 0) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(As + (r0 + 32 * i) * ROWB) + kc, ra[i]);
-#pragma unroll
-            for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(Bs + (r0 + 32 * i) * ROWB) + kc, rb[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) store_split4(As + (r0 + 32 * i) * ROWB + kc * 2, ra[i]);
-#pragma unroll
-            for (int i = 0; i < RB3; ++i) st4(reinterpret_cast<float*>(Bs + w3_lds[i]), rb[i]);
-        }
-    };
-
-    int tap = 0, c0 = 0;
-    const int half = lane >> 5, l31 = lane & 31;
-    // f32: lane reads 4 consecutive k (16 B) of its half-wave per 8-k sub-step; split: 8 consecutive bf16 k (16 B) per 16-k step
-    const char* a_frag = As + (wm * 32 * TM + l31) * ROWB + 16 * half;
-    const char* b_frag = Bs + (wn * 32 * TN + l31) * ROWB + 16 * half;
-    auto advance = [&]() {
-        c0 += BK;
-        if (c0 == a.Cin) { c0 = 0; set_tap(++tap); }
-    };
-
-    if constexpr (SPLIT) {
-        const int per = (ksteps + (int)gridDim.z - 1) / (int)gridDim.z;
-        const int ks0 = (int)blockIdx.z * per, ks1 = ks0 + per < ksteps ? ks0 + per : ksteps;
-        if (ks0 < ks1) {       // (uniform per workgroup; an empty range stores a zero tile)
-            tap = ks0 / cslices;
-            c0 = (ks0 - tap * cslices) * BK;
-            set_tap(tap);
-            load_slice(c0);
-            store_slice();
-            __syncthreads();
-            for (int ks = ks0; ks < ks1; ++ks) {
-                const bool more = ks + 1 < ks1;
-                if (more) {
-                    advance();
-                    load_slice(c0);
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float4 fa[TM], fb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_frag + i * 32 * ROWB) + 8 * s);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_frag + j * 32 * ROWB) + 8 * s);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-                }
-                __syncthreads();
-                if (more) {
-                    store_slice();
-                    __syncthreads();
-                }
-            }
-        }
-        awr_conv_args b = a;      // raw partial sums: the epilogue proper runs in splitk_reduce_kernel
-        b.out = a.partial + (size_t)blockIdx.z * ((size_t)a.B * a.Hout * a.Wout * a.N);
-        b.bias = nullptr; b.out_scale = nullptr; b.out_shift = nullptr; b.res = nullptr; b.stats = nullptr; b.bnr_y = nullptr; b.bnr2_y = nullptr; b.stats2 = nullptr; b.relu_out = 0;
-        gemm_epilogue<TM, TN>(b, ph, acc, smem, M, tile_m, tile_n);
-        return;
-    }
-    set_tap(0);
-    epi_rows epre;
-    unsigned eoff[EPRE ? TM : 1][4];
-    if constexpr (EPRE) {
-        epi_row_offsets<TM>(a, ph, M, tile_m, eoff);
-        epi_fetch<TM, TN>(a, eoff, tile_n, 0, 0, epre);      // lands while the K loop runs
-    }
-    if constexpr (NP == 0) {
-        load_slice(0);
-        store_slice();
-        __syncthreads();
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const bool more = ks + 1 < ksteps;
-            if (more) {
-                advance();
-                if (AWR_PROBE != 1 && AWR_PROBE < 3) load_slice(c0);        // global loads in flight while the MFMAs below run
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float4 fa[TM], fb[TN];
-                if (AWR_PROBE < 4 || ks == 0) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_frag + i * 32 * ROWB) + 8 * s);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_frag + j * 32 * ROWB) + 8 * s);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = make_float4(1.f + ks, 2.f, 3.f, 4.f);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = make_float4(1.f, 2.f + ks, 3.f, 4.f);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-            }
-            if (AWR_PROBE < 2) {
-                __syncthreads();
-                if (more) {
-                    store_slice();
-                    __syncthreads();
-                }
-            } else if (AWR_PROBE < 4) {
-                __syncthreads();
-            }
-        }
-    } else {
-        // Split mode.  The bf16 MFMAs of a slice last about as long as cutting the next slice into its pieces, so that
-        // arithmetic has to run in the shadow of the MFMAs, not between them: the raw activation rows of slice k+1 are
-        // requested before the MFMAs of slice k start, have landed by the time the first half of those MFMAs has issued,
-        // and are cut into their pieces (fused affine + ReLU first) by VALU instructions that sit between the MFMAs of the
-        // second half in program order; what remains between the two barriers is 8- and 16-byte LDS stores.  Weight
-        // pieces need no arithmetic: they go registers -> LDS verbatim.
-        float4 r1[RA];
-        unsigned ok1 = 0;
-        int c1 = 0;
-        uint2 S[RA][3];
-        auto load_a = [&](float4 (&dst)[RA], int cc) {
-            const unsigned cb = (unsigned)cc * 4u;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) dst[i] = buf_ld4(rs_in, (tapmask & (1u << i)) ? a_off[i] + cb : OOB);
-        };
-        auto load_b = [&](int cc) {
-            const unsigned sb = wtap + (unsigned)(cc / BK) * (6u * BK);
-#pragma unroll
-            for (int i = 0; i < RB3; ++i) rb[i] = buf_ld4(rs_w3, w3_off[i] + sb);
-        };
-        const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();
-        // branch-free (it has to stay in the MFMAs' basic block): affine + ReLU on in-bounds rows, then the 3-way cut
-        auto split_rows = [&](const float4 (&src)[RA], unsigned okm, float4 sc, float4 sh, int i0, int i1) {
-#pragma unroll
-            for (int i = i0; i < i1; ++i) {
-                float4 v = src[i];
-                if constexpr (AFF) {
-                    const bool ok = okm & (1u << i);
-                    v.x = ok ? fmaxf(v.x * sc.x + sh.x, relu_lo) : 0.f; v.y = ok ? fmaxf(v.y * sc.y + sh.y, relu_lo) : 0.f;
-                    v.z = ok ? fmaxf(v.z * sc.z + sh.z, relu_lo) : 0.f; v.w = ok ? fmaxf(v.w * sc.w + sh.w, relu_lo) : 0.f;
-                }
-                unsigned h[4], m[4], l[4];
-                split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
-                S[i][0] = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-                S[i][1] = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-                S[i][2] = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
-            }
-        };
-        auto coef = [&](int cc, float4& sc, float4& sh) {
-            sc = make_float4(1, 1, 1, 1); sh = make_float4(0, 0, 0, 0);
-            if (a.in_scale) { sc = ld4(a.in_scale + cc + kc); sh = ld4(a.in_shift + cc + kc); }
-        };
-        auto store_sb = [&]() {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                char* d = As + (r0 + 32 * i) * ROWB + kc * 2;
-                *reinterpret_cast<uint2*>(d) = S[i][0];
-                *reinterpret_cast<uint2*>(d + 2 * BK) = S[i][1];
-                *reinterpret_cast<uint2*>(d + 4 * BK) = S[i][2];
-            }
-#pragma unroll
-            for (int i = 0; i < RB3; ++i) st4(reinterpret_cast<float*>(Bs + w3_lds[i]), rb[i]);
-        };
-        float4 sc, sh;
-        float4 r2[RA];
-        unsigned ok2 = 0;
-        int c2 = 0;
-        load_a(r1, 0); ok1 = tapmask; c1 = 0;
-        load_b(0);
-        coef(0, sc, sh);
-        split_rows(r1, ok1, sc, sh, 0, RA);
-        store_sb();
-        if (ksteps > 1) {            // slice 1: activation rows into r1, weight pieces into rb
-            advance();
-            load_a(r1, c0); ok1 = tapmask; c1 = c0;
-            load_b(c0);
-        }
-        __syncthreads();
-        // one basic block: fragment reads and MFMAs of the slice in LDS, the cut of the next slice inside the second half
-        auto multiply_and_cut = [&](const float4 (&rows)[RA], unsigned okm) {
-            bf16x8 fa[TM][3], fb[TN][3];
-            load_split_frags<TM, TN>(a_frag, b_frag, fa, fb);
-            mfma_split16<TM, TN, NP>(fa, fb, acc);
-            load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_split16<TM, TN, NP>(fa, fb, acc, [&](int q) {
-                if (q < RA) split_rows(rows, okm, sc, sh, q, q + 1);
-            });
-        };
-        // Activation rows travel two slices ahead in two register sets that swap roles every slice (the loop is unrolled
-        // by two, no register copies): the rows cut during slice k were requested during slice k-1.
-        int ks = 0;
-        for (; ks + 2 < ksteps; ks += 2) {
-            advance();
-            load_a(r2, c0); ok2 = tapmask; c2 = c0;        // slice ks+2
-            coef(c1, sc, sh);
-            multiply_and_cut(r1, ok1);                      // slice ks from LDS, cut slice ks+1 (r1)
-            __syncthreads();
-            store_sb();
-            load_b(c2);                                     // weight pieces of slice ks+2 (same tap state as r2)
-            __syncthreads();
-            const bool more3 = ks + 3 < ksteps;
-            if (more3) {
-                advance();
-                load_a(r1, c0); ok1 = tapmask; c1 = c0;    // slice ks+3
-            }
-            coef(c2, sc, sh);
-            multiply_and_cut(r2, ok2);                      // slice ks+1 from LDS, cut slice ks+2 (r2)
-            __syncthreads();
-            store_sb();
-            if (more3) load_b(c1);
-            __syncthreads();
-        }
-        if (ks + 1 < ksteps) {       // one slice left to stage (r1 holds it)
-            coef(c1, sc, sh);
-            multiply_and_cut(r1, ok1);
-            __syncthreads();
-            store_sb();
-            __syncthreads();
-        }
-        {   // last slice: nothing left to stage
-            bf16x8 fa[TM][3], fb[TN][3];
-            load_split_frags<TM, TN>(a_frag, b_frag, fa, fb);
-            mfma_split16<TM, TN, NP>(fa, fb, acc);
-            load_split_frags<TM, TN>(a_frag + 32, b_frag + 32, fa, fb);
-            mfma_split16<TM, TN, NP>(fa, fb, acc);
-        }
-    }
-    if constexpr (FUSE2) {
-        constexpr int P2 = BN + 4;                               // pitch of the intermediate tile (floats): rows 4 banks apart like LDK
-        float* const A2 = smem;                                  // [BM][P2]: relu(bn(conv + bias)), ALL BN channels of the tile's pixels
-        char* const B2 = smem_raw + BM * P2 * 4;                 // [BN][LDK]: one K-slice of w2; afterwards the epilogue's transpose tiles
-        __syncthreads();                                         // the phase-1 slices are dead
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * 32 * TN + j * 32 + l31;
-            const float b1 = a.bias ? a.bias[col] : 0.f, sc = a.out_scale ? a.out_scale[col] : 1.f, sh = a.out_shift ? a.out_shift[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[i][j][r] + b1) * sc + sh;
-                    if (a.relu_out) v = relu1(v);
-                    A2[(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * P2 + col] = v;
-                }
-        }
-        // second GEMM: K = the BN intermediate channels (A from LDS) followed by a.N1x channels of a second tensor at the same pixel
-        // (`in2`: the block input of a residual with a skip conv -- w2 rows are [W3 | Wskip]; A fragments straight from global memory, a
-        // lane's 16 bytes per 8-k sub-step: no staging buffer, the 52 KB of LDS and three workgroups per CU stay)
-        const int K2 = BN + a.N1x, nsl = K2 / BK, nsl_lds = BN / BK;
-        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, OOB);
-        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.N1x ? a.in2 : a.in, a.N1x ? (unsigned)M * (unsigned)a.N1x * 4u : 0u);
-        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 * TM + l31) * P2) * 4 + 16 * half;
-        const char* b2_frag = B2 + (wn * 32 * TN + l31) * ROWB + 16 * half;
-        unsigned x_off[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-            x_off[i] = m < M ? ((unsigned)m * (unsigned)a.N1x + 4u * half) * 4u : OOB;
-        }
-        awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
-        e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
-        // BN output channels at a time: exactly two passes (N == 2 BN), unrolled so that each epilogue is straight-line code with its own
-        // register allocation (inside a run-time loop the inlined epilogue cost 47 VGPRs and a wave of occupancy)
-        float4 rb2[RB], xa[TM][4];
-        auto load_b2 = [&](int hf, int s2) {
-            const unsigned row0 = (unsigned)(hf * BN + r0), k0 = (unsigned)(BK * s2 + kc);
-#pragma unroll
-            for (int i = 0; i < RB; ++i) rb2[i] = buf_ld4(rs_w2, ((row0 + 32u * i) * (unsigned)K2 + k0) * 4u);
-        };
-        auto load_x = [&](int s2) {       // the four 8-k sub-steps of slice s2 (>= nsl_lds) of this lane's rows
-            const unsigned kb = (unsigned)(BK * (s2 - nsl_lds)) * 4u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xa[i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
-        };
-        load_b2(0, 0);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int s2 = 0; s2 < nsl; ++s2) {
-                if (s2 >= nsl_lds) load_x(s2);      // (in flight across the barriers and the slice's LDS stores)
-                __syncthreads();             // first slice: the intermediate tile is complete / the transpose tiles are dead; later: the previous slice is
-#pragma unroll
-                for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(B2 + (r0 + 32 * i) * ROWB) + kc, rb2[i]);
-                __syncthreads();
-                if (s2 + 1 < nsl) load_b2(hf, s2 + 1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float4 fa[TM], fb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[i] = s2 < nsl_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + BK * s2 + 8 * s) : xa[i][s];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_frag + j * 32 * ROWB) + 8 * s);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-                }
-            }
-            if (hf == 0) load_b2(1, 0);      // (in flight under the first pass's epilogue)
-            gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
-        }
-        return;
-    }
-    if constexpr (EPRE) gemm_epilogue<TM, TN, true>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
-    else gemm_epilogue<TM, TN>(a, ph, acc, smem, M, tile_m, tile_n);
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS-DMA operand staging (round 4): `buffer_load_dwordx4 ... offen lds`
-// ------------------------------------------------------------------------------------------
-// The kernel above moves every operand global -> VGPR -> ds_write -> LDS: RA + RB float4 staging registers per thread and a store phase
-// between two barriers per K-slice.  Operands that need no arithmetic on the way in -- the packed weights always, the activation rows
-// whenever there is no fused input affine / ReLU (every materialised input: block inputs, all data-gradient inputs, the deconvs) -- can go
-// global -> LDS directly.  What the instruction dictates (MI355X_MICROARCH.md, probed by tools/probes/lds_dma_probe.hip):
-//   * the destination is wave-uniform base (M0) + 16 * lane: a wave instruction fills 1 KB of CONSECUTIVE LDS, so rows are unpadded
-//     (KB * 4 bytes) and the bank-conflict-free fragment reads come from an XOR swizzle of the 16-byte chunk index instead of the 36-float
-//     pitch: chunk c of row r sits at chunk c ^ swz(r), swz(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows (the sixteen
-//     lanes of a ds_read_b128 group then hit sixteen distinct 16-byte slots).  The swizzle goes on the SOURCE address (lane (row, c)
-//     fetches chunk c ^ swz(row)) and on the fragment READ, never on the destination;
-//   * the source offset is per lane and out-of-range offsets WRITE ZEROS: the OOB trick of the register path (padding taps, ragged rows)
-//     carries over unchanged;
-//   * completion is the issuing wave's vmcnt, visibility to the other waves the barrier behind it.
-// Pipeline: NBUF = 2 stages of KB floats of K in LDS; stage k + 1 is requested before the MFMAs of stage k and awaited behind them, ONE
-// barrier per stage, no LDS store phase, no staging registers.  KB = 32 doubles the LDS of a workgroup (64x128: 48 KB, three workgroups
-// per CU); KB = 16 keeps it (24 KB) with 64-byte rows.  AFF: a fused input affine / ReLU (never-materialised BatchNorm) is applied to the A
-// fragments between LDS and the matrix pipe (see the body), so those launches move both operands by DMA as well.
-// The instruction is issued from inline assembly: through the builtin, hipcc (ROCm 7.2) cannot tell which LDS bytes a DMA in flight will
-// overwrite and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- i.e. right behind the request, the load latency fully exposed
-// (seen in the ISA of the first version).  From assembly the compiler does not count the request at all: dma_wait() before the barrier is
-// ours to place; its own counted waits for ordinary loads can only over-wait (vmcnt retires in order).  M0 (the LDS base) is written in the
-// same statement that reads it and restored afterwards (cdna_hip_programming.md: M0 is compiler-reserved).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 make_rsrc_words(const void* p, unsigned bytes) {      // the same descriptor as make_rsrc, as four SGPR words
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    i32x4 r;
-    r.x = (int)(unsigned)u;
-    r.y = (int)((unsigned)(u >> 32) & 0xFFFFu);
-    r.z = (int)bytes;
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_uniform, unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_uniform)
-                 : "memory");
-}
-constexpr int AFF_MAXC = 512;      // channels of a fused input affine the LDS-DMA kernel keeps in its LDS coefficient table
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)reinterpret_cast<unsigned long long>(p);      // a generic pointer into LDS: aperture in the high word, LDS byte offset in the low one
-}
-// SW: 0 = mfma(A fragment, W fragment) (lane = channel, registers = pixels), 1 = operand roles swapped (lane = pixel, registers = channels: 16-byte
-// bounce rows), 2 = swapped and, for the PLAIN epilogue, stored straight from the accumulators (no LDS in the epilogue at all)
-// FUSE2 (round 5): the fused conv pair of conv_gemm_body (a.w2: conv2 3x3 -> bn3 -> ReLU -> conv3 1x1 + skip in one launch, inference) with the FIRST GEMM on
-// LDS-DMA staging -- that GEMM is 80 % of the pair's work and was the last big launch family still on the register-staged kernel.
-// POOL (FUSE2 only, round 5): the pair also writes the 2x2 / stride-2 max-pool of its output (awr_conv_args.pool_out).  A workgroup tile is then a 2D patch --
-// two image rows x BM / 2 columns (tile2d_pixel) -- so the two M-waves hold vertically adjacent row segments and the four pixels of every window meet in
-// the epilogue's own LDS tiles: the separate pooling pass that re-reads the full-resolution tensor (1.07 GB at 128x128 x 128 channels x batch 128)
-// disappears.
-template <int BM>
-__device__ __forceinline__ int tile2d_pixel(const awr_conv_args& a, int m) {
-    constexpr int CX = BM / 2;
-    const int t = m / BM, r = m - t * BM;
-    const int tpr = a.Wq / CX, tx = t % tpr, q = t / tpr, hy = a.Hq >> 1;
-    const int y2 = q % hy, b = q / hy;
-    return (b * a.Hq + 2 * y2 + r / CX) * a.Wq + tx * CX + (r % CX);
-}
-// epilogue of one output-channel half (hf) of the pair's second GEMM with the pool: bias2 (+ identity skip) -> full-resolution rows as usual, the final
-// values written back into the wave's transpose tile, and -- once both M-waves of a column are there -- the 2x2 windows (row pair = the two M-waves, column
-// pair = neighbouring tile rows) reduced in the SAME comparison order as maxpool_fwd_kernel (first maximum wins) and stored to pool_out.
-template <int TM, int TN>
-__device__ __forceinline__ void pair_pool_epilogue(const awr_conv_args& e, f32x16 (&acc)[TM][TN], float* smem, int M, int tile_m, int hf) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, CX = BM / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    const int c4 = lane & 7, rbase = lane >> 3;
-    float* const tbuf = smem + wave * (32 * LDK);
-    const unsigned obytes = (unsigned)((size_t)e.B * e.Hout * e.Wout * e.N * 4u);
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(e.out, obytes), rs_res = make_rsrc(e.res ? e.res : e.out, e.res ? obytes : 0u),
-                                 rs_pool = make_rsrc(e.pool_out, obytes / 4u);
-    // the pooled pixel this lane serves after the barrier: lanes of the two M-waves of a column = 128 = 16 pooled pixels x 8 channel quads
-    const int pl = wm * 64 + lane, ppx = pl >> 3, pc4 = pl & 7;
-    const int t = tile_m, tpr = e.Wq / CX, tx = t % tpr, q = t / tpr;      // q = b * (Hq / 2) + row pair: the pooled map's row index over the batch
-    const float* const t0 = smem + wn * (32 * LDK);                        // transpose tiles of the wm = 0 / wm = 1 waves of this column
-    const float* const t1 = smem + (2 + wn) * (32 * LDK);
-    __syncthreads();                    // every wave is done with the staged w2 slices
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n0 = hf * BN + wn * 32 * TN + j * 32 + 4 * c4;
-        const float4 bias = e.bias ? ld4(e.bias + n0) : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * half) * LDK + l31] = acc[i][j][r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int row = rbase + 8 * qq, m = tile_m * BM + wm * 32 * TM + i * 32 + row;
-                float4 v = ld4(tbuf + row * LDK + 4 * c4);
-                const unsigned off = m < M ? (unsigned)tile2d_pixel<BM>(e, m) * (unsigned)e.N * 4u + (unsigned)n0 * 4u : OOB;
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-                if (e.res) {
-                    const float4 rr = buf_ld4(rs_res, off);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                buf_st4(rs_out, off, v);
-                st4(tbuf + row * LDK + 4 * c4, v);       // the final value, for the windows
-            }
-            __syncthreads();                              // both row segments of the column are final
-            {
-                const float4 a0 = ld4(t0 + (2 * ppx) * LDK + 4 * pc4), a1 = ld4(t0 + (2 * ppx + 1) * LDK + 4 * pc4),
-                             b0 = ld4(t1 + (2 * ppx) * LDK + 4 * pc4), b1 = ld4(t1 + (2 * ppx + 1) * LDK + 4 * pc4);
-                float4 mx = a0;                           // window order (ky, kx) = (0,0) (0,1) (1,0) (1,1); `>` keeps the first maximum
-                mx.x = a1.x > mx.x ? a1.x : mx.x; mx.y = a1.y > mx.y ? a1.y : mx.y; mx.z = a1.z > mx.z ? a1.z : mx.z; mx.w = a1.w > mx.w ? a1.w : mx.w;
-                mx.x = b0.x > mx.x ? b0.x : mx.x; mx.y = b0.y > mx.y ? b0.y : mx.y; mx.z = b0.z > mx.z ? b0.z : mx.z; mx.w = b0.w > mx.w ? b0.w : mx.w;
-                mx.x = b1.x > mx.x ? b1.x : mx.x; mx.y = b1.y > mx.y ? b1.y : mx.y; mx.z = b1.z > mx.z ? b1.z : mx.z; mx.w = b1.w > mx.w ? b1.w : mx.w;
-                const int xp = tx * (CX / 2) + i * 16 + ppx;                              // pooled column; the pooled row over the batch is q
-                const int pn0 = hf * BN + wn * 32 * TN + j * 32 + 4 * pc4;
-                const bool ok = tile_m * BM < M;
-                buf_st4(rs_pool, ok ? ((unsigned)(q * (e.Wq / 2) + xp) * (unsigned)e.N + (unsigned)pn0) * 4u : OOB, mx);
-            }
-            __syncthreads();                              // the tiles are rewritten by the next (i, j)
-        }
-    }
-}
-template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0, bool FUSE2 = false, bool POOL = false>
-__device__ __forceinline__ void conv_gemm_dma_body(const awr_conv_args& a) {
-    static_assert(!POOL || FUSE2, "POOL belongs to the fused pair");
-    static_assert((KB == 16 || KB == 32) && (NBUF == 1 || NBUF == 2 || NBUF == 4), "stage shape");
-    static_assert(AFF != 4 || (KB == 16 && NBUF == 2), "the in-LDS affine pass belongs to the shipped stage shape");
-    static_assert(NBUF != 4 || (KB == 16 && !ACCB && !FUSE2), "deep pipeline: 16-float stages, ordered accumulation");
-    static_assert(!FUSE2 || (AFF == 0 && !EPRE && !DUAL && !ACCB && SW == 0), "FUSE2: plain first GEMM");
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int ROWB = KB * 4;                  // unpadded LDS row (bytes)
-    constexpr int LPR = KB / 4;                   // 16-byte chunks (= staging lanes) per row
-    constexpr int RPP = 256 / LPR;                // rows covered by one pass of the 256 threads (32 | 64); one pass = 4 KB of LDS
-    constexpr int RA = BM / RPP, RB = BN / RPP;   // DMA instructions per thread and stage
-    constexpr int AROWS = AFF == 2 ? 2 * BM : BM; // AFF == 2: the rows of TWO tensors (g, y) per A row
-    constexpr int STAGE = (AROWS + BN) * ROWB;
-    constexpr bool DIRECT = SW == 2 && EM == 1;
-    constexpr int EPI = DIRECT ? 0 : 4 * 32 * LDK * 4;         // the epilogue's four 32x36 transpose tiles
-    // FUSE2: [stage buffers, later the intermediate tile BM x (BN + 4)][w2 K-slices BN x 36, then the transpose tiles]
-    constexpr int F2A = BM * (BN + 4) * 4, F2B = BN * LDK * 4 > EPI ? BN * LDK * 4 : EPI;
-    constexpr int BUFS = FUSE2 ? (NBUF * STAGE > F2A ? NBUF * STAGE : F2A) + F2B : (NBUF * STAGE > EPI ? NBUF * STAGE : EPI);
-    static_assert(RA >= 1 && RB >= 1, "tile too small for the stage shape");
-    // AFF: the coefficient vectors of the fused input arithmetic behind the stage buffers (<= AFF_MAXC channels; the launcher checks)
-    __shared__ __attribute__((aligned(16))) char smem_raw[BUFS + (AFF == 2 ? 4 : AFF ? 2 : 0) * AFF_MAXC * 4];
-    float* const smem = reinterpret_cast<float*>(smem_raw);
-
-    const awr_phase& ph = a.ph[blockIdx.y];
-    const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = FUSE2 ? 1 : (a.N + BN - 1) / BN;      // (FUSE2: a.N is the second conv's channel count; the first has BN)
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    // staging role: row r0 (+ RPP per pass) of the tile, LDS chunk cl of that row, which holds SOURCE chunk cl ^ swz(row)
-    const int r0 = tid / LPR, cl = tid % LPR;
-    const int kc = (cl ^ (KB == 32 ? (r0 >> 1) & 7 : (r0 >> 2) & 3)) * 4;      // this thread's 4 consecutive k inside the stage
-
-    int a_iy[RA], a_ix[RA];
-    unsigned a_img[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = tile_m * BM + r0 + RPP * i;
-        if (m < M) {
-            int qx, qy, b;
-            decode_row(a, POOL ? tile2d_pixel<BM>(a, m) : m, qx, qy, b);
-            a_iy[i] = qy * a.si;
-            a_ix[i] = qx * a.si;
-            a_img[i] = (unsigned)b * a.Hin * a.Win;
-        } else {
-            a_iy[i] = -(1 << 20);  // always out of bounds -> zeros
-            a_ix[i] = 0;
-            a_img[i] = 0;
-        }
-    }
-    // DUAL (single tap): channels [0, cin1) of the K extent come from `in` (with the fused input affine, if any), the rest from `in2` (plain):
-    // the hourglass residual's conv3 + skip_layer in one launch, as in conv_gemm_body
-    const int cin1 = DUAL ? a.Cin1 : a.Cin;
-    const i32x4 rw_in = make_rsrc_words(a.in, (unsigned)a.B * a.Hin * a.Win * cin1 * 4u), rw_w = make_rsrc_words(a.w, OOB);
-    const i32x4 rw_in2 = make_rsrc_words(DUAL ? a.in2 : AFF == 2 ? a.in_bnb_y : a.in, (unsigned)a.B * a.Hin * a.Win * (DUAL ? a.Cin - cin1 : cin1) * 4u);
-    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;      // this wave's 1 KB piece of every 4 KB pass
-    unsigned w_off[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) w_off[i] = ((unsigned)(tile_n * BN + r0 + RPP * i) * a.T * a.Cin + kc) * 4u;
-
-    // AFF: the fused input affine + ReLU (a BatchNorm output that is never written to HBM) is applied to the A FRAGMENTS on their way from LDS
-    // to the matrix pipe, not to the rows on their way into LDS: both operands travel by DMA, and the arithmetic (a multiply-add and a clamp
-    // per element, every element twice -- once per N-wave) issues between the 64-cycle MFMAs, where the wave's VALU slots are idle anyway.
-    // Padding must stay zero THROUGH the affine: a lane knows whether its fragment rows are inside the image for the current tap.
-    // AFF == 2 (data gradients): the input IS a BatchNorm backward that is never materialised.  d(y) = a1 g + a2 (y - mean) + a3 per channel, g =
-    // the (masked) gradient w.r.t. the BatchNorm's output, y its input, (a1, a2, a3, mean) from awr_bn_bwd_finalize_lin: the rows of BOTH tensors
-    // are staged (same pixel, same channel chunk, same padding rule) and the two multiply-adds run on the fragments -- the
-    // awr_bn_bwd_apply pass between two dependent data-gradient GEMMs leaves the critical chain.
-    float* const aff_tab = reinterpret_cast<float*>(smem_raw + BUFS);
-    // AFF == 4 (round 5): the same affine + ReLU as an IN-LDS pass -- the thread that requested a 16-byte chunk rewrites it in place once its own
-    // DMA has landed (behind its vmcnt wait, in front of the stage's barrier): once per element instead of once per (element, N-wave), off the
-    // fragment -> MFMA dependency chain, the padding rule a per-row skip (a row the request declared out of range holds the zeros it must keep).
-    constexpr bool FRAG_AFF = AFF == 1 || AFF == 2 || AFF == 3;      // arithmetic on the fragments
-    int f_iy[FRAG_AFF ? TM : 1], f_ix[FRAG_AFF ? TM : 1];
-    unsigned fmask = 0;
-    if constexpr (AFF) {
-        for (int c = tid * 4; c < cin1; c += 1024) {
-            if constexpr (AFF == 2) {
-                st4(aff_tab + c, ld4(a.in_bnb_coef + c));
-                st4(aff_tab + AFF_MAXC + c, ld4(a.in_bnb_coef + a.Cin + c));
-                st4(aff_tab + 2 * AFF_MAXC + c, ld4(a.in_bnb_coef + 2 * a.Cin + c));
-                st4(aff_tab + 3 * AFF_MAXC + c, ld4(a.in_bnb_coef + 3 * a.Cin + c));
-            } else {
-                st4(aff_tab + c, a.in_scale ? ld4(a.in_scale + c) : make_float4(1, 1, 1, 1));
-                st4(aff_tab + AFF_MAXC + c, a.in_shift ? ld4(a.in_shift + c) : make_float4(0, 0, 0, 0));
-            }
-        }
-        if constexpr (FRAG_AFF) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-                f_iy[i] = -(1 << 20);
-                f_ix[i] = 0;
-                if (m < M) {
-                    int qx, qy, b;
-                    decode_row(a, m, qx, qy, b);
-                    f_iy[i] = qy * a.si;
-                    f_ix[i] = qx * a.si;
-                }
-            }
-        } else {
-            __syncthreads();      // the first stage is rewritten in front of its barrier: the coefficient table has to be complete
-        }
-    }
-    float f_hi[FRAG_AFF ? TM : 1];      // upper clamp bound of the lane's fragment rows for the current tap: +inf inside the image, 0 on padding rows
-    auto set_ftap = [&](int tap) {
-        if constexpr (FRAG_AFF) {
-            const int tp = ph.tap[tap];
-            const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
-            fmask = 0;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int iy = f_iy[i] + dy, ix = f_ix[i] + dx;
-                const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-                fmask |= ok ? (1u << i) : 0u;
-                f_hi[i] = ok ? __builtin_inff() : 0.f;
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ACCB (awr_conv_args.accum = 1): blocked accumulation.  The matrix instruction adds onto its accumulator operand, so a K extent of 576 ...
-    // 4608 terms is ONE rounding chain; every ACC_BLOCK k the running sum moves into a second accumulator set and the chain restarts
-    // (chains of ACC_BLOCK + K / ACC_BLOCK terms): a conv's error against float64 falls to torch-CPU's.
-    constexpr int ACC_BLOCK = 128, ACC_STAGES = ACC_BLOCK / KB;
-    f32x16 tot[ACCB ? TM : 1][ACCB ? TN : 1];
-    int since = 0;
-    if constexpr (ACCB) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
-    }
-    auto fold = [&]() {
-        if constexpr (ACCB) {
-            if (++since == ACC_STAGES) {
-                since = 0;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
-            }
-        }
-    };
-
-    const int cslices = a.Cin / KB;
-    const int ksteps = ph.ntaps * cslices;
-    unsigned a_off[RA], a_off2[DUAL ? RA : 1], tapmask = 0, wtap = 0;
-    auto set_tap = [&](int tap) {
-        const int tp = ph.tap[tap];
-        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
-        tapmask = 0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            a_off[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * cin1 + kc) * 4u;
-            if constexpr (DUAL) a_off2[i] = ((a_img[i] + (unsigned)(iy * a.Win + ix)) * (a.Cin - cin1) + kc) * 4u;
-            tapmask |= ok ? (1u << i) : 0u;
-        }
-        wtap = (unsigned)wt * a.Cin * 4u;
-    };
-    // request stage (tap state, c0) into LDS stage buffer `buf`: nothing here waits for memory
-    // (`live` = false: a stage beyond the K extent, requested by the last trip of the pipelined loop -- every source out of range, zeros)
-    [[maybe_unused]] int probe_reqs = 0;
-    auto issue = [&](int c0, int buf, bool live = true) {
-        const unsigned cb = (unsigned)c0 * 4u;
-        const unsigned As = lds0 + (unsigned)(buf * STAGE), Bs = As + (unsigned)(AROWS * ROWB);
-        const bool first_req = (AWR_DMA_PROBE & 3) ? (a.B < 0 || probe_reqs++ == 0) : true;      // (probe builds: only the first stage's requests reach memory)
-        const unsigned tm_ = (live && ((AWR_DMA_PROBE & 1) == 0 || first_req)) ? tapmask : 0u;
-        if ((AWR_DMA_PROBE & 2) && !first_req) live = false;
-        if (DUAL && c0 >= cin1) {        // (wave-uniform) this stage comes from the second tensor
-            const unsigned cb2 = (unsigned)(c0 - cin1) * 4u;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) dma16(rw_in2, As + i * 4096u, (tm_ & (1u << i)) ? a_off2[DUAL ? i : 0] + cb2 : OOB);
-        } else {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) dma16(rw_in, As + i * 4096u, (tm_ & (1u << i)) ? a_off[i] + cb : OOB);
-            if constexpr (AFF == 2) {
-#pragma unroll
-                for (int i = 0; i < RA; ++i) dma16(rw_in2, As + (unsigned)(BM * ROWB) + i * 4096u, (tm_ & (1u << i)) ? a_off[i] + cb : OOB);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) dma16(rw_w, Bs + i * 4096u, live ? w_off[i] + (wtap + cb) : OOB);
-    };
-
-    // fragment reads: lane (l31, half) wants chunk 2 s + half of its rows for sub-step s; physically chunk (2 s + half) ^ swz(l31)
-    // (the wave / tile row offsets are multiples of 32: they do not change swz)
-    const int fswz = KB == 32 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
-    const char* const a_row = smem_raw + (wm * 32 * TM + l31) * ROWB;
-    const char* const b_row = smem_raw + AROWS * ROWB + (wn * 32 * TN + l31) * ROWB;
-    int ctap = 0, cc0 = 0;      // the stage the MFMAs are at (the requests run one stage ahead)
-    // MASKED = false (AFF == 3, chosen by the launcher for single-tap launches: a 1x1 conv has no padding): the padding selects -- four per
-    // fragment float4, half of the fragment-side arithmetic's measured cost (profiles/r04_microbench_affine_probe.txt) -- are compiled out.
-    // (A run-time fast path for fully valid taps was built too: two copies of the stage behind a wave-uniform branch cost 30-70 registers --
-    // the allocator keeps both arms' accumulator copies -- and a 3x3 tile of 64 consecutive pixels spans whole image rows anyway, so only
-    // its dx = 0 taps would ever qualify.)
-    constexpr bool MASKED = AFF == 1 || AFF == 2;
-    auto compute = [&](int buf) {
-        const bool aff_stage = AFF != 0 && (!DUAL || cc0 < cin1);       // (wave-uniform)
-#pragma unroll
-        for (int s = 0; s < KB / 8; ++s) {
-            const int fo = buf * STAGE + (((2 * s + half) ^ fswz) << 4);
-            float4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = ld4(reinterpret_cast<const float*>(a_row + fo + i * 32 * ROWB));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b_row + fo + j * 32 * ROWB));
-            if constexpr (AFF == 2) {
-                const float4 k1 = ld4(aff_tab + cc0 + 8 * s + 4 * half), k2 = ld4(aff_tab + AFF_MAXC + cc0 + 8 * s + 4 * half),
-                             k3 = ld4(aff_tab + 2 * AFF_MAXC + cc0 + 8 * s + 4 * half), mu = ld4(aff_tab + 3 * AFF_MAXC + cc0 + 8 * s + 4 * half);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const bool ok = !MASKED || (fmask & (1u << i));
-                    const float4 g = fa[i], y = ld4(reinterpret_cast<const float*>(a_row + BM * ROWB + fo + i * 32 * ROWB));
-                    // (y - mean first, like the apply kernel: a nearly constant channel would cancel catastrophically in a2 y + a3')
-                    fa[i].x = ok ? g.x * k1.x + ((y.x - mu.x) * k2.x + k3.x) : 0.f; fa[i].y = ok ? g.y * k1.y + ((y.y - mu.y) * k2.y + k3.y) : 0.f;
-                    fa[i].z = ok ? g.z * k1.z + ((y.z - mu.z) * k2.z + k3.z) : 0.f; fa[i].w = ok ? g.w * k1.w + ((y.w - mu.w) * k2.w + k3.w) : 0.f;
-                }
-            } else if constexpr (AFF == 1 || AFF == 3) {
-                if (aff_stage) {
-                    const float4 sc = ld4(aff_tab + cc0 + 8 * s + 4 * half), sh = ld4(aff_tab + AFF_MAXC + cc0 + 8 * s + 4 * half);
-                    // clamp(x, lo, hi) with (lo, hi) = (0 | -inf, +inf) on rows inside the image and (0, 0) on padding rows: the ReLU and the
-                    // padding rule in ONE v_med3 per element, bounds chosen once per tap (set_ftap) -- no compare, no select per element
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const float hi = MASKED ? f_hi[MASKED ? i : 0] : __builtin_inff(), lo = a.relu_in ? 0.f : -hi;      // (padding rows: hi = 0, so lo = 0 either way)
-                        float4 v = fa[i];
-                        fa[i].x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, lo, hi); fa[i].y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, lo, hi);
-                        fa[i].z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, lo, hi); fa[i].w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, lo, hi);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = SW ? __builtin_amdgcn_mfma_f32_32x32x2f32((&fb[j].x)[k], (&fa[i].x)[k], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (FRAG_AFF) {
-            cc0 += KB;
-            if (cc0 == a.Cin) { cc0 = 0; if (++ctap < ph.ntaps) set_ftap(ctap); }
-        }
-        fold();
-    };
-    // AFF == 4: rewrite this thread's own chunks of the stage it has just seen land (stage at channel offset c0s of the CURRENT tap state)
-    const float aff_lo = a.relu_in ? 0.f : -__builtin_inff();
-    auto rewrite = [&](int buf, int c0s) {
-        if constexpr (AFF == 4) {
-            if (DUAL && c0s >= cin1) return;       // (wave-uniform) the second tensor of a two-tensor K extent is plain
-            const float4 sc = ld4(aff_tab + c0s + kc), sh = ld4(aff_tab + AFF_MAXC + c0s + kc);
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                if (tapmask & (1u << i)) {
-                    float* p = reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16);
-                    float4 v = ld4(p);
-                    v.x = __builtin_amdgcn_fmed3f(v.x * sc.x + sh.x, aff_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * sc.y + sh.y, aff_lo, __builtin_inff());
-                    v.z = __builtin_amdgcn_fmed3f(v.z * sc.z + sh.z, aff_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * sc.w + sh.w, aff_lo, __builtin_inff());
-                    st4(p, v);
-                }
-            }
-        }
-    };
-    int tap = 0, c0 = 0;
-    auto advance = [&]() {
-        c0 += KB;
-        if (c0 == a.Cin) { c0 = 0; if (++tap < ph.ntaps) set_tap(tap); }
-    };
-
-    set_tap(0);
-    set_ftap(0);
-    epi_rows epre;
-    unsigned eoff[EPRE && !DIRECT ? TM : 1][4], eoffd[EPRE && DIRECT ? TM : 1];
-    if constexpr (EPRE && DIRECT) {
-        epi_row_offsets_direct<TM>(a, ph, M, tile_m, eoffd);
-        epi_fetch_direct<TM, TN>(a, eoffd, tile_n, 0, 0, epre);
-    } else if constexpr (EPRE) {
-        epi_row_offsets<TM>(a, ph, M, tile_m, eoff);
-        epi_fetch<TM, TN>(a, eoff, tile_n, 0, 0, epre);      // lands while the K loop runs
-    }
-    // stage_done: everything this wave asked for has landed (its own vmcnt), then the barrier: every wave's pieces are visible and every
-    // wave is done reading the stage that is requested next.  The scheduling fence keeps the MFMAs of the stage in front of the wait.
-    auto stage_done = [&](int buf = 0, int c0s = 0) {      // (buf, c0s): the stage that was requested last -- AFF == 4 rewrites it before the barrier
-        __builtin_amdgcn_sched_barrier(0);
-        dma_wait();
-        rewrite(buf, c0s);
-        __syncthreads();
-    };
-    if constexpr (NBUF == 4) {
-        // DEEP pipeline (round 5) for launches that cannot fill the chip (<= 2 workgroups per CU: low batch, the 4x4 ... 16x16 Hourglass levels, layer4):
-        // with one or two waves per SIMD nobody hides a stage's load latency (~1-2 us against 0.2 us of MFMAs per 16-float stage), so a workgroup
-        // keeps THREE stages in flight in four buffers -- the oldest is awaited with a COUNTED wait (vmcnt retires in order: at most the two younger
-        // stages' requests may still be outstanding), one barrier per stage as before.  Stages requested beyond the K extent come from nowhere (zeros
-        // nobody multiplies): the count stays constant through the tail; they are drained before the epilogue reuses the buffers.
-        constexpr int PER = RA * (AFF == 2 ? 2 : 1) + RB;      // DMA instructions per thread and stage
-        issue(0, 0);
-        advance(); issue(c0, 1, 1 < ksteps);
-        advance(); issue(c0, 2, 2 < ksteps);
-        for (int ks = 0; ks < ksteps; ks += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");      // stage ks + j has landed (this wave's share)
-                __syncthreads();                                                    // ... everybody's; and buffer (j + 3) % 4 (stage ks + j - 1) is free
-                advance(); issue(c0, (j + 3) & 3, ks + j + 3 < ksteps);
-                if (ks + j < ksteps) compute(j);
-            }
-        }
-        dma_wait();      // (the surplus requests of the tail: the epilogue's transpose tiles alias the stage buffers)
-    } else if constexpr (NBUF == 2) {
-        issue(0, 0);
-        stage_done(0, 0);
-        // unrolled by two: the stage buffer is a compile-time constant in every LDS address
-#ifndef AWR_GEMM_LOOP_NOEXITS
-        int ks = 0;
-        for (; ks + 2 <= ksteps; ks += 2) {
-            advance(); issue(c0, 1);      // (ks + 1 < ksteps holds here)
-            compute(0);
-            stage_done(1, c0);
-            const bool more = ks + 2 < ksteps;
-            if (more) { advance(); issue(c0, 0); }
-            compute(1);
-            if (more) stage_done(0, c0);
-        }
-        if (ks < ksteps) compute(0);      // odd stage count: the last stage sits in buffer 0
-#else
-        // study build: whole pairs of stages and nothing conditional inside the trip (the stages requested beyond the K extent come from nowhere:
-        // zeros) -- what took 30-60 registers off the weight-gradient kernels takes 4-10 off this one (104 -> 94 for the plain 128x128 tile),
-        // isolated launches +-2 % either way, the step 0.5 % slower (profiles/r04_loop_exits.txt)
-        for (int ks = 0; ks < ksteps; ks += 2) {
-            advance(); issue(c0, 1, ks + 1 < ksteps); compute(0); stage_done();
-            advance(); issue(c0, 0, ks + 2 < ksteps); compute(1); stage_done();
-        }
-#endif
-    } else {
-        issue(0, 0);
-        stage_done(0, 0);
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const bool more = ks + 1 < ksteps;
-            compute(0);
-            if (more) {
-                __syncthreads();
-                advance();
-                issue(c0, 0);
-                stage_done();
-            }
-        }
-    }
-    if constexpr (ACCB) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
-    }
-    if constexpr (FUSE2) {
-        // second GEMM: the tile (all BN channels of its BM pixels) -> bias / folded BatchNorm / ReLU in registers -> LDS as the A operand of the 1x1
-        // conv3 (w2 [N][BN + N1x]), N = 2 BN in two unrolled passes.  Its weight operand travels by LDS-DMA as well (round 5): 16-float stages,
-        // double-buffered in the region the epilogue's transpose tiles use afterwards; the block input's channels of a skip conv (N1x) come from
-        // global memory one stage ahead in two register sets.
-        constexpr int P2 = BN + 4, B2STAGE = BN * 64, RB2 = BN / 64;
-        float* const A2 = smem;
-        char* const B2 = smem_raw + (NBUF * STAGE > F2A ? NBUF * STAGE : F2A);
-        static_assert(2 * B2STAGE <= F2B, "the two w2 stages fit the transpose-tile region");
-        __syncthreads();                                         // the stage buffers are dead
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * 32 * TN + j * 32 + l31;
-            const float b1 = a.bias ? a.bias[col] : 0.f, sc = a.out_scale ? a.out_scale[col] : 1.f, sh = a.out_shift ? a.out_shift[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[i][j][r] + b1) * sc + sh;
-                    if (a.relu_out) v = relu1(v);
-                    A2[(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * P2 + col] = v;
-                }
-        }
-        const int K2 = BN + a.N1x, nst = K2 / 16, nst_lds = BN / 16;      // 16-float stages of the second K extent; the first nst_lds read A2
-        const i32x4 rw_w2 = make_rsrc_words(a.w2, OOB);
-        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.N1x ? a.in2 : a.in, a.N1x ? (unsigned)M * (unsigned)a.N1x * 4u : 0u);
-        const char* a2_frag = reinterpret_cast<const char*>(A2) + ((wm * 32 * TM + l31) * P2) * 4 + 16 * half;
-        const char* b2_row = B2 + (wn * 32 * TN + l31) * 64;
-        const unsigned ldsB = lds_addr(B2) + (unsigned)wave * 1024u;
-        unsigned x_off[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = tile_m * BM + wm * 32 * TM + i * 32 + l31;
-            x_off[i] = m < M ? ((unsigned)(POOL ? tile2d_pixel<BM>(a, m) : m) * (unsigned)a.N1x + 4u * half) * 4u : OOB;
-        }
-        awr_conv_args e = a;                                      // the second conv's epilogue: its bias and the residual; no affine, no ReLU
-        e.bias = a.bias2; e.out_scale = nullptr; e.out_shift = nullptr; e.relu_out = 0;
-        float4 xa[2][TM][2];
-        auto issue2 = [&](int hf, int st, int buf) {      // stage st of output half hf: rows r0 (+ 64 per pass) of w2, source chunk kc (the stage-1 roles)
-#pragma unroll
-            for (int i = 0; i < RB2; ++i)
-                dma16(rw_w2, ldsB + (unsigned)(buf * B2STAGE) + i * 4096u, (((unsigned)(hf * BN + r0 + 64 * i)) * (unsigned)K2 + (unsigned)(16 * st + kc)) * 4u);
-        };
-        auto load_x = [&](int st, int set) {
-            const unsigned kb = (unsigned)(16 * (st - nst_lds)) * 4u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) xa[set][i][q] = buf_ld4(rs_x, x_off[i] == OOB ? OOB : x_off[i] + kb + 32u * q);
-        };
-        auto compute2 = [&](int st, int buf, int set) {
-            const bool from_lds = st < nst_lds;      // (wave-uniform)
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const int fo = buf * B2STAGE + (((2 * sb + half) ^ fswz) << 4);
-                float4 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = from_lds ? ld4(reinterpret_cast<const float*>(a2_frag + i * 32 * P2 * 4) + 16 * st + 8 * sb) : xa[set][i][sb];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = ld4(reinterpret_cast<const float*>(b2_row + fo + j * 32 * 64));
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&fa[i].x)[k], (&fb[j].x)[k], acc[i][j], 0, 0, 0);
-            }
-        };
-        auto landed = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            dma_wait();
-            __syncthreads();
-        };
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            __syncthreads();             // first pass: the intermediate tile is complete; second: the first pass's transpose tiles are dead
-            issue2(hf, 0, 0);
-            landed();
-            for (int st = 0; st < nst; st += 2) {      // (K2 is a multiple of 32: an even number of stages)
-                issue2(hf, st + 1, 1);
-                if (st + 1 >= nst_lds) load_x(st + 1, 1);
-                compute2(st, 0, 0);
-                landed();
-                const bool more = st + 2 < nst;
-                if (more) {
-                    issue2(hf, st + 2, 0);
-                    if (st + 2 >= nst_lds) load_x(st + 2, 0);
-                }
-                compute2(st + 1, 1, 1);
-                if (more) landed();
-            }
-            if constexpr (POOL) pair_pool_epilogue<TM, TN>(e, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
-            else gemm_epilogue<TM, TN>(e, ph, acc, reinterpret_cast<float*>(B2), M, tile_m, hf);
-        }
-        return;
-    }
-    if constexpr (DIRECT) {
-        if constexpr (EPRE) gemm_epilogue_direct<TM, TN, true>(a, ph, acc, M, tile_m, tile_n, &epre, eoffd);
-        else gemm_epilogue_direct<TM, TN, false>(a, ph, acc, M, tile_m, tile_n);
-    } else {
-        if constexpr (EPRE) gemm_epilogue<TM, TN, true, EM, SW != 0>(a, ph, acc, smem, M, tile_m, tile_n, &epre, eoff);
-        else gemm_epilogue<TM, TN, false, EM, SW != 0>(a, ph, acc, smem, M, tile_m, tile_n);
-    }
-}
-template <int TM, int TN, int KB, int NBUF, int AFF, bool EPRE = false, int EM = 0, bool DUAL = false, bool ACCB = false, int SW = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_kernel(const awr_conv_args a) {
-    conv_gemm_dma_body<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, SW>(a);
-}
-template <int TM, int TN, bool POOL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_dma_pair_kernel(const awr_conv_args a) {
-    conv_gemm_dma_body<TM, TN, 16, 2, 0, false, 1, false, false, 0, true, POOL>(a);
-}
-
-// ------------------------------------------------------------------------------------------
-// Split-operand mode on LDS-DMA (round 5): BOTH operands arrive pre-cut
-// ------------------------------------------------------------------------------------------
-// conv_gemm_body<NP = 6> cuts every activation row into its three bf16 pieces while staging it -- ~90 VALU instructions per slice that have to hide
-// between bf16 MFMAs a third as long as the FP32 ones, once per (element, tap, column tile).  Here the PRODUCER has cut the tensor once
-// (awr_conv_args.in_split: the image awr_split_act / an epilogue's out_split wrote -- [pixel][Cin / 32][h | m | l][32] bf16, 6 bytes per element, the
-// format of the weights' split image), and both operands go global -> LDS by `buffer_load_dwordx4 ... lds` verbatim: no staging registers, no
-// arithmetic in the K loop but fragment reads and matrix instructions.
-//   * Stage = 16 k: per row three planes x two 16-byte chunks (k 0-7, k 8-15) = 96 bytes; two stages in LDS (128x128 tile: 2 x 24 KB).
-//   * LDS image: blocks of 16 rows, chunk-column-major inside a block -- slot(r, c) = (r / 16) * 96 + c * 16 + r % 16 (16-byte slots).  A
-//     ds_read_b128 lane group ({0-3, 12-15, 20-27} etc., MI355X_MICROARCH.md LDS) reads one chunk column c of sixteen rows that are distinct mod 16
-//     in two adjacent blocks (96 = 0 mod 16): sixteen distinct slots, conflict-free, without a swizzle -- 96-byte rows have no power-of-two XOR.
-//   * The DMA destination is lane-linear (M0 + 16 lane): wave instruction n fills slots [64 n, 64 n + 64) = four chunk columns of sixteen rows,
-//     i.e. sixteen 64-byte runs per instruction -- the access shape of the FP32 kernel's 16-float stages.  Out-of-range sources (padding taps,
-//     ragged rows) land zeros, and a zero has zero pieces.
-//   * Instructions are dealt round-robin to the four waves; which rows a lane serves is fixed for the launch (per-tap: one bounds test and one
-//     base offset per served row).
-template <int TM, int TN, int EM>
-__device__ __forceinline__ void conv_gemm_sdma_body(const awr_conv_args& a) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int CPR = 6;                              // 16-byte chunks per row and stage
-    constexpr int NINSTR = (BM + BN) * CPR / 64;        // wave-level DMA instructions per stage
-    constexpr int NA = BM * CPR / 64;                   // ... of which the first NA fill the activation rows
-    constexpr int NI = (NINSTR + 3) / 4;                // per wave
-    constexpr int STAGE = (BM + BN) * CPR * 16;
-    constexpr int EPI = 4 * 32 * LDK * 4;               // the epilogue's four 32x36 transpose tiles
-    constexpr int BUFS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-    __shared__ __attribute__((aligned(16))) char smem_raw[BUFS];
-    float* const smem = reinterpret_cast<float*>(smem_raw);
-
-    const awr_phase& ph = a.ph[blockIdx.y];
-    const int M = a.B * a.Hq * a.Wq;
-    const int tilesN = (a.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = wg / tilesN, tile_n = wg - tile_m * tilesN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int cslices = a.Cin / BK;                     // 192-byte slices per (row, tap)
-
-    // the rows / chunks this lane serves: instruction n = 4 i + wave fills slots [64 n, 64 n + 64)
-    int s_iy[NI], s_ix[NI];
-    unsigned s_img[NI], s_c[NI], s_off[NI];
-    unsigned okmask = 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int n = 4 * i + wave;
-        const int slot = 64 * n + lane, blk = slot / 96, w = slot - blk * 96, c = w >> 4, r = blk * 16 + (w & 15);
-        s_c[i] = (unsigned)((c >> 1) * 64 + (c & 1) * 16);      // byte offset of chunk c in the slice's first 16-k half
-        s_iy[i] = -(1 << 20); s_ix[i] = 0; s_img[i] = 0; s_off[i] = OOB;
-        if (n < NA) {                                            // an activation row: gathered, tap-dependent
-            const int m = tile_m * BM + r;
-            if (m < M) {
-                int qx, qy, b;
-                decode_row(a, m, qx, qy, b);
-                s_iy[i] = qy * a.si; s_ix[i] = qx * a.si; s_img[i] = (unsigned)b * a.Hin * a.Win;
-            }
-        } else if (n < NINSTR) {                                 // a weight row: [n][tap][slice][192 B]
-            s_off[i] = (unsigned)(tile_n * BN + (r - BM)) * (unsigned)a.T * (unsigned)cslices * 192u + s_c[i];
-        }
-    }
-    const i32x4 rw_in = make_rsrc_words(a.in_split, (unsigned)a.B * a.Hin * a.Win * a.Cin * 6u), rw_w = make_rsrc_words(a.w_split, OOB);
-    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
-    unsigned wtap = 0;
-    auto set_tap = [&](int tap) {
-        const int tp = ph.tap[tap];
-        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff), wt = tp >> 16;
-        okmask = 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (4 * i + wave < NA) {       // (wave-uniform)
-                const int iy = s_iy[i] + dy, ix = s_ix[i] + dx;
-                const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-                s_off[i] = (s_img[i] + (unsigned)(iy * a.Win + ix)) * (unsigned)cslices * 192u + s_c[i];
-                okmask |= ok ? (1u << i) : 0u;
-            }
-        }
-        wtap = (unsigned)wt * (unsigned)cslices * 192u;
-    };
-    // request the stage (current tap, slice sl, 16-k half t) into stage buffer `buf`
-    auto issue = [&](int sl, int t, int buf, bool live = true) {
-        const unsigned kb = (unsigned)sl * 192u + (unsigned)t * 32u;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = 4 * i + wave;
-            if (n < NINSTR) {              // (wave-uniform)
-                const unsigned dst = lds0 + (unsigned)(buf * STAGE) + (unsigned)i * 4096u;
-                if (n < NA) dma16(rw_in, dst, (live && (okmask & (1u << i))) ? s_off[i] + kb : OOB);
-                else dma16(rw_w, dst, live ? s_off[i] + wtap + kb : OOB);
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // fragment reads: lane (l31, half) wants chunk column 2 p + half of its row for plane p
-    const int ra = wm * 32 * TM + l31, rb = BM + wn * 32 * TN + l31;
-    const char* const a_frag = smem_raw + (((ra >> 4) * 96 + (ra & 15)) << 4) + half * 256;
-    const char* const b_frag = smem_raw + (((rb >> 4) * 96 + (rb & 15)) << 4) + half * 256;
-    auto compute = [&](int buf) {
-        bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) fa[i][p] = ld_frag(a_frag + buf * STAGE + i * 3072 + p * 512);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) fb[j][p] = ld_frag(b_frag + buf * STAGE + j * 3072 + p * 512);
-        mfma_split16<TM, TN, 6>(fa, fb, acc);
-    };
-    int tap = 0, sl = 0, t = 0;
-    auto advance = [&]() {
-        t ^= 1;
-        if (t == 0 && ++sl == cslices) { sl = 0; if (++tap < ph.ntaps) set_tap(tap); }
-    };
-    auto stage_done = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        dma_wait();
-        __syncthreads();
-    };
-    const int nstages = ph.ntaps * cslices * 2;          // (even)
-    set_tap(0);
-    issue(0, 0, 0);
-    stage_done();
-    // whole pairs of stages, nothing conditional inside the trip (the stage requested beyond the K extent comes from nowhere: zeros that
-    // nobody multiplies) -- the loop shape that took 30-60 registers off the weight-gradient kernels (profiles/r04_loop_exits.txt)
-    for (int ks = 0; ks < nstages; ks += 2) {
-        advance(); issue(sl, t, 1); compute(0); stage_done();
-        advance(); issue(sl, t, 0, ks + 2 < nstages); compute(1); stage_done();
-    }
-    gemm_epilogue<TM, TN, false, EM>(a, ph, acc, smem, M, tile_m, tile_n);
-}
-template <int TM, int TN, int EM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_sdma_kernel(const awr_conv_args a) {
-    conv_gemm_sdma_body<TM, TN, EM>(a);
-}
-
-// amdgpu_waves_per_eu(2): unified VGPR / AGPR allocation ("Register allocation")
-template <int TM, int TN, int NP, bool AFF, bool DUAL = false, bool SPLIT = false, bool FUSE2 = false, bool EPRE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(const awr_conv_args a) {
-    conv_gemm_body<TM, TN, NP, AFF, DUAL, SPLIT, FUSE2, EPRE>(a);
-}
-// The plain 64x64 tile at SIX waves per SIMD: 80 registers and two spilled dwords instead of 87 (five waves).  Same-box A/B: ResNet18 step
-// 13.83-13.86 vs 13.91-13.93 ms, Hourglass-1 train 25.20 vs 25.29 ms, config 3 13.32 vs 13.34 ms.  (The 64x128 tile at five waves -- 96
-// registers, twelve spilled dwords -- is no faster: 13.85-13.91 ms, Hourglass-1 slower.)  AWR_NO_OCC6=1 is the A/B hook.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void conv_gemm_kernel_11_occ6(const awr_conv_args a) {
-    conv_gemm_body<1, 1, 0, false>(a);
-}
-
-// out = epilogue(sum over the split-K copies, in order): bias, folded-BN affine, residual, ReLU
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t stride, const float* __restrict__ bias,
-                                                            const float* __restrict__ osc, const float* __restrict__ osh, const float* __restrict__ res,
-                                                            int relu, int64_t n4, int N4, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 v = ld4(partial + i * 4);
-    for (int z = 1; z < nsplit; ++z) {
-        const float4 p = ld4(partial + (int64_t)z * stride + i * 4);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-    }
-    const int n0 = (int)(i % N4) * 4;
-    if (bias) { const float4 b = ld4(bias + n0); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-    if (osc) {
-        const float4 sc = ld4(osc + n0), sh = ld4(osh + n0);
-        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-    }
-    if (res) { const float4 r = ld4(res + i * 4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-    if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-    st4(out + i * 4, v);
-}
-
-// ------------------------------------------------------------------------------------------
-// R[cd][t][cg] += sum_{m in K-chunk} D[m][cd] * G[gather(m,t)][cg]      (split-K over pixels)
-// ------------------------------------------------------------------------------------------
-template <int TM, int TN, bool FAST = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int BK = WBK;        // pixels per K-slice (shadows the channel-slice constant of the forward kernel)
-    constexpr int LDM = BM + 4, LDN = BN + 4;
-    constexpr int FM = BM / 4, FN = BN / 4;          // float4 per pixel row
-    constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows staged per pass
-    constexpr int RA = BK / PM, RB = BK / PN;
-    __shared__ __attribute__((aligned(16))) float Ds[BK * LDM];
-    __shared__ __attribute__((aligned(16))) float Gs[BK * LDN];
-
-    const int M = a.B * a.Hd * a.Wd;
-    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
-    int wg = blockIdx.x;
-    const int tcg = wg % tiles_cg; wg /= tiles_cg;
-    const int tcd = wg % tiles_cd; wg /= tiles_cd;
-    const int t = wg;                                 // tap
-    const int dy = a.dy[t], dx = a.dx[t];   // scalar (uniform) loads from the kernel arguments
-    const int m_begin = blockIdx.y * chunk;
-    int m_end = m_begin + chunk;
-    if (m_end > M) m_end = M;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int da_c = (tid % FM) * 4, da_r = tid / FM;   // D slice: channel offset, first pixel row
-    const int ga_c = (tid % FN) * 4, ga_r = tid / FN;
-    const bool d_cok = tcd * BM + da_c < a.Cd, g_cok = tcg * BN + ga_c < a.Cg;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 rd[RA], rg[RB];
-    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)M * a.Cd * 4u);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
-    const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
-    unsigned d_ok = 0, g_ok = 0;     // staged rows that hold real data (a fused affine must not touch padding / tail rows)
-    // `fast` (uniform; hshift >= 64 encodes it): power-of-two D and G maps and fewer than 2^24 pixels in either tensor -- every reference
-    // layer.  The per-slice address arithmetic then has no 32-bit multiply (v_mul_lo_u32 is a quarter-rate instruction: the 14 of them per
-    // slice were half of the ~100 VALU instructions a wave issued per 16 MFMAs, profiles/r03_pmc_wgrad.txt): shifts for the map strides,
-    // 24-bit multiplies (full rate) by the channel pitches.
-    constexpr bool fast = FAST;      // (a compile-time variant: the general path's code and registers stay out of the loop)
-    const int hsh = hshift & 63, gws = (hshift >> 8) & 63, ghs = (hshift >> 16) & 63, sgs = a.sg - 1;      // log2(Hd), log2(Wg), log2(Hg); sg in {1, 2}
-    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
-    auto load_slice = [&](int m0) {
-        d_ok = g_ok = 0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int m = m0 + da_r + PM * i;
-            const bool ok = m < m_end && d_cok;
-            rd[i] = buf_ld4(rs_d, ok ? (fast ? __umul24((unsigned)m, dpitch) : (unsigned)m * dpitch) + d_col : OOB);
-            d_ok |= ok ? (1u << i) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int m = m0 + ga_r + PN * i;
-            if constexpr (fast) {
-                const int x = m & (a.Wd - 1), tt = m >> wshift, y = tt & (a.Hd - 1), b = tt >> hsh;
-                const int gy = (y << sgs) + dy, gx = (x << sgs) + dx;
-                const bool ok = m < m_end && g_cok && (unsigned)gy < (unsigned)a.Hg && (unsigned)gx < (unsigned)a.Wg;
-                const unsigned pix = (unsigned)((((b << ghs) + gy) << gws) + gx);
-                rg[i] = buf_ld4(rs_g, ok ? __umul24(pix, gpitch) + g_col : OOB);
-                g_ok |= ok ? (1u << i) : 0u;
-                continue;
-            }
-            int x = 0, y = 0, b = 0;
-            if constexpr (fast) {
-            } else if (wshift >= 0) {      // power-of-two feature maps (every layer of both backbones): no integer division per slice
-                x = m & (a.Wd - 1);
-                const int tt = m >> wshift;
-                y = tt & (a.Hd - 1);
-                b = tt >> (hshift & 63);
-            } else {
-                x = m % a.Wd;
-                const int tt = m / a.Wd;
-                y = tt % a.Hd;
-                b = tt / a.Hd;
-            }
-            const int gy = y * a.sg + dy, gx = x * a.sg + dx;
-            const bool ok = m < m_end && g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
-            rg[i] = buf_ld4(rs_g, ok ? ((unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg) * 4u + g_col : OOB);
-            g_ok |= ok ? (1u << i) : 0u;
-        }
-    };
-    // per-thread channel chunk is fixed: the fused BatchNorm coefficients are loaded once
-    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
-    if (a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * BM + da_c); dsh = ld4(a.d_shift + tcd * BM + da_c); }
-    if (a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * BN + ga_c); gsh = ld4(a.g_shift + tcg * BN + ga_c); }
-    // column sums of D (= the conv's bias gradient): only the tap-0 / first-cg-tile workgroups of each pixel chunk count
-    const bool do_colsum = a.d_colsum != nullptr && t == 0 && tcg == 0;
-    float4 csum = make_float4(0, 0, 0, 0);
-    auto store_slice = [&]() {
-        if (a.d_scale) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                if (d_ok & (1u << i)) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
-        }
-        if (do_colsum) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
-        }
-        if (a.g_scale) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-                if (g_ok & (1u << i)) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) st4(&Ds[(da_r + PM * i) * LDM + da_c], rd[i]);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) st4(&Gs[(ga_r + PN * i) * LDN + ga_c], rg[i]);
-    };
-
-    load_slice(m_begin);
-    store_slice();
-    __syncthreads();
-    const float* a_frag = &Ds[half * LDM + wm * 32 * TM + l31];   // A[i = cd][k = pixel]: lane reads Ds[k][i]
-    const float* b_frag = &Gs[half * LDN + wn * 32 * TN + l31];
-
-    for (int m0 = m_begin; m0 < m_end; m0 += BK) {
-        const bool more = m0 + BK < m_end;
-        if (more) load_slice(m0 + BK);
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = a_frag[2 * kp * LDM + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = b_frag[2 * kp * LDN + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) {
-            store_slice();
-            __syncthreads();
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) {
-                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
-                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];     // deterministic mode: own copy per K-chunk
-                    else atomicAdd(o, acc[i][j][r]);
-                }
-            }
-    }
-    if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
-        __syncthreads();
-        float4* red = reinterpret_cast<float4*>(Ds);
-        red[da_r * FM + (tid % FM)] = csum;
-        __syncthreads();
-        if (da_r == 0 && d_cok) {
-            float4 tsum = make_float4(0, 0, 0, 0);
-            for (int g = 0; g < PM; ++g) {
-                const float4 v = red[g * FM + tid];
-                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
-            }
-            if (a.split_stride) {
-                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + da_c, tsum);
-            } else {
-                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
-                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Weight gradient with LDS-DMA staging (round 4)
-// ------------------------------------------------------------------------------------------
-// Same decomposition as conv_wgrad_kernel (workgroup = (tap, cd tile, cg tile, pixel chunk); K = pixels), same multiply-free slice
-// addressing (power-of-two maps: every reference layer), but an operand that needs no arithmetic on the way in goes global -> LDS directly
-// (`buffer_load_dwordx4 ... lds`, see conv_gemm_dma_body): the pixel rows of a slice are already what the instruction wants -- a pixel's BM
-// (BN) channels are contiguous in HBM and the slice image is [pixel][channel], so with UNPADDED rows thread t's 16-byte chunk lands at
-// 16 t of its 4 KB pass, lane-linear; the fragments are 4-byte reads of 32 consecutive floats per half-wave (conflict-free at any pitch), so
-// no swizzle is needed.  Stages of KP pixels are double-buffered: stage k + 1 is requested before the MFMAs of stage k, one barrier per
-// stage, no store phase, no staging registers.  DREG / GREG: that operand still travels through registers (fused BatchNorm + ReLU loader of
-// a never-materialised activation; the bias-gradient column sums need D in registers as well).
-template <int TM, int TN, int KP, bool DREG, bool GREG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? 5 : TM * TN == 2 ? 4 : 3))) void conv_wgrad_dma_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int FM = BM / 4, FN = BN / 4;          // 16-byte chunks per pixel row
-    constexpr int PM = 256 / FM, PN = 256 / FN;      // pixel rows per 4 KB pass of the 256 threads
-    constexpr int RA = KP / PM, RB = KP / PN;        // passes (DMA instructions / float4 registers) per thread and stage
-    constexpr int DST = KP * BM * 4, STAGE = KP * (BM + BN) * 4;
-    static_assert(RA >= 1 && RB >= 1, "stage too small for the tile");
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * STAGE];
-
-    const int M = a.B * a.Hd * a.Wd;
-    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
-    int wg = blockIdx.x;
-    const int tcg = wg % tiles_cg; wg /= tiles_cg;
-    const int tcd = wg % tiles_cd; wg /= tiles_cd;
-    const int t = wg;                                 // tap
-    const int dy = a.dy[t], dx = a.dx[t];
-    const int m_begin = blockIdx.y * chunk;
-    int m_end = m_begin + chunk;
-    if (m_end > M) m_end = M;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int da_c = (tid % FM) * 4, da_r = tid / FM;
-    const int ga_c = (tid % FN) * 4, ga_r = tid / FN;
-    const bool d_cok = tcd * BM + da_c < a.Cd, g_cok = tcg * BN + ga_c < a.Cg;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 rd[DREG ? RA : 1], rg[GREG ? RB : 1];
-    const unsigned dbytes = (unsigned)M * a.Cd * 4u, gbytes = (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u;
-    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, dbytes), rs_g = make_rsrc(a.G, gbytes);
-    const i32x4 rw_d = make_rsrc_words(a.D, dbytes), rw_g = make_rsrc_words(a.G, gbytes);
-    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
-    const unsigned d_col = d_cok ? (unsigned)(tcd * BM + da_c) * 4u : OOB, g_col = g_cok ? (unsigned)(tcg * BN + ga_c) * 4u : OOB;
-    unsigned d_ok = 0, g_ok = 0;
-    const int hsh = hshift & 63, gws = (hshift >> 8) & 63, ghs = (hshift >> 16) & 63, sgs = a.sg - 1;      // log2(Hd), log2(Wg), log2(Hg); sg in {1, 2}
-    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
-    auto issue = [&](int m0, int buf) {
-        const unsigned Dl = lds0 + (unsigned)(buf * STAGE), Gl = Dl + (unsigned)DST;
-        d_ok = g_ok = 0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int m = m0 + da_r + PM * i;
-            const bool ok = m < m_end && d_cok;
-            const unsigned off = ok ? __umul24((unsigned)m, dpitch) + d_col : OOB;
-            if constexpr (DREG) rd[i] = buf_ld4(rs_d, off);
-            else dma16(rw_d, Dl + i * 4096u, off);
-            d_ok |= ok ? (1u << i) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int m = m0 + ga_r + PN * i;
-            const int x = m & (a.Wd - 1), tt = m >> wshift, y = tt & (a.Hd - 1), b = tt >> hsh;
-            const int gy = (y << sgs) + dy, gx = (x << sgs) + dx;
-            const bool ok = m < m_end && g_cok && (unsigned)gy < (unsigned)a.Hg && (unsigned)gx < (unsigned)a.Wg;
-            const unsigned pix = (unsigned)((((b << ghs) + gy) << gws) + gx);
-            const unsigned off = ok ? __umul24(pix, gpitch) + g_col : OOB;
-            if constexpr (GREG) rg[i] = buf_ld4(rs_g, off);
-            else dma16(rw_g, Gl + i * 4096u, off);
-            g_ok |= ok ? (1u << i) : 0u;
-        }
-    };
-    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
-    if (DREG && a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * BM + da_c); dsh = ld4(a.d_shift + tcd * BM + da_c); }
-    if (GREG && a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * BN + ga_c); gsh = ld4(a.g_shift + tcg * BN + ga_c); }
-    const bool do_colsum = DREG && a.d_colsum != nullptr && t == 0 && tcg == 0;
-    float4 csum = make_float4(0, 0, 0, 0);
-    auto commit = [&](int buf) {       // register-path operands: fused affine + ReLU (padding / tail rows stay zero), then into the stage image
-        if constexpr (DREG) {
-            if (a.d_scale) {
-#pragma unroll
-                for (int i = 0; i < RA; ++i)
-                    if (d_ok & (1u << i)) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
-            }
-            if (do_colsum) {
-#pragma unroll
-                for (int i = 0; i < RA; ++i) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
-            }
-#pragma unroll
-            for (int i = 0; i < RA; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + i * 4096 + tid * 16), rd[i]);
-        }
-        if constexpr (GREG) {
-            if (a.g_scale) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-                    if (g_ok & (1u << i)) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) st4(reinterpret_cast<float*>(smem_raw + buf * STAGE + DST + i * 4096 + tid * 16), rg[i]);
-        }
-    };
-    const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * BM + wm * 32 * TM + l31;            // A[i = cd][k = pixel]: Ds[k][i]
-    const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * BN + wn * 32 * TN + l31;
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int kp = 0; kp < KP / 2; ++kp) {
-            float fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = a_frag[buf * (STAGE / 4) + 2 * kp * BM + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = b_frag[buf * (STAGE / 4) + 2 * kp * BN + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    auto stage_done = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        dma_wait();
-        __syncthreads();
-    };
-    issue(m_begin, 0);
-    commit(0);
-    stage_done();
-    // whole pairs of stages, no exit inside the trip (an exit between the two halves costs accumulator copies: the kernel-row kernel went from
-    // 123 to 81 registers when its exits went): a stage beyond the chunk is requested from nowhere -- zeros
-    for (int m0 = m_begin; m0 < m_end; m0 += 2 * KP) {
-        issue(m0 + KP, 1); compute(0); commit(1); stage_done();
-        issue(m0 + 2 * KP, 0); compute(1); commit(0); stage_done();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) {
-                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
-                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];     // deterministic mode: own copy per K-chunk
-                    else atomicAdd(o, acc[i][j][r]);
-                }
-            }
-    }
-    if (do_colsum) {      // fold the PM row-groups of the workgroup through LDS, then one atomic per channel
-        __syncthreads();
-        float4* red = reinterpret_cast<float4*>(smem_raw);
-        red[da_r * FM + (tid % FM)] = csum;
-        __syncthreads();
-        if (da_r == 0 && d_cok) {
-            float4 tsum = make_float4(0, 0, 0, 0);
-            for (int g = 0; g < PM; ++g) {
-                const float4 v = red[g * FM + tid];
-                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
-            }
-            if (a.split_stride) {
-                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + da_c, tsum);
-            } else {
-                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + da_c;
-                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Weight gradient of 3x3 stride-1 convolutions, one workgroup per KERNEL ROW (round 4)
-// ------------------------------------------------------------------------------------------
-// The workgroup-per-tap kernels give every tap its own workgroup: the nine taps of a filter each stream the same D pixels and a shifted
-// window of the same G pixels (PMC: ~4.5x the algorithmic bytes), a 64x64 tile has ONE accumulator per wave -- every MFMA waits for the
-// previous one (SQ_WAIT_INST_ANY 66 % of the wave cycles) -- and two LDS reads feed each MFMA.  Here a workgroup owns a 64x64 (cd x cg) tile
-// for the THREE taps of one kernel row (ty): a K-stage is 16 consecutive D pixels -- one row segment of 16 pixels, or two rows of an 8-wide
-// map -- and the G pixels of the same rows shifted by ty - 1, with one halo pixel on either side (PH x (PW + 2) pixel rows; pixels outside
-// the image are out-of-range DMA sources: zeros).  The B fragment of tap tx for D pixel p is the G pixel at row position p + tx: the three
-// taps read three consecutive positions, and position p + 2 of one pixel pair is position p' + 0 of the next -- per pixel pair ONE A read
-// and TWO new B reads feed THREE MFMAs into three independent accumulators.  Operands go global -> LDS by DMA (pixel-major rows: lane-linear,
-// no swizzle, as in conv_wgrad_dma_kernel), two stages in flight, one barrier per stage.
-//   GAFF: G is relu(g * scale + shift) of the stored tensor (a BatchNorm + ReLU output that was never written).  The arithmetic runs ONCE per
-//   staged element, in LDS, one stage ahead of the MFMAs: three stage buffers -- stage s + 2 is being requested, stage s + 1 (landed behind
-//   the previous barrier) is rewritten in place by the 256 threads (five floats each), stage s feeds the matrix pipe through the same
-//   fragment reads as the plain kernel -- still one barrier per stage.  Halo / padding pixels stay zero THROUGH the affine: their DMA wrote
-//   zeros and the rewrite skips them (rows outside the image, the two halo columns at the image's left / right edge).  (First version:
-//   multiply-add + clamp on every B fragment, i.e. on every element three times and in the MFMAs' dependency chain: matrix pipe busy 0.61
-//   against 0.73 for the plain kernel, 110 vs 130 TF on the 128 -> 128 layers at 64x64 -- profiles/r04_microbench_wgrad_row.txt.)
-//   The bias gradient (column sums of D = dY) is the sum of the A fragments over the stage's pixels: no register path for D either.
-#ifndef AWR_ROW_FENCE
-#define AWR_ROW_FENCE 2      // pixel pairs of fragment reads the scheduler may hoist in front of their MFMAs (study hook: 2 | 4 | 8)
-#endif
-#ifndef AWR_ROW_WAVES
-#define AWR_ROW_WAVES 4      // study hook: `4, 4` caps the resident waves per SIMD at four (the kernel needs 79-96 registers: five or six would fit)
-#endif
-template <int PW, bool GAFF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWR_ROW_WAVES))) void conv_wgrad_row_kernel(const awr_wgrad_args a, int stages_per_wg, int wlog, int hlog) {
-    constexpr int KP = 16;                           // D pixels per stage
-    constexpr int PH = KP / PW;                      // rows per stage (1 | 2)
-    constexpr int GW = PW + 2, GP = PH * GW;         // G pixel rows per stage: 18 | 20
-    constexpr int DST = KP * 64 * 4;                 // bytes of the D stage (4 KB)
-    constexpr int GST = 20 * 64 * 4;                 // ... of the G stage (five 1 KB DMA pieces)
-    constexpr int STAGE = DST + GST;
-    constexpr int NB = GAFF ? 3 : 2;                 // stage buffers
-    __shared__ __attribute__((aligned(16))) char smem_raw[NB * STAGE + (GAFF ? 512 : 0)];      // GAFF: + the tile's 64 (scale, shift) pairs
-
-    const int tiles_cg = (a.Cg + 63) >> 6, tiles_cd = (a.Cd + 63) >> 6;
-    int wg = blockIdx.x;
-    const int tcg = wg % tiles_cg; wg /= tiles_cg;
-    const int tcd = wg % tiles_cd; wg /= tiles_cd;
-    const int ty = wg;                               // kernel row 0..2
-    const int W = a.Wd, H = a.Hd;
-    const int segs_x = W / PW;                       // stages per image row (PH == 1) -- W >= PW, both powers of two
-    const int nstage = PH == 1 ? a.B * H * segs_x : a.B * (H / PH);
-    const int s_begin = blockIdx.y * stages_per_wg;
-    int s_end = s_begin + stages_per_wg;
-    if (s_end > nstage) s_end = nstage;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int ch4 = (lane & 15) * 4;                 // this lane's 4 channels of a staged pixel row
-    const bool d_cok = tcd * 64 + ch4 < a.Cd, g_cok = tcg * 64 + ch4 < a.Cg;
-    const i32x4 rw_d = make_rsrc_words(a.D, (unsigned)a.B * H * W * a.Cd * 4u), rw_g = make_rsrc_words(a.G, (unsigned)a.B * H * W * a.Cg * 4u);
-    const unsigned lds0 = lds_addr(smem_raw) + (unsigned)wave * 1024u;
-    const unsigned dpitch = (unsigned)a.Cd * 4u, gpitch = (unsigned)a.Cg * 4u;
-    const unsigned d_col = (unsigned)(tcd * 64 + ch4) * 4u, g_col = (unsigned)(tcg * 64 + ch4) * 4u;
-    // staging roles, fixed for the kernel: D piece `wave` = pixels 4 wave .. 4 wave + 3 of the stage; G pieces `wave` and (wave 0 only) 4
-    const int dpx = 4 * wave + (lane >> 4);
-    int g_r[2], g_j[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int slot = 4 * (i == 0 ? wave : 4) + (lane >> 4);
-        g_r[i] = slot < GP ? slot / GW : -(1 << 20);      // (a slot beyond the patch: always out of range)
-        g_j[i] = slot % GW;
-    }
-    auto geom = [&](int st, int& b, int& y0, int& x0) {      // stage -> image, first D row, first D column
-        if constexpr (PH == 1) {
-            x0 = (st & (segs_x - 1)) * PW;
-            const int t = st >> (wlog - (PW == 16 ? 4 : 3));
-            y0 = t & (H - 1);
-            b = t >> hlog;
-        } else {
-            x0 = 0;
-            const int rows = H / PH;
-            y0 = (st & (rows - 1)) * PH;
-            b = st >> (hlog - 1);
-        }
-    };
-    auto issue = [&](int st, int buf) {
-        int b, y0, x0;
-        geom(st, b, y0, x0);
-        const bool live = st < s_end;      // (GAFF walks whole triples of stages: a stage beyond the range is requested from nowhere -- zeros)
-        const unsigned Dl = lds0 + (unsigned)(buf * STAGE), Gl = lds0 - (unsigned)wave * 1024u + (unsigned)(buf * STAGE + DST);
-        {
-            const int r = dpx / PW, c = dpx % PW;
-            const unsigned pix = (unsigned)((((b << hlog) + y0 + r) << wlog) + x0 + c);
-            dma16(rw_d, Dl, d_cok && live ? __umul24(pix, dpitch) + d_col : OOB);
-        }
-        const int gy0 = y0 + ty - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && wave != 0) break;          // (wave-uniform: the fifth piece belongs to wave 0)
-            const int gy = gy0 + g_r[i], gx = x0 - 1 + g_j[i];
-            const bool ok = g_cok && live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const unsigned pix = (unsigned)((((b << hlog) + gy) << wlog) + gx);
-            dma16(rw_g, Gl + (unsigned)((i == 0 ? wave : 4) * 1024), ok ? __umul24(pix, gpitch) + g_col : OOB);
-        }
-    };
-    f32x16 acc[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // GAFF: this thread rewrites float4 `tid` (and, threads 0..63, float4 256 + tid) of the landed G stage: pixel slot tid >> 4 (16 + (tid >> 4)),
-    // channels ch4 .. ch4 + 3 -- coefficients out of range are zero (those columns were never fetched: zeros stay zeros)
-    // (kept in LDS and re-read per stage: eight more resident registers spill at this kernel's 128)
-    float* const gco = reinterpret_cast<float*>(smem_raw + NB * STAGE);
-    if (GAFF && tid < 64) {
-        const bool cok = tcg * 64 + tid < a.Cg;
-        gco[tid] = cok ? a.g_scale[tcg * 64 + tid] : 0.f;
-        gco[64 + tid] = cok ? a.g_shift[tcg * 64 + tid] : 0.f;
-    }
-    const float g_lo = a.g_relu ? 0.f : -__builtin_inff();
-    auto transform = [&](int st, int buf) {
-        if constexpr (GAFF) {
-            __builtin_amdgcn_sched_barrier(0);      // (its temporaries die before the stage's fragment reads start)
-            int b, y0, x0;
-            geom(st, b, y0, x0);
-            const int gy0 = y0 + ty - 1;
-            const bool edge_l = x0 > 0, edge_r = x0 + PW < W;
-            float* const Gs = reinterpret_cast<float*>(smem_raw + buf * STAGE + DST);
-            const float4 gsc = ld4(gco + ch4), gsh = ld4(gco + 64 + ch4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && tid >= 64) break;
-                const int slot = 16 * i + (tid >> 4);
-                if (slot >= GP) break;               // (PW == 16: the patch has 18 pixel slots)
-                const int r = slot / GW, j = slot - r * GW;
-                const bool ok = st < s_end && (unsigned)(gy0 + r) < (unsigned)H && (j != 0 || edge_l) && (j != GW - 1 || edge_r);
-                if (ok) {
-                    float4 v = ld4(Gs + slot * 64 + ch4);
-                    v.x = __builtin_amdgcn_fmed3f(v.x * gsc.x + gsh.x, g_lo, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y * gsc.y + gsh.y, g_lo, __builtin_inff());
-                    v.z = __builtin_amdgcn_fmed3f(v.z * gsc.z + gsh.z, g_lo, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w * gsc.w + gsh.w, g_lo, __builtin_inff());
-                    st4(Gs + slot * 64 + ch4, v);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    const bool do_colsum = a.d_colsum != nullptr && ty == 0 && tcg == 0 && wn == 0;
-    float csum = 0.f;
-    const float* const a_frag = reinterpret_cast<const float*>(smem_raw) + half * 64 + wm * 32 + l31;               // D[pixel][cd]
-    const float* const b_frag = reinterpret_cast<const float*>(smem_raw + DST) + half * 64 + wn * 32 + l31;         // G[patch pixel][cg]
-    auto compute = [&](int buf) {
-        auto gread = [&](int r, int pos) -> float {      // G position `pos` (0 = left halo) of patch row r for this lane's half: pos + half
-            return b_frag[buf * (STAGE / 4) + (r * GW + pos) * 64];
-        };
-#pragma unroll
-        for (int r = 0; r < PH; ++r) {
-            float b0 = gread(r, 0);
-#pragma unroll
-            for (int kp = 0; kp < PW / 2; ++kp) {
-                const float fa = a_frag[buf * (STAGE / 4) + (r * PW + 2 * kp) * 64];
-                const float b1 = gread(r, 2 * kp + 1), b2 = gread(r, 2 * kp + 2);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b2, acc[2], 0, 0, 0);
-                if (do_colsum) csum += fa;
-                b0 = b2;
-                // (left alone the scheduler hoists all 25 fragment reads of the stage in front of its MFMAs: 130 registers; a fence
-                // every second pixel pair keeps two pairs of reads in flight ahead of the matrix instructions)
-                if ((kp & (AWR_ROW_FENCE - 1)) == AWR_ROW_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    auto stage_done = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        dma_wait();
-        __syncthreads();
-    };
-    if (s_begin < s_end) {
-        issue(s_begin, 0);
-        stage_done();
-        if constexpr (GAFF) {
-            transform(s_begin, 0);
-            issue(s_begin + 1, 1);
-            stage_done();
-            // three stages per trip (every LDS address a compile-time constant; no exits inside the trip -- exits there cost accumulator
-            // copies the allocator spilled): buffer of stage st = (st - s_begin) % 3; the last trip's surplus stages are zeros
-            for (int st = s_begin; st < s_end; st += 3) {
-                issue(st + 2, 2); transform(st + 1, 1); compute(0); stage_done();
-                issue(st + 3, 0); transform(st + 2, 2); compute(1); stage_done();
-                issue(st + 4, 1); transform(st + 3, 0); compute(2); stage_done();
-            }
-        } else {
-            for (int st = s_begin; st < s_end; st += 2) {      // (whole pairs, for the same reason)
-                issue(st + 1, 1); compute(0); stage_done();
-                issue(st + 2, 0); compute(1); stage_done();
-            }
-        }
-    }
-    {
-        const int cg = tcg * 64 + wn * 32 + l31;
-        float* const Rw = a.R + (a.split_stride ? (int64_t)blockIdx.y * a.split_stride : 0);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = tcd * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) {
-                    const unsigned off = (unsigned)((cd * 9 + ty * 3 + j) * a.ld + cg);       // (R holds Cd x 9 x ld < 2^31 floats)
-                    if (a.split_stride) Rw[off] = acc[j][r];
-                    else atomicAdd(Rw + off, acc[j][r]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (a.d_colsum != nullptr && ty == 0 && tcg == 0) {      // (uniform per workgroup) lane (l31, half) of the wn = 0 waves holds its channel's sum over its half's pixels
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem_raw);
-        if (wn == 0) red[wm * 64 + lane] = csum;
-        __syncthreads();
-        if (tid < 64) {
-            const int cd = tcd * 64 + tid;
-            const float t = red[(tid >> 5) * 64 + (tid & 31)] + red[(tid >> 5) * 64 + 32 + (tid & 31)];
-            if (cd < a.Cd) {
-                if (a.split_stride) a.d_colsum[(size_t)blockIdx.y * a.Cd + cd] = t;
-                else atomicAdd(a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + cd, t);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Weight gradient, one wave per filter tap
-// ------------------------------------------------------------------------------------------
-// The kernel above gives every (tap, channel tile, pixel chunk) its own workgroup: the KS*KS taps of a filter each re-stream
-// the same D pixels and a shifted window of the same G pixels (PMC, 64-channel 3x3 layer at batch 64: 411 MB of HBM traffic
-// per launch against 134 MB of operands), and a 64x64 workgroup tile carries only 16 MFMAs per wave between two barriers.
-// Here a workgroup owns a 64 x 64 (cd x cg) channel tile for ALL taps: its K-slices are PH x 8 patches of D pixels, staged in
-// LDS once together with the halo'd patch of G pixels they touch -- and a wave contracts them for ONE ROW of taps and one 32x32
-// quadrant of the channel tile (KS accumulator tiles): the B-operand fragment of tap (ty, tx) is the G pixel of the A-operand's
-// D pixel shifted by that tap, i.e. the same LDS address plus a constant.  4 KS waves per workgroup = KS per SIMD, evenly.
-// Per K-slice a wave issues KS x (pixels / 2) MFMAs between two barriers, operand bytes per MFMA fall by roughly the number
-// of taps, and the slices are double-buffered in LDS (one barrier each).
-//   SG: stride of the gathered operand (1: 3x3 conv; 2: strided 3x3 conv, 4x4 transposed conv); KS: taps per axis; PH: patch rows
-template <int SG, int KS, int PH>
-__global__ __launch_bounds__(64 * KS * 4) void conv_wgrad_taps_kernel(const awr_wgrad_args a, int patches_per_wg, int pc_log, int pr_log) {
-    constexpr int NW = KS * 4, NTHR = 64 * NW;
-    constexpr int PP = PH * 8;                          // D pixels per K-slice
-    constexpr int GH = (PH - 1) * SG + KS, GW = 7 * SG + KS, GP = GH * GW;     // halo'd G patch
-    constexpr int ND = PP * 16, NG = GP * 16;           // float4 per slice (64 channels = 16 float4 per pixel)
-    constexpr int RD = (ND + NTHR - 1) / NTHR, RG = (NG + NTHR - 1) / NTHR;
-    __shared__ __attribute__((aligned(16))) float Ds[2][PP * 64];
-    __shared__ __attribute__((aligned(16))) float Gs[2][GP * 64];
-
-    const int tiles_cg = (a.Cg + 63) >> 6;
-    const int tcg = blockIdx.x % tiles_cg, tcd = blockIdx.x / tiles_cg;
-    const int npatch = a.B << (pc_log + pr_log);
-    const int p_begin = blockIdx.y * patches_per_wg;
-    int p_end = p_begin + patches_per_wg;
-    if (p_end > npatch) p_end = npatch;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int trow = wave >> 2, qi = (wave >> 1) & 1, qj = wave & 1;       // tap row, quadrant (cd half, cg half) of this wave
-    const int half = lane >> 5, l31 = lane & 31;
-    const int dmin_y = a.dy[0], dmin_x = a.dx[0];      // taps are listed row-major from the top-left one
-
-    // staging roles (fixed for the whole kernel): float4 e = tid + NTHR * i of the D patch / of the G patch
-    const int c4 = tid & 15;
-    const bool d_cok = tcd * 64 + 4 * c4 < a.Cd, g_cok = tcg * 64 + 4 * c4 < a.Cg;
-    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)a.B * a.Hd * a.Wd * a.Cd * 4u);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
-    int d_r[RD], d_c[RD], g_r[RG], g_c[RG];
-#pragma unroll
-    for (int i = 0; i < RD; ++i) {
-        const int e = tid + NTHR * i, p = e >> 4;
-        d_r[i] = e < ND ? p >> 3 : -1;
-        d_c[i] = p & 7;
-    }
-#pragma unroll
-    for (int i = 0; i < RG; ++i) {
-        const int e = tid + NTHR * i, gp = e >> 4;
-        g_r[i] = e < NG ? gp / GW : -(1 << 20);
-        g_c[i] = gp % GW;
-    }
-    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0), gsc = dsc, gsh = dsh;
-    if (a.d_scale && d_cok) { dsc = ld4(a.d_scale + tcd * 64 + 4 * c4); dsh = ld4(a.d_shift + tcd * 64 + 4 * c4); }
-    if (a.g_scale && g_cok) { gsc = ld4(a.g_scale + tcg * 64 + 4 * c4); gsh = ld4(a.g_shift + tcg * 64 + 4 * c4); }
-    const bool do_colsum = a.d_colsum != nullptr && tcg == 0;
-    float4 csum = make_float4(0, 0, 0, 0);
-
-    float4 rd[RD], rg[RG];
-    unsigned g_ok = 0;
-    auto load_slice = [&](int patch) {
-        const int pc = patch & ((1 << pc_log) - 1), pr = (patch >> pc_log) & ((1 << pr_log) - 1), b = patch >> (pc_log + pr_log);
-        const int py0 = pr * PH, px0 = pc * 8;
-#pragma unroll
-        for (int i = 0; i < RD; ++i) {
-            const bool ok = d_r[i] >= 0 && d_cok;
-            rd[i] = buf_ld4(rs_d, ok ? (unsigned)((b * a.Hd + py0 + d_r[i]) * a.Wd + px0 + d_c[i]) * a.Cd * 4u + (unsigned)(tcd * 64 + 4 * c4) * 4u : OOB);
-        }
-        g_ok = 0;
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-            const int gy = py0 * SG + dmin_y + g_r[i], gx = px0 * SG + dmin_x + g_c[i];
-            const bool ok = g_cok && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
-            rg[i] = buf_ld4(rs_g, ok ? (unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg * 4u + (unsigned)(tcg * 64 + 4 * c4) * 4u : OOB);
-            g_ok |= ok ? (1u << i) : 0u;
-        }
-    };
-    auto store_slice = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < RD; ++i) {
-            if (d_r[i] < 0) continue;
-            if (a.d_scale && d_cok) rd[i] = affine_relu(rd[i], dsc, dsh, a.d_relu);
-            if (do_colsum) { csum.x += rd[i].x; csum.y += rd[i].y; csum.z += rd[i].z; csum.w += rd[i].w; }
-            st4(&Ds[buf][((d_r[i] << 3) + d_c[i]) * 64 + 4 * c4], rd[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < RG; ++i) {
-            if (g_r[i] < 0) continue;
-            if (a.g_scale && (g_ok & (1u << i))) rg[i] = affine_relu(rg[i], gsc, gsh, a.g_relu);      // padding stays zero
-            st4(&Gs[buf][(g_r[i] * GW + g_c[i]) * 64 + 4 * c4], rg[i]);
-        }
-    };
-
-    f32x16 acc[KS];
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    // fragment addresses: D pixel p = 2 kp + half of the patch (row p >> 3, column p & 7); its G pixel for tap (trow, j) sits
-    // j G-pixels further along the row
-    const int a_lane = half * 64 + qi * 32 + l31;
-    const int b_lane = (trow * GW + half * SG) * 64 + qj * 32 + l31;
-
-    if (p_begin < p_end) {
-        load_slice(p_begin);
-        store_slice(0);
-    }
-    __syncthreads();
-    for (int patch = p_begin; patch < p_end; ++patch) {
-        const int cur = (patch - p_begin) & 1;
-        const bool more = patch + 1 < p_end;
-        if (more) load_slice(patch + 1);
-        const float* dsl = &Ds[cur][a_lane];
-        const float* gsl = &Gs[cur][b_lane];
-#pragma unroll
-        for (int kp = 0; kp < PP / 2; ++kp) {
-            const int p0 = 2 * kp;
-            const int goff = ((p0 >> 3) * SG * GW + (p0 & 7) * SG) * 64;
-            const float fa = dsl[p0 * 64];
-            float fb[KS];
-#pragma unroll
-            for (int j = 0; j < KS; ++j) fb[j] = gsl[goff + j * 64];
-#pragma unroll
-            for (int j = 0; j < KS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], acc[j], 0, 0, 0);
-        }
-        if (more) store_slice(cur ^ 1);
-        __syncthreads();
-    }
-
-    {
-        const int cg = tcg * 64 + qj * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < KS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = tcd * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) {
-                    float* o = a.R + ((int64_t)cd * a.T + trow * KS + j) * a.ld + cg;
-                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[j][r];
-                    else atomicAdd(o, acc[j][r]);
-                }
-            }
-    }
-    if (do_colsum) {      // fold the staging threads that share a channel chunk through LDS, one atomic per channel
-        float4* red = reinterpret_cast<float4*>(&Gs[0][0]);
-        red[tid] = csum;
-        __syncthreads();
-        if (tid < 16 && d_cok) {
-            float4 tsum = make_float4(0, 0, 0, 0);
-            for (int g = tid; g < NTHR; g += 16) {
-                const float4 v = red[g];
-                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
-            }
-            if (a.split_stride) {
-                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * 64 + 4 * tid, tsum);
-            } else {
-                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * 64 + 4 * tid;
-                atomicAdd(o + 0, tsum.x); atomicAdd(o + 1, tsum.y); atomicAdd(o + 2, tsum.z); atomicAdd(o + 3, tsum.w);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Weight gradient in split-operand mode (NP = 6 / 9).
-// ------------------------------------------------------------------------------------------
-// The contraction runs over pixels, so both MFMA operands need pixel-contiguous (k-contiguous) rows per channel, while HBM
-// holds channel-contiguous pixels: each thread owns a 4-pixel x 4-channel unit, loads its four float4 (a wave covers 8
-// pixel groups x 8 channel groups = eight full 128-byte lines per load instruction), transposes the 4x4 block in
-// registers (free: it is only a choice of which register feeds which store), cuts every value into its three bf16 pieces
-// and writes one 8-byte store per channel and piece.  Lane = pixel group + 8 x channel group keeps both the global loads
-// (128 B per pixel) and the LDS stores (64 contiguous bytes per 8 lanes, the other 8 lanes 16 banks away) conflict-free.
-// LDS image, fragment reads and MFMA schedule are the ones of the forward kernel (rows = channels).
-template <int TM, int TN, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_split_kernel(const awr_wgrad_args a, int chunk, int wshift, int hshift) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int UD = 2 * BM, UG = 2 * BN;            // 4x4 units per 32-pixel slice of the D / G tile
-    constexpr int NU = (UD + UG + 255) / 256;          // unit slots per thread
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * LDR];
-    char* const Ds = smem;
-    char* const Gs = smem + BM * LDR;
-
-    const int M = a.B * a.Hd * a.Wd;
-    const int tiles_cg = (a.Cg + BN - 1) / BN, tiles_cd = (a.Cd + BM - 1) / BM;
-    int wg = blockIdx.x;
-    const int tcg = wg % tiles_cg; wg /= tiles_cg;
-    const int tcd = wg % tiles_cd; wg /= tiles_cd;
-    const int t = wg;                                 // tap
-    const int dy = a.dy[t], dx = a.dx[t];
-    const int m_begin = blockIdx.y * chunk;
-    int m_end = m_begin + chunk;
-    if (m_end > M) m_end = M;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-
-    // unit slots (the role of a slot is uniform per wave: the D/G boundary is a multiple of 128 threads)
-    int role[NU], upg[NU], uch[NU];
-    unsigned ucol[NU];
-    float4 usc[NU], ush[NU];
-    int urelu[NU];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        int u = tid + 256 * i;
-        role[i] = u < UD ? 0 : (u < UD + UG ? 1 : 2);
-        if (role[i] == 1) u -= UD;
-        upg[i] = u & 7;
-        uch[i] = (u >> 3) * 4;
-        const int cbase = role[i] == 0 ? tcd * BM + uch[i] : tcg * BN + uch[i];
-        const bool cok = role[i] == 0 ? cbase < a.Cd : (role[i] == 1 && cbase < a.Cg);
-        ucol[i] = cok ? (unsigned)cbase * 4u : OOB;
-        usc[i] = make_float4(1, 1, 1, 1); ush[i] = make_float4(0, 0, 0, 0); urelu[i] = 0;
-        if (role[i] == 0 && a.d_scale && cok) { usc[i] = ld4(a.d_scale + cbase); ush[i] = ld4(a.d_shift + cbase); urelu[i] = a.d_relu; }
-        if (role[i] == 1 && a.g_scale && cok) { usc[i] = ld4(a.g_scale + cbase); ush[i] = ld4(a.g_shift + cbase); urelu[i] = a.g_relu; }
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 raw[NU][4];
-    unsigned okm[NU];
-    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.D, (unsigned)M * a.Cd * 4u);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (unsigned)a.B * a.Hg * a.Wg * a.Cg * 4u);
-    const bool row4 = (a.Wd & 3) == 0;      // a unit's four pixels share an image row
-    auto g_offset = [&](int m, bool& ok) -> unsigned {
-        int x, y, b;
-        if (wshift >= 0) {
-            x = m & (a.Wd - 1);
-            const int tt = m >> wshift;
-            y = tt & (a.Hd - 1);
-            b = tt >> hshift;
-        } else {
-            x = m % a.Wd;
-            const int tt = m / a.Wd;
-            y = tt % a.Hd;
-            b = tt / a.Hd;
-        }
-        const int gy = y * a.sg + dy, gx = x * a.sg + dx;
-        ok = m < m_end && gy >= 0 && gy < a.Hg && gx >= 0 && gx < a.Wg;
-        return (unsigned)((b * a.Hg + gy) * a.Wg + gx) * a.Cg * 4u;
-    };
-    auto load_slice = [&](int m0) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            okm[i] = 0;
-            const int mb = m0 + 4 * upg[i];
-            if (role[i] == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool ok = mb + q < m_end && ucol[i] != OOB;
-                    raw[i][q] = buf_ld4(rs_d, ok ? (unsigned)(mb + q) * a.Cd * 4u + ucol[i] : OOB);
-                    okm[i] |= ok ? (1u << q) : 0u;
-                }
-            } else if (role[i] == 1) {
-                if (row4) {
-                    bool ok0;
-                    const unsigned base = g_offset(mb, ok0);       // validity of the row; columns are tested per pixel below
-                    const int x0 = (wshift >= 0 ? (mb & (a.Wd - 1)) : mb % a.Wd) * a.sg + dx;
-                    int y; { const int tt = wshift >= 0 ? (mb >> wshift) : mb / a.Wd; y = (wshift >= 0 ? (tt & (a.Hd - 1)) : tt % a.Hd) * a.sg + dy; }
-                    const bool rowok = y >= 0 && y < a.Hg && ucol[i] != OOB;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int gx = x0 + q * a.sg;
-                        const bool ok = rowok && mb + q < m_end && gx >= 0 && gx < a.Wg;
-                        raw[i][q] = buf_ld4(rs_g, ok ? base + (unsigned)(q * a.sg * a.Cg) * 4u + ucol[i] : OOB);
-                        okm[i] |= ok ? (1u << q) : 0u;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        bool ok;
-                        const unsigned off = g_offset(mb + q, ok);
-                        ok = ok && ucol[i] != OOB;
-                        raw[i][q] = buf_ld4(rs_g, ok ? off + ucol[i] : OOB);
-                        okm[i] |= ok ? (1u << q) : 0u;
-                    }
-                }
-            }
-        }
-    };
-    const bool do_colsum = a.d_colsum != nullptr && t == 0 && tcg == 0;
-    float4 csum = make_float4(0, 0, 0, 0);
-    auto store_slice = [&]() {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            if (role[i] == 2) continue;
-            if (role[i] == 0 ? a.d_scale != nullptr : a.g_scale != nullptr) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (okm[i] & (1u << q)) raw[i][q] = affine_relu(raw[i][q], usc[i], ush[i], urelu[i]);
-            }
-            if (role[i] == 0 && do_colsum) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { csum.x += raw[i][q].x; csum.y += raw[i][q].y; csum.z += raw[i][q].z; csum.w += raw[i][q].w; }
-            }
-            char* dst = (role[i] == 0 ? Ds : Gs) + uch[i] * LDR + 8 * upg[i];
-            store_split4(dst, make_float4(raw[i][0].x, raw[i][1].x, raw[i][2].x, raw[i][3].x));
-            store_split4(dst + LDR, make_float4(raw[i][0].y, raw[i][1].y, raw[i][2].y, raw[i][3].y));
-            store_split4(dst + 2 * LDR, make_float4(raw[i][0].z, raw[i][1].z, raw[i][2].z, raw[i][3].z));
-            store_split4(dst + 3 * LDR, make_float4(raw[i][0].w, raw[i][1].w, raw[i][2].w, raw[i][3].w));
-        }
-    };
-
-    load_slice(m_begin);
-    store_slice();
-    __syncthreads();
-    const char* a_frag = Ds + (wm * 32 * TM + l31) * LDR + 16 * half;
-    const char* b_frag = Gs + (wn * 32 * TN + l31) * LDR + 16 * half;
-    for (int m0 = m_begin; m0 < m_end; m0 += BK) {
-        const bool more = m0 + BK < m_end;
-        if (more) load_slice(m0 + BK);
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 fa[TM][3], fb[TN][3];
-            load_split_frags<TM, TN>(a_frag + 32 * s, b_frag + 32 * s, fa, fb);
-            mfma_split16<TM, TN, NP>(fa, fb, acc);
-        }
-        __syncthreads();
-        if (more) {
-            store_slice();
-            __syncthreads();
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cg = tcg * BN + wn * 32 * TN + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = tcd * BM + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (cd < a.Cd && cg < a.Cg) {
-                    float* o = a.R + ((int64_t)cd * a.T + t) * a.ld + cg;
-                    if (a.split_stride) o[(int64_t)blockIdx.y * a.split_stride] = acc[i][j][r];
-                    else atomicAdd(o, acc[i][j][r]);
-                }
-            }
-    }
-    if (do_colsum && role[0] == 0) {      // the 8 pixel-group lanes of a channel group hold partial sums of the same 4 channels
-#pragma unroll
-        for (int o = 1; o <= 4; o <<= 1) {
-            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-        }
-        if (upg[0] == 0 && ucol[0] != OOB) {
-            if (a.split_stride) {
-                st4(a.d_colsum + (size_t)blockIdx.y * a.Cd + tcd * BM + uch[0], csum);
-            } else {
-                float* o = a.d_colsum + (size_t)(blockIdx.y % AWR_STAT_SLOTS) * a.Cd + tcd * BM + uch[0];
-                atomicAdd(o + 0, csum.x); atomicAdd(o + 1, csum.y); atomicAdd(o + 2, csum.z); atomicAdd(o + 3, csum.w);
-            }
-        }
-    }
-}
-
+void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, int mode, int aff, bool epre, int em);
+extern template void launch_dma_tile<1, 1>(const awr_conv_args*, dim3, hipStream_t, int, int, bool, int);
+extern template void launch_dma_tile<1, 2>(const awr_conv_args*, dim3, hipStream_t, int, int, bool, int);
+extern template void launch_dma_tile<2, 1>(const awr_conv_args*, dim3, hipStream_t, int, int, bool, int);
+extern template void launch_dma_tile<2, 2>(const awr_conv_args*, dim3, hipStream_t, int, int, bool, int);
 }  // namespace awr
 
 using namespace awr;
 
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
-// ---- dispatch of the LDS-DMA GEMM instantiations (run-time flags -> compile-time variants) ----
-template <int TM, int TN, int KB, int NBUF, int AFF>
-static void launch_dma_em(const awr_conv_args* a, dim3 grid, hipStream_t st, bool epre, int em) {
-    // Accumulator orientation (round 5 study, profiles/r05_epilogue_orientation.txt): 0 = mfma(activation fragment, weight fragment), a lane owns 16 PIXELS
-    // of one channel -- the shipped form.  Builds with -DAWR_EPI_STUDY also carry 1 = operand roles swapped (a lane owns 16 CHANNELS of one pixel: the bounce
-    // tile written as four 16-byte rows instead of sixteen 4-byte columns) and 2 = 1 with the reduction-free epilogue stored straight from the accumulators
-    // (no LDS): bit-identical results, 1 is not faster anywhere, 2 is 6-9 % SLOWER on the store-heavy 1x1 launches (32-byte runs per pixel per store
-    // instruction instead of whole 128-byte lines).  $AWR_EPI selects.
-#ifdef AWR_EPI_STUDY
-    static const int sw = env_int("AWR_EPI", 0);
-#define AWR_DMA_SW(EPRE, EM, DUAL, ACCB)                                                                                                                   \
-    do {                                                                                                                                                   \
-        if (sw == 0) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, 0>), grid, dim3(256), 0, st, *a);               \
-        else if (sw == 1 || EM != 1) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, 1>), grid, dim3(256), 0, st, *a); \
-        else hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, (EM == 1 ? 2 : 1)>), grid, dim3(256), 0, st, *a);      \
-    } while (0)
-#else
-#define AWR_DMA_SW(EPRE, EM, DUAL, ACCB) hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, KB, NBUF, AFF, EPRE, EM, DUAL, ACCB, 0>), grid, dim3(256), 0, st, *a)
-#endif
-#define AWR_DMA_K(EPRE, EM, DUAL) AWR_DMA_SW(EPRE, EM, DUAL, false)
-#define AWR_DMA_KB(EM) AWR_DMA_SW(false, EM, false, (KB == 16 && NBUF == 2))
-    const bool blocked = KB == 16 && NBUF == 2 && a->accum == 1 && a->Cin * a->ph[0].ntaps > 256;      // (shorter K extents are one block anyway)
-    // statistics from the accumulators (EM 5) where the stored value is accumulator + bias and every tile lies inside M.  OPT-IN (AWR_FAST_STATS=1): built,
-    // bit-identical outputs, statistics 1.5x CLOSER to float64 than the row-layout form, isolated 1x1 launches with statistics +4-8 % (16x16 maps +20 %),
-    // Hourglass-1 step -0.5 % -- and not the default, because the two-image training-mode golden fixture of ResNet18 is chaotic in the statistics' last bits
-    // (mean joint error 1.01e-3 -> 1.27e-3 mm against a bar of 1.26e-3 with the MORE accurate sums): profiles/r05_fast_stats.txt
-    {
-        const int64_t M = (int64_t)a->B * a->Hq * a->Wq;
-#ifndef AWR_EPI_STUDY      // (the swapped-operand study forms keep the row-layout statistics)
-        // (not the 128x128 tile with the masked input affine: 128 -> 131 registers would cost it its fourth wave)
-        if (em == 2 && !a->res && !a->out_scale && !epre && M % (64 * TM) == 0 && !(TM == 2 && TN == 2 && AFF == 1) && env_int("AWR_FAST_STATS", 0)) em = 5;
-#endif
-    }
-    if constexpr (AFF == 2) {          // data gradients only: no statistics epilogue, no second tensor, no operand prefetch
-        if (blocked) {
-            if (em == 4) AWR_DMA_KB(4);
-            else if (em == 3) AWR_DMA_KB(3);
-            else AWR_DMA_KB(1);
-        } else {
-            if (em == 4) AWR_DMA_K(false, 4, false);
-            else if (em == 3) AWR_DMA_K(false, 3, false);
-            else AWR_DMA_K(false, 1, false);
-        }
-    } else if (a->in2) {               // conv3 + skip_layer: K = [in | in2]; no operand prefetch (the launcher excludes it), no BNR epilogue
-        if (blocked) {                 // (Hourglass conv3 + skip: K = 128 + 256)
-            if (em == 5) AWR_DMA_SW(false, 5, true, (KB == 16 && NBUF == 2));
-            else if (em == 2) AWR_DMA_SW(false, 2, true, (KB == 16 && NBUF == 2));
-            else AWR_DMA_SW(false, 1, true, (KB == 16 && NBUF == 2));
-        } else {
-            if (em == 5) AWR_DMA_K(false, 5, true);
-            else if (em == 2) AWR_DMA_K(false, 2, true);
-            else AWR_DMA_K(false, 1, true);
-        }
-    } else if (epre) {                 // short K loops (<= 256 terms: one accumulation block in either mode) whose epilogue reads exactly one operand tensor
-        if (em == 3) AWR_DMA_K(true, 3, false);
-        else if (em == 2) AWR_DMA_K(true, 2, false);
-        else AWR_DMA_K(true, 1, false);
-    } else if (blocked) {
-        if (em == 4) AWR_DMA_KB(4);
-        else if (em == 3) AWR_DMA_KB(3);
-        else if (em == 5) AWR_DMA_KB(5);
-        else if (em == 2) AWR_DMA_KB(2);
-        else AWR_DMA_KB(1);
-    } else {
-        if (em == 4) AWR_DMA_K(false, 4, false);
-        else if (em == 3) AWR_DMA_K(false, 3, false);
-        else if (em == 5) AWR_DMA_K(false, 5, false);
-        else if (em == 2) AWR_DMA_K(false, 2, false);
-        else AWR_DMA_K(false, 1, false);
-    }
-#undef AWR_DMA_KB
-#undef AWR_DMA_K
-#undef AWR_DMA_SW
-}
-template <int TM, int TN>
-static void launch_dma_tile(const awr_conv_args* a, dim3 grid, hipStream_t st, int mode, int aff, bool epre, int em) {
-#ifdef AWR_DMA_STUDY
-    if (mode == 1 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 2, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 2, 0>(a, grid, st, epre, em); return; }
-    if (mode == 3 && aff < 2) { aff ? launch_dma_em<TM, TN, 32, 1, 1>(a, grid, st, epre, em) : launch_dma_em<TM, TN, 32, 1, 0>(a, grid, st, epre, em); return; }
-#endif
-    // (round-5 study, -DAWR_AFF_LDS_STUDY + AWR_AFF_LDS=1: the fused input affine as an in-LDS pass, AFF == 4 -- fewer registers, bit-identical, NOT faster:
-    // profiles/r05_affine_lds_pass.txt)
-#ifdef AWR_AFF_LDS_STUDY
-    static const int aff_lds = env_int("AWR_AFF_LDS", 0);
-    if (aff && aff != 2 && aff_lds) { launch_dma_em<TM, TN, 16, 2, 4>(a, grid, st, epre, em); return; }
-#endif
-    // deep pipeline (four stage buffers, three in flight) for launches of at most 384 workgroups (1.5 per CU) whose K loop is long enough to matter;
-    // ordered accumulation, no 128x128 tile (it never wins at that size), no un-materialised BatchNorm backward.  Measured (profiles/r05_deep_pipeline.txt):
-    // isolated launches do not move, steps whose launches are ALL small do -- ResNet18 train batch 4 3.59 -> 3.01 ms, batch 16 5.04 -> 4.59 ms (a launch
-    // that shares the CUs with the weight gradients of two side streams sees load latencies two buffers do not cover); with 512 the batch-64 steps
-    // lose 1 % (layer4, the Hourglass 8x8 levels), with 384 they are unchanged.  AWR_DEEP=0: never (A/B hook), AWR_DEEP_MAX_WGS: the bound
-    if constexpr (!(TM == 2 && TN == 2)) {
-        const int deep_on = env_int("AWR_DEEP", 1);      // (read per launch: tests and same-box A/Bs toggle it inside one process)
-        int minsteps = 1 << 30;
-        for (int p = 0; p < a->nphase; ++p) minsteps = a->ph[p].ntaps * (a->Cin / 16) < minsteps ? a->ph[p].ntaps * (a->Cin / 16) : minsteps;
-        static const int deep_wgs = env_int("AWR_DEEP_MAX_WGS", 384);
-        // AWR_DEEP_1X1 (study hook, results unchanged): single-tap launches of ANY size take the deep form -- a 1x1 conv at 64x64 x 64 images streams
-        // its whole A operand from HBM once (2-3.5 TB/s needed at MFMA speed) with one 4 KB stage per resident workgroup in flight
-        bool single_tap = env_int("AWR_DEEP_1X1", 0) != 0;
-        for (int p = 0; p < a->nphase && single_tap; ++p) single_tap = a->ph[p].ntaps == 1;
-        if (deep_on && aff != 2 && a->accum == 0 && ((int64_t)grid.x * grid.y <= deep_wgs || single_tap) && minsteps >= 8) {
-            if (aff == 3) launch_dma_em<TM, TN, 16, 4, 3>(a, grid, st, epre, em);
-            else if (aff == 1) launch_dma_em<TM, TN, 16, 4, 1>(a, grid, st, epre, em);
-            else launch_dma_em<TM, TN, 16, 4, 0>(a, grid, st, epre, em);
-            return;
-        }
-    }
-    if (aff == 2) launch_dma_em<TM, TN, 16, 2, 2>(a, grid, st, epre, em);
-    else if (aff == 3) launch_dma_em<TM, TN, 16, 2, 3>(a, grid, st, epre, em);
-    else if (aff == 1) launch_dma_em<TM, TN, 16, 2, 1>(a, grid, st, epre, em);
-    else launch_dma_em<TM, TN, 16, 2, 0>(a, grid, st, epre, em);
-}
 static void launch_dma(const awr_conv_args* a, int TM, int TN, dim3 grid, hipStream_t st, int mode, int aff, bool epre, int em) {
     if (TM == 2 && TN == 2) launch_dma_tile<2, 2>(a, grid, st, mode, aff, epre, em);
     else if (TM == 2 && TN == 1) launch_dma_tile<2, 1>(a, grid, st, mode, aff, epre, em);
@@ -2952,45 +41,20 @@ static void launch_dma(const awr_conv_args* a, int TM, int TN, dim3 grid, hipStr
     else launch_dma_tile<1, 1>(a, grid, st, mode, aff, epre, em);
 }
 
-template <int TM, int TN, int KP>
-static void launch_wgrad_dma_t(const awr_wgrad_args* a, bool dreg, bool greg, dim3 grid, hipStream_t st, int chunk, int wshift, int hshift) {
-    if (dreg && greg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, true, true>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
-    else if (dreg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, true, false>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
-    else if (greg) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, false, true>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
-    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<TM, TN, KP, false, false>), grid, dim3(256), 0, st, *a, chunk, wshift, hshift);
-}
-static void launch_wgrad_dma(const awr_wgrad_args* a, int TM, int TN, int kp, bool dreg, bool greg, dim3 grid, hipStream_t st, int chunk, int wshift, int hshift) {
-#define AWR_WD(tm, tn)                                                                                       \
-    do {                                                                                                     \
-        if (kp == 32) launch_wgrad_dma_t<tm, tn, 32>(a, dreg, greg, grid, st, chunk, wshift, hshift);        \
-        else launch_wgrad_dma_t<tm, tn, 16>(a, dreg, greg, grid, st, chunk, wshift, hshift);                 \
-    } while (0)
-    if (TM == 2 && TN == 2) AWR_WD(2, 2);
-    else if (TM == 2 && TN == 1) AWR_WD(2, 1);
-    else if (TM == 1 && TN == 2) AWR_WD(1, 2);
-    else AWR_WD(1, 1);
-#undef AWR_WD
-}
-
-// (plain functions, not lambdas, for the initialisers: hipcc 7.2 initialised a second namespace-scope `static int g = []() { ... }();` of one
-// translation unit with the FIRST lambda's body -- DESIGN.md 5, side finding of round 3)
-static int g_force_tm = 0, g_force_tn = 0, g_products = env_int("AWR_GEMM_PRODUCTS", 1);
-// Split-operand mode, weight gradients.  AWR_WGRAD_SPLIT=0 (round-5 study, profiles/r05_split_mode_studies.txt) runs them on the FP32-MFMA kernels instead
-// (kernel row, LDS-DMA per tap: exact fp32 products as well, and FASTER in isolation than the split-operand kernel whose staged rows are transposed and
-// cut in registers) -- and the step gets SLOWER: 10.77-10.91 -> 11.39-11.46 ms (a weight gradient runs beside the bf16 data-gradient chain; an FP32-MFMA
-// launch holds the matrix pipe three times as long per product).  Default: the split-operand weight gradient.
-static int g_wgrad_split = env_int("AWR_WGRAD_SPLIT", 1);
-static inline int wg_products() { return (g_products == 6 && g_wgrad_split) ? 6 : 1; }
-static int g_staging = env_int("AWR_DMA", 2);
-static int g_accum = env_int("AWR_ACCUM", 0);
-static int g_accum_auto_k = 1024;       // accum = 2 (auto): launches whose K extent reaches this many terms accumulate blocked
-
 extern "C" {
 
 int awr_debug_force_tile(int tm, int tn) {
     AWR_REQUIRE((tm == 0 && tn == 0) || ((tm == 1 || tm == 2) && (tn == 1 || tn == 2)), "force_tile: tm,tn must be 0,0 or in {1,2}");
     g_force_tm = tm;
     g_force_tn = tn;
+    return AWR_OK;
+}
+
+int awr_debug_set_knob(const char* name, int value) {
+    AWR_REQUIRE(name, "debug_set_knob: NULL name");
+    int* k = !strcmp(name, "deep") ? &g_knob_deep : !strcmp(name, "deep_1x1") ? &g_knob_deep_1x1 : !strcmp(name, "fast_stats") ? &g_knob_fast_stats : nullptr;
+    AWR_REQUIRE(k, "debug_set_knob: unknown knob '%s' (deep, deep_1x1, fast_stats)", name);
+    *k = value;
     return AWR_OK;
 }
 
@@ -3024,17 +88,23 @@ int awr_set_gemm_accum(int mode) {
 
 int awr_get_gemm_accum(void) { return g_accum; }
 
-int awr_set_gemm_accum_auto_k(int min_k) {
-    AWR_REQUIRE(min_k >= 256, "gemm_accum_auto_k: the threshold is a K extent >= 256 (shorter extents are one block anyway)");
+int awr_set_gemm_accum_auto(int min_k, int dgrad) {
+    AWR_REQUIRE(min_k >= 256, "gemm_accum_auto: the threshold is a K extent >= 256 (shorter extents are one block anyway)");
     g_accum_auto_k = min_k;
+    g_accum_auto_dgrad = dgrad != 0;
     return AWR_OK;
 }
 
-int awr_get_gemm_accum_auto_k(void) { return g_accum_auto_k; }
+int awr_get_gemm_accum_auto(int* min_k, int* dgrad) {
+    if (min_k) *min_k = g_accum_auto_k;
+    if (dgrad) *dgrad = g_accum_auto_dgrad;
+    return AWR_OK;
+}
 
-int awr_resolve_gemm_accum(int k_extent, int plain_launch) {
+int awr_resolve_gemm_accum(int k_extent, int kind) {
     if (g_accum != 2) return g_accum;
-    return (plain_launch && g_products == 1 && g_staging != 0 && k_extent >= g_accum_auto_k) ? 1 : 0;
+    if (kind != AWR_GEMM_FORWARD && !(kind == AWR_GEMM_DGRAD && g_accum_auto_dgrad)) return 0;
+    return (g_products == 1 && g_staging != 0 && k_extent >= g_accum_auto_k) ? 1 : 0;
 }
 
 static int conv_gemm_one(const awr_conv_args* a, void* stream);
@@ -3073,6 +143,7 @@ int awr_conv_gemm(const awr_conv_args* a, void* stream) {
     return AWR_OK;
 }
 
+#ifdef AWR_STUDY      // study form (round 5, measured slower on every shape: profiles/r05_half_batch_wavefront.txt); not in the default library
 // One of `nparts` equal batch parts of the launch `a` describes (images [part * B / nparts, (part + 1) * B / nparts)): images are independent rows of
 // the GEMM, so the parts are independent launches that may be issued at different points of a stream (the half-batch BatchNorm-backward wavefront of
 // the training plans: the data gradient of half A runs while half B's d(y) is still being written).  Deterministic mode: part p's workgroups take the
@@ -3100,6 +171,7 @@ int awr_conv_gemm_part(const awr_conv_args* a, int nparts, int part, void* strea
     if (a->stat_slots > 0) b.stat_slot_base = a->stat_slot_base + part * (a->stat_slots / nparts);      // (slot = (base + workgroup) % stat_slots, as in the > 4 GB chunk loop)
     return awr_conv_gemm(&b, stream);
 }
+#endif
 
 static int conv_gemm_one(const awr_conv_args* a_in, void* stream) {
     // output-store policy (awr_conv_args.out_nt): 0 = automatic -> streaming (`buffer_store ... nt`, the epilogue's operand loads too) when the output tensor is
@@ -3225,6 +297,7 @@ static int conv_gemm_one(const awr_conv_args* a_in, void* stream) {
     }
     const dim3 grid((unsigned)(blocks(TM, TN) / a->nphase), a->nphase);
     const bool aff = a->in_scale != nullptr || a->relu_in;
+#ifdef AWR_STUDY      // study form (round 5: 15-40 % slower than the in-register cut, profiles/r05_split_mode_studies.txt); not in the default library
     // split-operand mode with a PRE-CUT activation image (in_split): both operands by LDS-DMA (conv_gemm_sdma_body)
     static const int sdma_on = env_int("AWR_SPLIT_DMA", 1);      // 0: never (the same-box A/B hook back to the in-kernel cut)
     if (g_products == 6 && a->in_split && sdma_on) {
@@ -3246,6 +319,9 @@ static int conv_gemm_one(const awr_conv_args* a_in, void* stream) {
 #undef AWR_SDMA_EM
         return check_launch("conv_gemm_sdma_kernel");
     }
+#else
+    AWR_REQUIRE(!a->in_split, "conv_gemm: pre-cut activation images (in_split) are a study form: build the library with -DAWR_STUDY");
+#endif
     // short K loops (<= 8 slices) whose epilogue reads exactly one operand tensor: that tensor's rows are requested ahead (EPRE)
     static const bool no_epre = getenv("AWR_NO_EPRE") != nullptr;      // same-box A/B hook
     const bool epre = !no_epre && g_products == 1 && !a->in2 && a->nphase == 1 && a->ph[0].ntaps * (a->Cin / BK) <= 8 &&
@@ -3278,254 +354,6 @@ static int conv_gemm_one(const awr_conv_args* a_in, void* stream) {
     else AWR_LAUNCH_GEMM(1, 1);
 #undef AWR_LAUNCH_GEMM
     return check_launch("conv_gemm_kernel");
-}
-
-// geometry served by the one-wave-per-tap kernel: 3x3 (stride 1 / 2) and 4x4 stride-2 filters whose taps are listed row-major
-// from the top-left one, power-of-two D maps that a PH x 8 patch tiles
-static int wgrad_taps_patch_rows(const awr_wgrad_args* a) {
-    const int ks = a->T == 9 ? 3 : a->T == 16 ? 4 : 0;
-    if (!ks || (ks == 4 && a->sg != 2) || (a->sg != 1 && a->sg != 2)) return 0;
-    for (int t = 0; t < a->T; ++t)
-        if (a->dy[t] != a->dy[0] + t / ks || a->dx[t] != a->dx[0] + t % ks) return 0;
-    const int ph = a->sg == 1 ? 4 : 2;
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (!pow2(a->Hd) || !pow2(a->Wd) || a->Wd < 8 || a->Hd < ph) return 0;
-    return ph;
-}
-
-// launch geometry of one weight-gradient problem: algorithm, tile, split-K depth.  Shared by the launch and by
-// awr_conv_wgrad_splits (a deterministic-mode caller sizes its per-chunk copies of R with it)
-struct wgrad_launch {
-    int row_pw;         // > 0: one-workgroup-per-kernel-row kernel (3x3 stride 1), segments of this many pixels (8 | 16)
-    int taps_ph;        // > 0: one-wave-per-tap kernel with this patch height
-    int TM, TN, tiles;
-    int64_t nsplit, chunk;
-    int pc_log, pr_log;
-};
-
-static bool wgrad_row_ok(const awr_wgrad_args* a) {
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
-    bool ok = wg_products() == 1 && g_staging != 0 && a->T == 9 && a->sg == 1 && a->Hd == a->Hg && a->Wd == a->Wg && pow2(a->Wd) && pow2(a->Hd) && a->Wd >= 8 &&
-              a->Hd >= 2 && !a->d_scale && M < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24);
-    for (int t = 0; ok && t < 9; ++t) ok = a->dy[t] == t / 3 - 1 && a->dx[t] == t % 3 - 1;
-    return ok;
-}
-
-static int wgrad_plan(const awr_wgrad_args* a, wgrad_launch* w) {
-    AWR_REQUIRE(a->Cd % 4 == 0 && a->Cg % 4 == 0 && a->Cd > 0 && a->Cg > 0, "conv_wgrad: channel counts must be multiples of 4");
-    AWR_REQUIRE(a->T >= 1 && a->T <= 16 && a->ld >= a->Cg && a->sg >= 1, "conv_wgrad: bad geometry");
-    AWR_REQUIRE((a->d_scale == nullptr) == (a->d_shift == nullptr) && (a->g_scale == nullptr) == (a->g_shift == nullptr),
-                "conv_wgrad: scale/shift must come in pairs");
-    AWR_REQUIRE(a->algo >= 0 && a->algo <= 3, "conv_wgrad: algo must be 0 (automatic), 1 (workgroup per tap), 2 (wave per tap) or 3 (workgroup per kernel row)");
-    AWR_REQUIRE(a->split_stride >= 0 && (a->split_stride == 0 || a->max_split >= 1), "conv_wgrad: split_stride > 0 (deterministic K-chunk copies) needs max_split >= 1");
-    const int64_t M = (int64_t)a->B * a->Hd * a->Wd;
-    AWR_REQUIRE(M > 0 && M < (1LL << 31), "conv_wgrad: bad pixel count");
-    AWR_REQUIRE(M * a->Cd * 4 < (1LL << 32) && (int64_t)a->B * a->Hg * a->Wg * a->Cg * 4 < (1LL << 32),
-                "conv_wgrad: tensors must stay below 4 GB (32-bit buffer offsets)");
-    static const int env_algo = []() { const char* e = getenv("AWR_WGRAD_ALGO"); return e ? atoi(e) : 0; }();      // study hook
-    const int ph = wg_products() == 1 ? wgrad_taps_patch_rows(a) : 0;
-    const int algo = a->algo ? a->algo : (env_algo ? env_algo : 1);
-    AWR_REQUIRE(a->algo != 2 || ph, "conv_wgrad: algo 2 (wave per tap) does not serve this geometry / product mode");
-    w->taps_ph = 0;
-    w->row_pw = 0;
-    {   // one workgroup per kernel row: 3x3, stride 1, same-size power-of-two maps, taps row-major from the top-left one, D plain
-        const bool ok = wgrad_row_ok(a);
-        // default (algo 0): wherever the geometry allows -- isolated launches 121-136 TF against 105-127 for the best per-tap geometry with a
-        // plain gathered operand, 114-127 against 98-124 with the fused BatchNorm loader (since that became an in-LDS pass;
-        // profiles/r04_loop_exits.txt).  AWR_WGRAD_ROW=0: never; an explicit algo wins, and the plan autotuner times algo 3 against the
-        // per-tap geometries per launch.
-        static const int env_row = env_int("AWR_WGRAD_ROW", -1);
-        const bool want_row = env_row != 0;
-        AWR_REQUIRE(a->algo != 3 || ok, "conv_wgrad: algo 3 (workgroup per kernel row) serves 3x3 stride-1 filters on power-of-two maps >= 8 wide in the FP32-MFMA mode");
-        if (ok && (a->algo == 3 || (a->algo == 0 && want_row))) {
-            w->row_pw = a->Wd >= 16 ? 16 : 8;
-            const int64_t nstage = M / 16;
-            w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64) * 3;
-            // The workgroups of a launch are equally long, so the count that fits ONE generation of resident workgroups wins (five or six per
-            // CU by registers; isolated launches: 768 / 1024 / 1280 workgroups within 2 TF of each other, 1026 with the round's first build --
-            // two generations, the second almost empty -- 106 against 114-119; profiles/r04_microbench_wgrad_row.txt): floor, not ceil
-            const int want = a->target_blocks > 0 ? a->target_blocks : 1024;
-            int64_t nsplit = want / w->tiles;
-            if (nsplit > nstage / 8) nsplit = nstage / 8;            // at least 8 stages (128 pixels) per workgroup
-            if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
-            if (nsplit < 1) nsplit = 1;
-            w->chunk = (nstage + nsplit - 1) / nsplit;
-            w->nsplit = (nstage + w->chunk - 1) / w->chunk;
-            return AWR_OK;
-        }
-    }
-    if (ph && algo == 2) {
-        auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
-        w->taps_ph = ph;
-        w->pc_log = log2i(a->Wd / 8);
-        w->pr_log = log2i(a->Hd / ph);
-        const int64_t npatch = (int64_t)a->B << (w->pc_log + w->pr_log);
-        w->tiles = ((a->Cd + 63) / 64) * ((a->Cg + 63) / 64);
-        const int want = a->target_blocks > 0 ? a->target_blocks : 256;
-        int64_t nsplit = (want + w->tiles - 1) / w->tiles;
-        if (nsplit > npatch / 4) nsplit = npatch / 4;            // at least 4 K-slices per workgroup
-        if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
-        if (nsplit < 1) nsplit = 1;
-        w->chunk = (npatch + nsplit - 1) / nsplit;
-        w->nsplit = (npatch + w->chunk - 1) / w->chunk;
-        return AWR_OK;
-    }
-    // measured (tools/microbench_gemm.py, AWR_WGRAD_BLOCKS sweep): 64x64 tiles with ~3072 workgroups win on the small
-    // feature maps; the 128x64 (cd x cg) tile with ~2048 workgroups wins once there are >= 128K pixels to contract.
-    int TM = (a->Cd > 64 && M >= 131072) ? 2 : 1, TN = 1;
-    if (a->tile_m) {
-        AWR_REQUIRE((a->tile_m == 1 || a->tile_m == 2) && (a->tile_n == 1 || a->tile_n == 2), "conv_wgrad: tile_m/tile_n must be 1 or 2");
-        TM = a->tile_m;
-        TN = a->tile_n;
-    }
-    if (g_force_tm) { TM = g_force_tm; TN = g_force_tn; }
-    w->TM = TM;
-    w->TN = TN;
-    w->tiles = ((a->Cd + 64 * TM - 1) / (64 * TM)) * ((a->Cg + 64 * TN - 1) / (64 * TN)) * a->T;
-    static const int target_blocks = []() { const char* e = getenv("AWR_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning hook
-    const int want_blocks = a->target_blocks > 0 ? a->target_blocks : target_blocks ? target_blocks : (TM == 2 ? 2048 : 3072);
-    int64_t nsplit = (want_blocks + w->tiles - 1) / w->tiles;
-    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);   // at least 256 pixels per workgroup
-    if (nsplit > max_split) nsplit = max_split;
-    if (a->split_stride && nsplit > a->max_split) nsplit = a->max_split;
-    if (nsplit < 1) nsplit = 1;
-    int64_t chunk = (M + nsplit - 1) / nsplit;
-    chunk = (chunk + 63) / 64 * 64;
-    w->chunk = chunk;
-    w->nsplit = (M + chunk - 1) / chunk;
-    return AWR_OK;
-}
-
-int awr_conv_wgrad_algo_ok(const awr_wgrad_args* a, int algo) {
-    if (!a) return 0;
-    if (algo == 0 || algo == 1) return 1;
-    if (algo == 2) return wg_products() == 1 && wgrad_taps_patch_rows(a) > 0;
-    if (algo == 3) return wgrad_row_ok(a) ? 1 : 0;
-    return 0;
-}
-
-int awr_conv_wgrad_splits(const awr_wgrad_args* a, int* nsplit) {
-    AWR_REQUIRE(a && nsplit, "conv_wgrad_splits: null pointer");
-    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
-    int nchunk = 1;
-    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
-    awr_wgrad_args b = *a;
-    b.B = a->B / nchunk;
-    wgrad_launch w;
-    if (int e = wgrad_plan(&b, &w)) return e;
-    *nsplit = (int)w.nsplit * nchunk;          // batch chunks (tensors above 4 GB) take consecutive ranges of copies
-    return AWR_OK;
-}
-
-static int conv_wgrad_one(const awr_wgrad_args* a, void* stream) {
-    wgrad_launch w;
-    if (int e = wgrad_plan(a, &w)) return e;
-    hipStream_t st = as_stream(stream);
-    const dim3 grid((unsigned)w.tiles, (unsigned)w.nsplit);
-    if (w.row_pw) {
-        int wlog = 0, hlog = 0;
-        while ((1 << wlog) < a->Wd) ++wlog;
-        while ((1 << hlog) < a->Hd) ++hlog;
-        if (w.row_pw == 16) {
-            if (a->g_scale) hipLaunchKernelGGL((conv_wgrad_row_kernel<16, true>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
-            else hipLaunchKernelGGL((conv_wgrad_row_kernel<16, false>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
-        } else {
-            if (a->g_scale) hipLaunchKernelGGL((conv_wgrad_row_kernel<8, true>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
-            else hipLaunchKernelGGL((conv_wgrad_row_kernel<8, false>), grid, dim3(256), 0, st, *a, (int)w.chunk, wlog, hlog);
-        }
-        return check_launch("conv_wgrad_row_kernel");
-    }
-    if (w.taps_ph) {
-        if (a->T == 16) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 4, 2>), grid, dim3(1024), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
-        else if (a->sg == 2) hipLaunchKernelGGL((conv_wgrad_taps_kernel<2, 3, 2>), grid, dim3(768), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
-        else hipLaunchKernelGGL((conv_wgrad_taps_kernel<1, 3, 4>), grid, dim3(768), 0, st, *a, (int)w.chunk, w.pc_log, w.pr_log);
-        return check_launch("conv_wgrad_taps_kernel");
-    }
-    const int TM = w.TM, TN = w.TN;
-    const int64_t chunk = w.chunk;
-    auto log2i = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
-    int wshift = log2i(a->Wd), hshift = log2i(a->Hd);
-    if (wshift < 0 || hshift < 0) wshift = hshift = -1;
-    // FP32 kernel: multiply-free slice addressing when G's map sides are powers of two as well and both tensors hold < 2^24 pixels
-    // (packed into the hshift argument: bits 0-5 log2 Hd, bit 6 the flag, bits 8-13 log2 Wg, bits 16-21 log2 Hg)
-    int hshift_f32 = hshift;
-    {
-        const int gws = log2i(a->Wg), ghs = log2i(a->Hg);
-        static const bool no_fast = getenv("AWR_WGRAD_SLOW_ADDR") != nullptr;      // same-box A/B hook
-        if (!no_fast && wshift >= 0 && gws >= 0 && ghs >= 0 && (a->sg == 1 || a->sg == 2) && (int64_t)a->B * a->Hd * a->Wd < (1 << 24) &&
-            (int64_t)a->B * a->Hg * a->Wg < (1 << 24) && a->Cd * 4 < (1 << 24) && a->Cg * 4 < (1 << 24))
-            hshift_f32 = hshift | 64 | (gws << 8) | (ghs << 16);
-    }
-    // LDS-DMA staging (conv_wgrad_dma_kernel): the default whenever BOTH operands are plain (AWR_WGRAD_DMA: 0 = never, 1 = always, unset = that
-    // rule; AWR_WGRAD_KP = stage depth in pixels, 16 | 32).  Since its pipelined loop lost its exits (162 -> 100 / 96 -> 69 / 50 -> 36 registers)
-    // isolated launches with plain operands gain 5-7 % on every layer shape (profiles/r04_microbench_wgrad_dma.txt) and the ResNet18 step 0.8 %;
-    // an operand that still goes through registers (fused BatchNorm loader, bias-gradient column sums) gains nothing in isolation and the
-    // Hourglass step (nearly all of whose weight gradients have one) nothing either.
-    static const int wdma = env_int("AWR_WGRAD_DMA", -1);
-    static const int wkp = env_int("AWR_WGRAD_KP", 0);
-    if (wdma && g_staging && wg_products() == 1 && hshift_f32 >= 64) {
-        const bool dreg = a->d_scale != nullptr || a->d_colsum != nullptr, greg = a->g_scale != nullptr;
-        if (wdma > 0 || (!dreg && !greg)) {
-            const int kp = wkp ? wkp : ((TM == 1 && TN == 1) ? 32 : 16);
-            launch_wgrad_dma(a, TM, TN, kp, dreg, greg, grid, st, (int)chunk, wshift, hshift_f32);
-            return check_launch("conv_wgrad_dma_kernel");
-        }
-    }
-#define AWR_LAUNCH_WGRAD(tm, tn)                                                                                                          \
-    do {                                                                                                                                  \
-        if (wg_products() == 6) hipLaunchKernelGGL((conv_wgrad_split_kernel<tm, tn, 6>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift);       \
-        else if (hshift_f32 >= 64) hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn, true>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32); \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<tm, tn>), grid, dim3(256), 0, st, *a, (int)chunk, wshift, hshift_f32);                            \
-    } while (0)
-    if (TM == 2 && TN == 2) AWR_LAUNCH_WGRAD(2, 2);
-    else if (TM == 2 && TN == 1) AWR_LAUNCH_WGRAD(2, 1);
-    else if (TM == 1 && TN == 2) AWR_LAUNCH_WGRAD(1, 2);
-    else AWR_LAUNCH_WGRAD(1, 1);
-#undef AWR_LAUNCH_WGRAD
-    return check_launch("conv_wgrad_kernel");
-}
-
-// Deterministic mode (split_stride > 0): the caller sums ALL max_split K-chunk copies.  A launch may write fewer than it did when the caller sized them --
-// the kernel choice follows the process-wide product / staging modes at LAUNCH time (awr_set_gemm_products / awr_set_gemm_staging after the plan was
-// built) -- so the copies this launch leaves untouched are zero-filled here: the sum stays the gradient whatever the modes were switched to.
-static int wgrad_clear_unwritten(const awr_wgrad_args* a, int written, void* stream) {
-    AWR_REQUIRE(written <= a->max_split, "conv_wgrad: the launch writes %d K-chunk copies, the caller allocated %d", written, a->max_split);
-    if (written == a->max_split) return AWR_OK;
-    const size_t n = (size_t)(a->max_split - written);
-    if (hipMemsetAsync(a->R + (int64_t)written * a->split_stride, 0, n * (size_t)a->split_stride * sizeof(float), as_stream(stream)) != hipSuccess ||
-        (a->d_colsum && hipMemsetAsync(a->d_colsum + (int64_t)written * a->Cd, 0, n * (size_t)a->Cd * sizeof(float), as_stream(stream)) != hipSuccess)) {
-        set_error("conv_wgrad: clearing the unwritten K-chunk copies failed");
-        return AWR_ERR_HIP;
-    }
-    return AWR_OK;
-}
-
-int awr_conv_wgrad(const awr_wgrad_args* a, void* stream) {
-    AWR_REQUIRE(a && a->D && a->G && a->R, "conv_wgrad: null pointer");
-    const int64_t d_img = (int64_t)a->Hd * a->Wd * a->Cd, g_img = (int64_t)a->Hg * a->Wg * a->Cg;
-    int nchunk = 1;
-    while ((d_img * (a->B / nchunk) * 4 >= (1LL << 32) || g_img * (a->B / nchunk) * 4 >= (1LL << 32)) && a->B % (nchunk * 2) == 0) nchunk *= 2;
-    if (a->split_stride) {
-        int written = 0;
-        if (int e = awr_conv_wgrad_splits(a, &written)) return e;
-        if (int e = wgrad_clear_unwritten(a, written, stream)) return e;
-    }
-    if (nchunk == 1) return conv_wgrad_one(a, stream);
-    for (int c = 0; c < nchunk; ++c) {       // split-K over batch chunks: partial sums accumulate in R
-        awr_wgrad_args b = *a;
-        b.B = a->B / nchunk;
-        b.D = a->D + d_img * b.B * c;
-        b.G = a->G + g_img * b.B * c;
-        if (a->split_stride) {            // deterministic mode: every batch chunk writes its own range of K-chunk copies
-            wgrad_launch w;
-            if (int e = wgrad_plan(&b, &w)) return e;
-            b.R = a->R + (int64_t)c * w.nsplit * a->split_stride;
-            if (a->d_colsum) b.d_colsum = a->d_colsum + (int64_t)c * w.nsplit * a->Cd;
-        }
-        if (int e = conv_wgrad_one(&b, stream)) return e;
-    }
-    return AWR_OK;
 }
 
 }  // extern "C"

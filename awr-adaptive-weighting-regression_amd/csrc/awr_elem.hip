@@ -699,6 +699,7 @@ int awr_pack_weight(const float* w, int d0, int d1, int T, int transpose, int n_
     return check_launch("pack_weight_kernel");
 }
 
+#ifdef AWR_STUDY      // the pre-cut activation image of the split-operand study (awr_conv_args.in_split); not in the default library
 // eight consecutive channels per thread: two 16-byte reads, optional affine + ReLU, the exact three-way cut, three 16-byte writes (one per plane)
 __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                         int64_t n8, int C, char* __restrict__ split) {
@@ -741,6 +742,7 @@ int awr_split_act(const float* x, const float* scale, const float* shift, int re
     hipLaunchKernelGGL(split_act_kernel, dim3(nblk(n8)), dim3(256), 0, as_stream(stream), x, scale, shift, relu, n8, C, static_cast<char*>(split));
     return check_launch("split_act_kernel");
 }
+#endif
 
 int awr_split_weight(const float* packed, void* split, int64_t n, void* stream) {
     AWR_REQUIRE(packed && split && n > 0 && n % 32 == 0, "split_weight: n must be a positive multiple of 32");

@@ -1,0 +1,7 @@
+// LDS-DMA implicit GEMM (forward / data gradients), workgroup tile 64 x 64 waves-tiles: every epilogue / prologue / accumulation variant of
+// this tile shape (csrc/awr_gemm_launch.inc).  Split by tile so that the four shapes compile in parallel.
+#include "awr_gemm_launch.inc"
+
+namespace awr {
+template void launch_dma_tile<1, 1>(const awr_conv_args*, dim3, hipStream_t, int, int, bool, int);
+}  // namespace awr

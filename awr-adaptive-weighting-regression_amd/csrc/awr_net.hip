@@ -331,7 +331,8 @@ static Prob dgrad_problem(const Spec& s, int hin, int win) {
     return Prob{ho, wo, s.cout_pad, hin, win, s.cin_pad, hin / 2, win / 2, 2, 1, ph, full};
 }
 
-static void fill_conv_args(awr_conv_args& a, const Prob& p, int B, const float* in, const float* w, const void* w_split, float* out, int T) {
+static void fill_conv_args(awr_conv_args& a, const Prob& p, int B, const float* in, const float* w, const void* w_split, float* out, int T,
+                           int kind = AWR_GEMM_OTHER) {
     memset(&a, 0, sizeof a);
     a.in = in; a.w = w; a.out = out; a.w_split = w_split;
     a.B = B; a.Hin = p.Hin; a.Win = p.Win; a.Cin = p.Cin;
@@ -341,7 +342,7 @@ static void fill_conv_args(awr_conv_args& a, const Prob& p, int B, const float* 
     {   // the accumulation order is captured when the plan is built, like the deterministic mode; AUTO resolves per launch by its K extent
         size_t taps = 0;
         for (auto& ph : p.phases) taps = std::max(taps, ph.taps.size());
-        a.accum = awr_resolve_gemm_accum((int)taps * p.Cin, 1);
+        a.accum = awr_resolve_gemm_accum((int)taps * p.Cin, kind);
     }
     for (int i = 0; i < a.nphase; ++i) {
         a.ph[i].py = p.phases[i].py;
@@ -892,7 +893,11 @@ struct Builder {
             // shape (ResNet18 12.8 -> 13.4 ms, Hourglass-1 23.5 -> 24.7 ms at 32 768 rows per half: two half-batch data gradients lose more than the
             // hidden apply pass wins; profiles/r05_half_batch_wavefront.txt).  AWR_HALF_BNB_MIN_ROWS = rows of the data-gradient GEMM per half from
             // which a layer takes part (read per plan); 0 = off, the default.
+#ifdef AWR_STUDY
             const int64_t half_min = env_or("AWR_HALF_BNB_MIN_ROWS", 0);
+#else
+            const int64_t half_min = 0;      // (the wavefront's scheduling states exist in study builds only: ADVICE r5)
+#endif
             y->half_ok = P.training && half_min > 0 && !o.res && x->needs_grad && B % 2 == 0 && (int64_t)(B / 2) * x->H * x->W >= half_min;
         }
         if (o.want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, (int)prob.phases.size()), prob.N);
@@ -905,7 +910,7 @@ struct Builder {
         }
         P.cargs.emplace_back();
         awr_conv_args* a = &P.cargs.back();
-        fill_conv_args(*a, prob, B, x->buf, layer->p_fwd.p, layer->p_fwd.split, y->buf, spec.T());
+        fill_conv_args(*a, prob, B, x->buf, layer->p_fwd.p, layer->p_fwd.split, y->buf, spec.T(), P.training ? AWR_GEMM_FORWARD : AWR_GEMM_OTHER);
         a->in_scale = o.in_scale; a->in_shift = o.in_shift; a->bias = bias;
         a->out_scale = o.out_scale; a->out_shift = o.out_shift;
         a->res = o.res ? o.res->buf : nullptr;
@@ -951,7 +956,7 @@ struct Builder {
         const Spec &s2 = c2->spec, &s3 = c3->spec;
         const int64_t wgs = ((int64_t)x->B * x->H * x->W + 63) / 64;
         const int n1 = s2.cout;
-        if (off || P.training || awr_resolve_gemm_accum(s2.T() * s2.cin_pad, 1) != 0 || awr_resolve_gemm_accum(s3.cin_pad, 1) != 0 || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
+        if (off || P.training || awr_resolve_gemm_accum(s2.T() * s2.cin_pad, AWR_GEMM_OTHER) != 0 || awr_resolve_gemm_accum(s3.cin_pad, AWR_GEMM_OTHER) != 0 || awr_get_gemm_products() != 1 || s2.deconv || s3.deconv || s2.stride != 1 || s3.k != 1 || s3.stride != 1 ||
             (n1 != 128 && n1 != 64) || s3.cin != n1 || s3.cout != 2 * n1 || wgs < min_wgs || x->lazy || (dual && no_dual))
             return nullptr;
         if (dual && (dual->sk->spec.k != 1 || dual->sk->spec.stride != 1 || dual->sk->spec.cout != s3.cout || dual->sk->spec.cin_pad % 32 != 0 ||
@@ -1034,7 +1039,7 @@ struct Builder {
         if (want_stats) y->stats = stat_buf(gemm_slots(B, prob.Hq, prob.Wq, prob.N, 1), prob.N);
         P.cargs.emplace_back();
         awr_conv_args* ca = &P.cargs.back();
-        fill_conv_args(*ca, prob, B, a->buf, d->p.p, nullptr, y->buf, 1);
+        fill_conv_args(*ca, prob, B, a->buf, d->p.p, nullptr, y->buf, 1, P.training ? AWR_GEMM_FORWARD : AWR_GEMM_OTHER);
         ca->in2 = x->buf;
         ca->Cin1 = cin1;
         if (a->lazy) { ca->in_scale = a->lz_scale; ca->in_shift = a->lz_shift; ca->relu_in = a->lz_relu; }
@@ -1168,12 +1173,13 @@ struct Builder {
             }
             P.cargs.emplace_back();
             awr_conv_args* da = &P.cargs.back();
-            fill_conv_args(*da, dp, B, y->lz_g ? y->lz_g : dy, layer->p_dgrad.p, layer->p_dgrad.split, gx, spec.T());
+            fill_conv_args(*da, dp, B, y->lz_g ? y->lz_g : dy, layer->p_dgrad.p, layer->p_dgrad.split, gx, spec.T(), AWR_GEMM_DGRAD);
             if (y->lz_g) { da->in_bnb_y = y->buf; da->in_bnb_coef = y->lz_lin4; }
             da->res = acc ? gx : nullptr;
             // remember who wrote d(x), in order: a full-coverage dgrad that is the LAST producer can host the fused BN-backward reduction
             P.grad_writers[x].push_back(dp.full ? da : nullptr);
             const std::string dname = "awr_conv_dgrad:" + layer->name;
+#ifdef AWR_STUDY
             if (y->half_dy && res == nullptr) {      // d(y) arrives half by half (bn_bwd): part 0 now, part 1 behind the record of half B
                 Op& d0 = b(dname, [da](void* s) { return awr_conv_gemm_part(da, 2, 0, s); });
                 d0.gemm = true;
@@ -1183,7 +1189,9 @@ struct Builder {
                 Op& d1 = b(dname + "/b", [da](void* s) { return awr_conv_gemm_part(da, 2, 1, s); });
                 d1.gemm = true;
                 d1.macs = 0.5 * layer_macs;
-            } else {
+            } else
+#endif
+            {
                 if (y->half_dy) {      // (cannot happen: half_ok excludes a fused residual) -- still correct: wait for half B first
                     Op& hw = b("__halfwait__", nullptr);
                     hw.kind = OP_HALFWAIT;
@@ -2591,11 +2599,13 @@ static void dp_bucket(void* user, int64_t lo, int64_t hi, void* stream) {
 
 int awr_plan_set_dp(awr_plan* p, awr_dp* dp) {
     AWR_REQUIRE(p && p->built_bwd, "plan_set_dp: needs a training plan");
-    if (dp && !p->dp) {
+    AWR_REQUIRE(!dp || awr_dp_generation(dp) != 0, "plan_set_dp: not a live communicator");      // (before any state changes)
+    // the host's own callback is saved when the plan's takes its place -- not when it is ALREADY in place (a re-attach after a lost
+    // communicator, p->dp == NULL with bucket_cb == dp_bucket, must not overwrite the saved callback with dp_bucket itself)
+    if (dp && p->bucket_cb != dp_bucket) {
         p->saved_cb = p->bucket_cb;
         p->saved_user = p->bucket_user;
     }
-    AWR_REQUIRE(!dp || awr_dp_generation(dp) != 0, "plan_set_dp: not a live communicator");
     p->dp = dp;
     p->dp_gen = dp ? awr_dp_generation(dp) : 0;
     p->dp_error = 0;

@@ -18,6 +18,12 @@ from . import _lib as L
 from .engine import PARAM_KINDS, NetHandle, Plan
 
 
+def _auto_rule():
+    k, d = L.C.c_int(0), L.C.c_int(0)
+    L.call("awr_get_gemm_accum_auto", L.C.byref(k), L.C.byref(d))
+    return (k.value, d.value)
+
+
 class _Node(nn.Module):
     """Anonymous container: the module tree exists only to reproduce the reference's state_dict keys."""
 
@@ -144,10 +150,12 @@ class AwrBackbone(nn.Module):
     # ---- execution ----------------------------------------------------------------------------------
     def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1, accum=None):
         """accum: None = the process-wide mode (awr_amd.set_gemm_accum), "ordered" / "blocked" / "auto" = this plan's own (awr_conv_args.accum;
-        "auto" blocks the launches whose K extent reaches awr_get_gemm_accum_auto_k() terms, include/awr_hip.h)."""
+        "auto" blocks the forward launches whose K extent reaches awr_get_gemm_accum_auto()'s threshold, include/awr_hip.h)."""
         if not self._arena.is_cuda:
             raise L.AwrError("the AWR backbone runs on the MI355X only: call .cuda() first (there is no CPU path)")
         acc = int(L.lib.awr_get_gemm_accum()) if accum is None else {"ordered": 0, "blocked": 1, "auto": 2}[accum]
+        if acc == 2 and not training:
+            acc = 0          # auto never blocks an evaluation plan's launches (include/awr_hip.h): the same plan as "ordered"
         if acc and (int(L.lib.awr_get_gemm_products()) != 1 or int(L.lib.awr_get_gemm_staging()) == 0):
             # the blocked kernel exists for the FP32-MFMA mode with LDS-DMA staging only (include/awr_hip.h: awr_conv_args.accum): fail here, at
             # build time and by name, rather than at the first launch -- "auto" never asks for what cannot run, so it degrades to ordered
@@ -155,7 +163,7 @@ class AwrBackbone(nn.Module):
                 raise L.AwrError("blocked accumulation (the parity mode) needs gemm_products = 1 and LDS-DMA staging; this process runs "
                                  "products = %d, staging = %d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging()))
         key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets, L.lib.awr_get_deterministic(), acc,
-               int(L.lib.awr_get_gemm_accum_auto_k()) if acc == 2 else 0)
+               _auto_rule() if acc == 2 else 0)
         plan = self._plans.get(key)
         if plan is None:
             was = int(L.lib.awr_get_gemm_accum())

@@ -315,30 +315,55 @@ class Augmenter:
 
 class NYU(torch.utils.data.Dataset):
     def __init__(self, root, phase, val=False, img_size=128, aug_para=None, cube=(300, 300, 300), jt_num=14):
-        assert phase in ("train", "test")
         import scipy.io as sio
-        self.name, self.root, self.phase, self.val = "nyu", root, phase, val
-        self.paras, self.flip = PARAS, -1
-        self.cube = np.asarray(cube, dtype=np.float64)
-        self.dsize = np.asarray([img_size, img_size])
-        self.img_size, self.jt_num, self.aug_para = img_size, jt_num, aug_para
+        self._common(root, phase, val, img_size, aug_para, cube, jt_num)
         data_path = "{}/{}".format(root, phase)
         files = sorted(glob(data_path + "/depth_1*.png"))
         labels = sio.loadmat("{}/joint_data.mat".format(data_path))
         self.labels_xyz = labels["joint_xyz"][0][:, JOINT, :][:, EVAL, :]
         centers = np.loadtxt("{}/center_{}_refined.txt".format(root, phase)).reshape(-1, 3)
         n = min(len(files), len(self.labels_xyz), len(centers))
-        self.files, self.centers = files[:n], centers[:n]
+        self.files, self.centers, self.frames = files[:n], centers[:n], None
+        self._cubes(n)
+        print("loading dataset, containing %d images." % n)
+
+    def _common(self, root, phase, val, img_size, aug_para, cube, jt_num):
+        assert phase in ("train", "test")
+        self.name, self.root, self.phase, self.val = "nyu", root, phase, val
+        self.paras, self.flip = PARAS, -1
+        self.cube = np.asarray(cube, dtype=np.float64)
+        self.dsize = np.asarray([img_size, img_size])
+        self.img_size, self.jt_num, self.aug_para = img_size, jt_num, aug_para
+        self.aug = Augmenter(self.paras, self.flip)
+
+    def _cubes(self, n):
         self.test_cube = np.ones([max(n, 8252), 3]) * self.cube
         self.test_cube[2440:, :] = self.test_cube[2440:, :] * 5.0 / 6.0           # nyu_loader.py:31-32
-        self.aug = Augmenter(self.paras, self.flip)
-        print("loading dataset, containing %d images." % n)
+
+    @classmethod
+    def from_arrays(cls, frames, labels_xyz, centers, phase, frame_of=None, val=False, img_size=128, aug_para=None, cube=(300, 300, 300), jt_num=14):
+        """The same dataset over decoded frames held in memory ((n_frames, 480, 640) depth in mm, e.g. the uint16 cache of
+        awr_amd.nyu_device.build_frame_cache) instead of a PNG directory: labels_xyz (n, J, 3) camera-space joints, centers (n, 3) refined
+        hand centres, frame_of[i] = the frame of sample i (default i)."""
+        self = cls.__new__(cls)
+        self._common(None, phase, val, img_size, aug_para, cube, jt_num)
+        self.frames, self.labels_xyz, self.centers = frames, np.asarray(labels_xyz), np.asarray(centers, np.float64).reshape(-1, 3)
+        n = len(self.centers)
+        self.files = [None] * n
+        self.frame_of = np.arange(n) if frame_of is None else np.asarray(frame_of)
+        self._cubes(n)
+        return self
+
+    def read_frame(self, index):
+        if self.frames is None:
+            return read_depth_png(self.files[index])
+        return np.asarray(self.frames[self.frame_of[index]], dtype=np.float32)
 
     def __len__(self):
         return len(self.files)
 
     def __getitem__(self, index):
-        img = read_depth_png(self.files[index])
+        img = self.read_frame(index)
         jt_xyz = self.labels_xyz[index].astype(np.float64).copy()
         cube = self.test_cube[index] if self.phase == "test" else self.cube
         center_xyz = self.centers[index].astype(np.float64).copy()

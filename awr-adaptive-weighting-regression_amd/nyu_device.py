@@ -168,8 +168,22 @@ class DeviceNYU(ND.NYU):
 
     def __init__(self, root, phase, frame_shape=(480, 640), **kw):
         super().__init__(root, phase, **kw)
-        self.aug = ParamAugmenter(self.paras, self.flip)
         self.fh, self.fw = frame_shape
+        self.frame_of = np.arange(len(self.files))
+
+    def _common(self, *a):
+        super()._common(*a)
+        self.aug = ParamAugmenter(self.paras, self.flip)
+        self.fh, self.fw = 480, 640
+
+    @classmethod
+    def from_arrays(cls, frames, *a, **kw):
+        """labels / centres as nyu_data.NYU.from_arrays; `frames` only lends its shape (or pass the (n, fh, fw) shape tuple): the pixels
+        are the FrameStore's business."""
+        shape = tuple(frames) if isinstance(frames, (tuple, list)) else tuple(frames.shape)
+        self = super().from_arrays(None, *a, **kw)
+        self.fh, self.fw = int(shape[-2]), int(shape[-1])
+        return self
 
     def __getitem__(self, index):
         blk = L.NyuSample()
@@ -178,7 +192,7 @@ class DeviceNYU(ND.NYU):
         center_xyz = self.centers[index].astype(np.float64).copy()
         center_uvd = xyz2uvd(center_xyz, self.paras, self.flip).astype(np.float64)
         jt_xyz -= center_xyz
-        M = set_crop(blk, index, center_uvd, cube, self.dsize, self.paras, self.fh, self.fw)
+        M = set_crop(blk, self.frame_of[index], center_uvd, cube, self.dsize, self.paras, self.fh, self.fw)
         if self.phase == "train" and not self.val:
             op, trans, scale, rot = self.aug.random_aug(*(self.aug_para or (None, None, None)))
             self.aug.begin(blk)

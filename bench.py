@@ -118,6 +118,113 @@ def cpu_baseline():
                       "is the same step at the best thread count of a {8,16,32,64,all} sweep (1 warm-up, median of 3)" % (cores, cores)}
 
 
+def synth_nyu(n_frames, n_samples, seed=77):
+    """Synthetic NYU-layout data for the data-path record: uint16 480 x 640 depth frames (far wall, a tilted hand-sized disc around the
+    refined centre, 5 % sensor holes), camera-space joints around the centre, refined centres; sample i uses frame i % n_frames."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:480, 0:640]
+    frames, fc = np.empty((n_frames, 480, 640), np.uint16), []
+    for k in range(n_frames):
+        c = np.array([rng.uniform(-120, 120), rng.uniform(-80, 80), rng.uniform(600, 950)])
+        u, v = 588.03 * c[0] / c[2] + 320.0, -587.07 * c[1] / c[2] + 240.0
+        d = np.full((480, 640), 1500.0 + rng.uniform(-200, 200))
+        hand = (xx - u) ** 2 + (yy - v) ** 2 < (70 * 750.0 / c[2]) ** 2
+        d[hand] = c[2] + 0.3 * (xx[hand] - u) - 0.2 * (yy[hand] - v) + rng.uniform(-3, 3, int(hand.sum()))
+        d[rng.rand(480, 640) < 0.05] = 0
+        frames[k] = np.round(d).astype(np.uint16)
+        fc.append(c)
+    frame_of = np.arange(n_samples) % n_frames
+    centers = np.array(fc)[frame_of]
+    raw = centers[:, None, :] + rng.uniform(-70, 70, (n_samples, 36, 3))        # joint_data.mat layout: 36 joints, nyu_loader.py:9-11 selects 14
+    return frames, raw, centers, frame_of
+
+
+def measure_data_path(awr_amd, O, dev, headline_ms, steps, warmup, batch=64, workers=8):
+    """SURVEY 8f-2 / VERDICT r5 item 1: what feeds the engine.  (i) the host loader (awr_amd.nyu_data: the reference's per-sample numpy
+    pipeline, dataloader/loader.py:19-179, PNG decode excluded) on ONE core; (ii) the device path's host half (parameter blocks + labels)
+    on one core and its kernel alone; (iii) the BASELINE configs[1] train step fed by the device path: a DataLoader of `workers` processes
+    yields parameter blocks (the reference's num_workers = 8, config.py:37), ONE awr_nyu_batch launch renders the batch from the frames
+    resident in HBM, the engine steps on it -- images and labels differ every step."""
+    import numpy as np
+    from awr_amd import nyu_data as ND, nyu_device as DV
+    from awr_amd.trainer import TrainEngine
+    n_frames, n_samples = 256, batch * (steps + warmup + 4)
+    frames, raw, centers, frame_of = synth_nyu(n_frames, n_samples)
+    labels = raw[:, ND.JOINT][:, ND.EVAL]
+    kw = dict(frame_of=frame_of, img_size=128, aug_para=[10, 0.1, 180])
+    host = ND.NYU.from_arrays(frames, labels, centers, "train", **kw)
+    devd = DV.DeviceNYU.from_arrays(frames.shape, labels, centers, "train", **kw)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 3.0:
+            host[n % n_samples]
+            n += 1
+        cpu_rate = n / (time.perf_counter() - t0)
+        t0, m = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.5:
+            devd[m % n_samples]
+            m += 1
+        param_rate = m / (time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    store = DV.FrameStore(frames)
+    render = DV.Renderer(store, 128, batch)
+    blocks = torch.stack([devd[i][0] for i in range(batch)])
+    out = torch.empty((batch, 1, 128, 128), device=dev)
+    for _ in range(5):
+        render(blocks, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        render(blocks, out)
+    e1.record()
+    torch.cuda.synchronize()
+    render_us = e0.elapsed_time(e1) * 1e3 / 50          # includes the 12.8 KB block upload of each call
+    render.check(batch)
+    # bit-exactness spot check against the host loader inside the record (fresh datasets: the two random streams start together)
+    h2 = ND.NYU.from_arrays(frames, labels, centers, "train", **kw)
+    d2 = DV.DeviceNYU.from_arrays(frames.shape, labels, centers, "train", **kw)
+    same = all(torch.equal(render(d2[i][0][None]).cpu()[0], h2[i][0]) for i in range(16))
+    # (iii) the fed train step
+    torch.manual_seed(0)
+    net = _make_net(awr_amd, "resnet_18").cuda()
+    eng = TrainEngine(net, batch, 128, 1.0, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False)
+    img0, jt0 = O.synth_batch(batch, 128, 14, seed=1234)
+    eng.compile(img0.to(dev), jt0.to(dev))
+    loader = torch.utils.data.DataLoader(devd, batch_size=batch, shuffle=False, num_workers=workers, drop_last=True, pin_memory=True,
+                                         persistent_workers=False, prefetch_factor=4 if workers else None)
+    it = iter(loader)
+    t_start = None
+    for k in range(warmup + steps):
+        if k == warmup:
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+        blk, _, jt_uvd, _, _, _ = next(it)
+        eng.step(render(blk), jt_uvd.to(dev, non_blocking=True))
+    torch.cuda.synchronize()
+    fed_ms = (time.perf_counter() - t_start) / steps * 1e3
+    loss = float(eng.losses[2])
+    del it, loader, eng, net
+    torch.cuda.empty_cache()
+    cores, model = _host_cpu()
+    return {"frames": "synthetic uint16 480x640, %d frames resident in HBM (%.0f MB)" % (n_frames, store.nbytes / 1e6),
+            "cpu_loader": {"samples_per_s_per_worker": round(cpu_rate, 1), "cores_used": 1, "cpu_model": model, "host_cores": cores,
+                           "what": "awr_amd.nyu_data.NYU.__getitem__ (crop + one of trans/scale/rot/none + normalise + labels), PNG decode excluded, 3 s sample"},
+            "device_loader": {"host_param_blocks_per_s_per_worker": round(param_rate, 1),
+                              "render_us_per_batch": round(render_us, 2), "render_samples_per_s": round(batch / render_us * 1e6, 0),
+                              "render_gbps_out": round(batch * 128 * 128 * 4 / render_us / 1e3, 1), "batch": batch,
+                              "bit_identical_to_host_loader": bool(same), "checked_samples": 16},
+            "train_fed": {"workload": "resnet_18 train step, batch %d, every batch rendered by awr_nyu_batch from HBM-resident frames, parameter blocks + labels from "
+                                      "a DataLoader with %d worker processes" % (batch, workers), "steps": steps, "warmup": warmup,
+                          "ms_per_step": round(fed_ms, 3), "value": round(batch / fed_ms * 1e3, 2), "unit": "images/s",
+                          "vs_synthetic_headline": round(headline_ms / fed_ms, 4), "final_loss": loss},
+            "speedup_per_worker_vs_cpu_loader": round(param_rate / cpu_rate, 1)}
+
+
 def _make_net(awr_amd, name, J=14):
     """'resnet_<18|50|101|152>' | 'hourglass_<n>' (train.py:51-57)"""
     return awr_amd.get_deconv_net(int(name.split("_")[1]), J, 2) if name.startswith("resnet") else awr_amd.PoseNet(name, J)
@@ -346,6 +453,7 @@ def main():
                                                                "the per-bucket all-reduce timeline is reported either way when N > 1")
     ap.add_argument("--no-hourglass-train", action="store_true", help="skip the Hourglass training sub-records 'hg1_train_b64' and 'config5'")
     ap.add_argument("--no-b256", action="store_true", help="skip the config-4 per-GPU shape (batch 256) sub-record")
+    ap.add_argument("--no-data-path", action="store_true", help="skip the 'data_path' sub-record (host loader vs device loader, train step fed by the device path)")
     ap.add_argument("--no-accurate-mode", action="store_true", help="skip the blocked-accumulation (parity mode) sub-record 'accurate_mode'")
     ap.add_argument("--no-native-rccl", action="store_true", help="N > 1: skip the 'native_rccl' sub-record (same steps, gradient buckets exchanged by the "
                                                                   "library's own RCCL communicator instead of torch.distributed work objects)")
@@ -635,6 +743,13 @@ def main():
                                                      "hourglass_1 NYU-shape 128x128 J=14 train step, batch 64")
                 out["config5"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,
                                                "hourglass_2 256x256 J=21 train step, batch 128/GPU = BASELINE configs[4] per-GPU shape")
+        if world == 1 and nprod == 1 and not args.no_data_path and args.net == "resnet_18" and args.batch == 64 and not args.deterministic:
+            eng = None
+            torch.cuda.empty_cache()
+            try:
+                out["data_path"] = measure_data_path(awr_amd, O, dev, out["ms_per_step"], max(args.steps, 20), 5)
+            except Exception as e:          # (the headline has been measured: report, do not lose the line)
+                out["data_path"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and nprod == 1 and not args.no_accurate_mode and not args.deterministic:
             # the parity mode (blocked accumulation: awr_conv_args.accum = 1, what Trainer.test scores with and TrainEngine(accum="blocked") trains
             # with): the headline's step at the same batch, the scoring pass at batch 128, and the joint error against the oracle in that mode

@@ -254,9 +254,11 @@ typedef struct awr_conv_args {
 /* conv / transposed conv forward and data-gradient (all are the same gather-GEMM).
  * Replaces nn.Conv2d / nn.ConvTranspose2d forward and their dgrad. */
 int awr_conv_gemm(const awr_conv_args* a, void* stream);
-/* one of `nparts` equal batch parts of that launch (B % nparts == 0): images are independent rows of the GEMM.  The training plans issue a data
- * gradient as two half-batch parts so that the first runs while the BatchNorm-backward pass of the second half is still writing */
+#ifdef AWR_STUDY
+/* STUDY BUILDS ONLY (-DAWR_STUDY; the default library does not export it): one of `nparts` equal batch parts of that launch (B % nparts == 0) --
+ * the half-batch BatchNorm-backward wavefront of round 5 (AWR_HALF_BNB_MIN_ROWS), measured slower on every shape */
 int awr_conv_gemm_part(const awr_conv_args* a, int nparts, int part, void* stream);
+#endif
 /* test hook: force the (TM,TN) in {1,2}^2 workgroup tile of awr_conv_gemm / awr_conv_wgrad
  * (0,0 = automatic choice).  Not for production use. */
 int awr_debug_force_tile(int tm, int tn);
@@ -269,10 +271,13 @@ int awr_debug_force_tile(int tm, int tn);
  * Replaces nothing in the reference (torch's conv precision is whatever cuDNN / oneDNN pick; cuDNN defaults to TF32). */
 int awr_set_gemm_products(int n);
 int awr_get_gemm_products(void);
-/* split image of an activation tensor x (npix, C), C % 32 == 0: every element [relu](x * scale[c] + shift[c]) (scale / shift optional) cut EXACTLY
+#ifdef AWR_STUDY
+/* STUDY BUILDS ONLY (-DAWR_STUDY; the default library exports neither this nor the kernel that reads awr_conv_args.in_split: 15-40 % slower than
+ * the in-register cut, profiles/r05_split_mode_studies.txt).  Split image of an activation tensor x (npix, C), C % 32 == 0: every element [relu](x * scale[c] + shift[c]) (scale / shift optional) cut EXACTLY
  * into three bf16 pieces, element idx -> shorts (idx / 32) * 96 + idx % 32 + {0, 32, 64} (the format of awr_split_weight).  What awr_conv_args.in_split
  * reads: a BatchNorm + ReLU output that the FP32 mode never materialises is written ONCE here instead of being cut per (tap, column tile) in the GEMM. */
 int awr_split_act(const float* x, const float* scale, const float* shift, int relu, int64_t npix, int C, void* split, void* stream);
+#endif
 /* the product mode awr_conv_wgrad runs in: awr_get_gemm_products(), unless $AWR_WGRAD_SPLIT=0 sends the split mode's weight gradients to the FP32-MFMA
  * kernels (a measured-slower study arm: profiles/r05_split_mode_studies.txt) */
 int awr_get_wgrad_products(void);
@@ -281,22 +286,33 @@ int awr_get_wgrad_products(void);
  *       (weights always; activations whenever no fused input affine / ReLU has to touch them on the way in);
  *   0 = global -> registers -> ds_write -> LDS (rounds 1-3; kept as the same-box A/B reference and for split-K / fused pairs).
  * Results are bit-identical between the two (same k order).  Replaces nothing in the reference. */
+/* Launch-path study knobs (cached at load from $AWR_DEEP / $AWR_DEEP_1X1 / $AWR_FAST_STATS): "deep" = deep pipeline for small launches (1),
+ * "deep_1x1" = ... for every single-tap launch (0), "fast_stats" = BatchNorm statistics summed from the accumulators (1).  Results are
+ * bit-identical either way except the statistics' summation order ("fast_stats"); tests and same-box A/Bs only. */
+int awr_debug_set_knob(const char* name, int value);
 int awr_set_gemm_staging(int mode);
 int awr_get_gemm_staging(void);
-/* Accumulation order of the forward / data-gradient GEMMs of plans created from now on (process-wide; default 0, or $AWR_ACCUM):
- * 0 = ordered, 1 = blocked (awr_conv_args.accum), 2 = AUTO: a launch is blocked when its K extent (taps x input channels of its longest
- * phase) reaches awr_get_gemm_accum_auto_k() terms (default 1 024: ResNet18's layer2-4 3x3 convolutions and every transposed-convolution
- * phase) and it is a plain launch the blocked kernel exists for (FP32-MFMA, LDS-DMA staging, no fused pair / split-K), ordered otherwise.
- * The rounding error of an ordered chain grows with its length while the cost of blocking (a second accumulator set: one resident wave
- * per SIMD on the wider tiles) falls with the tile count, so AUTO buys most of blocked's accuracy for a fraction of its cost: TrainEngine's
- * default.  Blocked brings a convolution's rounding error down to torch-CPU's: the parity mode (InferEngine(parity=True),
- * TrainEngine(accum="blocked")).  awr_resolve_gemm_accum: what a launch of that K extent gets under the current mode (what plan
+/* Accumulation order of the forward / data-gradient GEMMs of plans created from now on (process-wide; default 2, or $AWR_ACCUM):
+ * 0 = ordered, 1 = blocked (awr_conv_args.accum), 2 = AUTO (the default): a plain FORWARD launch of a TRAINING plan (FP32-MFMA, LDS-DMA
+ * staging, no fused pair / split-K: what the blocked kernel exists for) is blocked when its K extent (taps x input channels of its longest
+ * phase) reaches min_k terms (default 576: every 3x3 convolution from 64 channels up and the transposed convolutions), everything else --
+ * data gradients, evaluation plans -- is ordered.  Why this split: the joints a network returns are a function of its forward GEMMs only;
+ * training-mode BatchNorm divides by batch statistics, which is where a long ordered chain's rounding error (it grows with the chain) gets
+ * amplified, while eval-mode plans measure no difference (1.851e-4 mm from the oracle either way); and blocking costs a second accumulator
+ * set (occupancy 4 -> 2-3 waves per SIMD on the 128x128 tile), +4.5 % on the ResNet18 step when every launch is blocked, +1.3 % for the
+ * training forward alone (profiles/r06_accum_modes.txt) -- for which the joints of the two-image training-mode fixtures land CLOSER to
+ * float64 than the fp32 oracle's own.  awr_set_gemm_accum_auto(min_k, dgrad): the threshold, and whether data-gradient launches follow the
+ * same rule (default no).  Blocked = every launch the blocked kernel exists for: the parity mode (InferEngine(parity=True),
+ * TrainEngine(accum="blocked")).  awr_resolve_gemm_accum: what a launch of that K extent and kind gets under the current mode (what plan
  * builders store in awr_conv_args.accum, which itself only takes 0 / 1). */
+#define AWR_GEMM_OTHER 0        /* evaluation-plan forward, fused pairs, anything else */
+#define AWR_GEMM_FORWARD 1      /* forward launch of a training plan */
+#define AWR_GEMM_DGRAD 2        /* data gradient */
 int awr_set_gemm_accum(int mode);
 int awr_get_gemm_accum(void);
-int awr_set_gemm_accum_auto_k(int min_k);
-int awr_get_gemm_accum_auto_k(void);
-int awr_resolve_gemm_accum(int k_extent, int plain_launch);
+int awr_set_gemm_accum_auto(int min_k, int dgrad);
+int awr_get_gemm_accum_auto(int* min_k, int* dgrad);
+int awr_resolve_gemm_accum(int k_extent, int kind);
 
 /* weight gradient:  R[cd][t][cg] += sum_m D[m][cd] * G[pix(m,t)][cg]
  * D: dense operand (B,Hd,Wd,Cd); G: gathered operand (B,Hg,Wg,Cg) read at (y*sg+dy[t], x*sg+dx[t]).

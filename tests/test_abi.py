@@ -18,9 +18,12 @@ def lib():
     return _lib
 
 
-def declared_symbols():
+def declared_symbols(study=False):
+    """entry points include/awr_hip.h declares for the default build (study=True: those inside #ifdef AWR_STUDY blocks instead)"""
     text = open(os.path.join(REPO, "include", "awr_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    blocks = re.findall(r"#ifdef AWR_STUDY(.*?)#endif", text, flags=re.S)
+    text = "\n".join(blocks) if study else re.sub(r"#ifdef AWR_STUDY.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(awr_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -33,6 +36,23 @@ def test_header_symbols_are_exported_and_bound(lib):
         assert s in lib.EXPORTS, "%s is declared in the header but not bound in _lib.py" % s
     for s in lib.EXPORTS:
         assert s in syms, "%s is bound but not declared in include/awr_hip.h" % s
+
+
+def test_default_library_exports_no_study_entry_points(lib):
+    """forms that were built, measured and NOT adopted (pre-cut split-operand GEMM, half-batch BatchNorm-backward
+    wavefront) are compiled only with -DAWR_STUDY: the header declares them inside #ifdef AWR_STUDY, the binding lists them apart, and the
+    library the product loads has neither their symbols nor their kernels."""
+    import subprocess
+    from awr_amd import build
+    study = declared_symbols(study=True)
+    assert sorted(study) == sorted(lib.STUDY_EXPORTS) and len(study) >= 2
+    if lib.HAS_STUDY:
+        pytest.skip("a study build (-DAWR_STUDY) is loaded")
+    for s in study:
+        assert not hasattr(lib.lib, s), "the default library exports the study entry point %s" % s
+    dyn = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True).stdout
+    for needle in ("sdma", "split_act"):
+        assert needle not in dyn, "study kernel / entry point %r is in the default library" % needle
 
 
 def test_version_and_error_string(lib):

@@ -10,6 +10,16 @@ import torch
 import awr_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+def _has_study():
+    import awr_amd  # noqa: F401
+    from awr_amd import _lib
+    return _lib.HAS_STUDY
+
+
+# measured-and-rejected forms of earlier rounds live in study builds only (AWR_BUILD_STUDY=1 python -m awr_amd.build --force): their tests run there
+study_only = pytest.mark.skipif(not _has_study(), reason="study form: needs libawr_hip.so built with -DAWR_STUDY")
 REPORT = {}
 
 
@@ -65,21 +75,31 @@ def oracle_fp64_joint_gap(net, sd, img, ks, training, stages=None):
     return gaps
 
 
-def assert_joints(name, got, ref, gap, factor=2.0):
+def assert_joints(name, got, ref, gap, factor=2.0, yardstick=None):
     """got / ref: (B,J,3) normalised joints.  Bar: mean 3D distance <= 1e-3 mm (north_star), max <= 5e-3 mm -- widened to `factor` x
     (mean) / 3 `factor` x (max: the worst single joint of a handful is a noisy statistic) the oracle's own fp32-vs-fp64 gap where the
-    inputs are that ill-conditioned.  Two fp32 implementations that each sit one gap from the exact answer differ by ~1.4 gaps: round 4
-    tightens the default from 3 to 2 gaps.  The ORDERED accumulation mode carries 1.8-2.6x the oracle's rounding error (one k-chain per
-    output element); the two fixture families where that matters -- ResNet18 / ResNet-50 with training-mode BatchNorm --
-    say so at their call sites (factor 3 / 4) and have a blocked-mode twin that meets the PLAIN bar
-    (test_blocked_accumulation_meets_the_plain_north_star_bar)."""
+    inputs are that ill-conditioned (Hourglass-2 stage 1, ResNet-50: the fp32 oracle itself sits beyond the north_star figure from float64
+    there, and two fp32 implementations that each sit one gap from the exact answer differ by ~1.4 gaps).
+
+    yardstick = r (round 6) -- the two-image training-mode fixtures with procedural weights are CHAOTIC around 1e-3 mm: where
+    an implementation lands against another fp32 implementation (the golden joints) depends on which way a handful of roundings fall in the
+    BatchNorm statistics, and a MORE accurate summation can land farther away.  For those the criterion is distance to the TRUTH: the HIP
+    joints must sit within r x the fp32 oracle's own distance from float64 (both computed on the spot), plus the plain north_star bar
+    against the golden joints -- no widening."""
     d = np.linalg.norm(np.asarray(got, np.float64) - np.asarray(ref, np.float64), axis=-1) * 150.0
     mean, mx = float(d.mean()), float(d.max())
     report(name + "/joint_err_mm_mean", mean)
     report(name + "/joint_err_mm", mx)
     report(name + "/oracle_fp32_vs_fp64_gap_mm_mean", gap[0])
+    hip64 = None
     if len(gap) > 2 and tuple(gap[2].shape) == tuple(np.asarray(got).shape):      # how far the HIP joints themselves sit from float64
-        report(name + "/hip_vs_fp64_mm_mean", float(np.linalg.norm(np.asarray(got, np.float64) - gap[2].numpy(), axis=-1).mean() * 150.0))
+        hip64 = float(np.linalg.norm(np.asarray(got, np.float64) - gap[2].numpy(), axis=-1).mean() * 150.0)
+        report(name + "/hip_vs_fp64_mm_mean", hip64)
+    if yardstick is not None:
+        assert hip64 is not None, name
+        assert hip64 <= yardstick * gap[0], (name, "HIP vs float64", hip64, "oracle vs float64", gap[0], "allowed ratio", yardstick)
+        assert mean <= NORTH_STAR_MEAN_MM and mx <= 5e-3, (name, mean, mx, "plain north_star bar")
+        return mean, mx
     bar_mean, bar_max = max(NORTH_STAR_MEAN_MM, factor * gap[0]), max(5e-3, 3.0 * factor * gap[1])
     assert mean <= bar_mean and mx <= bar_max, (name, mean, mx, "bars", bar_mean, bar_max, "fp64 gap", gap)
     return mean, mx
@@ -121,8 +141,10 @@ def test_backbone_forward_golden(amd, dev, golden_dir, net):
             # ResNet-50 (not a BASELINE config; procedural weights, batch 2, training-mode BatchNorm over 32 samples per channel at layer4) is
             # ill-conditioned -- the fp32 oracle itself sits 4.4e-3 mm from float64 -- and 50 layers deep: the MFMA's k-ordered accumulation
             # carries 2.6x the oracle's rounding error, i.e. an expected distance of sqrt(1 + 2.6^2) = 2.8 gaps, measured 3.06
+            # ResNet18, training mode: the chaotic two-image fixture -> distance to float64 (the default accumulation mode blocks the training
+            # forward's long K extents: measured 0.87x the oracle's own gap, profiles/r06_accum_modes.txt)
             assert_joints("%s/%s/stage%d" % (net, mode, s), jt, g["%s_s%d_jt" % (mode, s)], gaps[s],
-                          factor=4.0 if net == "resnet_50" else 3.0 if (net == "resnet_18" and mode == "train") else 2.0)
+                          factor=4.0 if net == "resnet_50" else 2.0, yardstick=1.5 if (net == "resnet_18" and mode == "train") else None)
         if mode == "train":
             got_sd = m.state_dict()
             for i, k in enumerate(g["bn_keys"]):
@@ -177,7 +199,8 @@ def test_fused_train_step_golden(amd, dev, golden_dir, net, tag, cw):
     assert abs(l0 - ref0) <= 2e-4 * abs(ref0), (l0, ref0)
     assert abs(float(losses[0]) - float(g[tag + "_lcoord0"])) <= 2e-4 * max(1e-6, abs(float(g[tag + "_lcoord0"]))) + 1e-9
     gap = oracle_fp64_joint_gap(net, O.procedural_state(man, seed=1), img, ks, True)[-1]
-    assert_joints("%s/%s/train" % (net, tag), jt.cpu().numpy(), g[tag + "_jt0"], gap, factor=4.0 if net == "resnet_50" else 3.0 if net == "resnet_18" else 2.0)
+    assert_joints("%s/%s/train" % (net, tag), jt.cpu().numpy(), g[tag + "_jt0"], gap, factor=4.0 if net == "resnet_50" else 2.0,
+                  yardstick=1.5 if net == "resnet_18" else None)
     # gradients: golden = reference autograd (train.py:116-121: for the hourglass only the LAST stage's loss survives)
     # (ResNet-50: 50 layers of ReLU / pooling decisions between the loss and the stem, procedural weights, batch 2 -- the first layers'
     # gradient NORMS move by 1-2 % when a handful of decisions fall the other way; the tensor-by-tensor float64 yardstick below is the sharp
@@ -232,7 +255,7 @@ def test_blocked_accumulation_meets_the_plain_north_star_bar(amd, dev, golden_di
     assert float(d.mean()) <= NORTH_STAR_MEAN_MM and float(d.max()) <= 5e-3, (float(d.mean()), float(d.max()))
     worst = check_grad_norms(m, [str(k) for k in g["pkeys"]], g[tag + "_grad_l2"], g[tag + "_grad_smp"], tol=5e-3)
     report("%s/%s/train_blocked/worst_grad_norm_rel_err" % (net, tag), worst)
-    assert amd.get_gemm_accum() == "ordered"          # the engine's mode is its plan's, not the process's
+    assert amd.get_gemm_accum() == "auto"             # the engine's mode is its plan's, not the process's (whose default is auto)
     if tag == "c0":      # the forward fixture through the drop-in module (training-mode BatchNorm), process-wide mode
         gf = np.load(os.path.join(golden_dir, "resnet_18_fwd.npz"))
         amd.set_gemm_accum("blocked")
@@ -244,7 +267,7 @@ def test_blocked_accumulation_meets_the_plain_north_star_bar(amd, dev, golden_di
             o = o[-1] if isinstance(o, (list, tuple)) else o
             jf = amd.FeatureModule().offset2joint_softmax(o, torch.from_numpy(gf["img"]).to(dev), float(gf["ks"])).cpu().numpy()
         finally:
-            amd.set_gemm_accum("ordered")
+            amd.set_gemm_accum("auto")
         df = np.linalg.norm(jf.astype(np.float64) - gf["train_s0_jt"].astype(np.float64), axis=-1) * 150.0
         report("%s/train_blocked/stage0/joint_err_mm_mean" % net, float(df.mean()))
         assert float(df.mean()) <= NORTH_STAR_MEAN_MM and float(df.max()) <= 5e-3, (float(df.mean()), float(df.max()))
@@ -643,9 +666,10 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
         use_hipgraph = False
     tr = Trainer(Cfg(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
     mpe0 = tr.test(0)
-    # the scoring pass (test.py:67-86) is the one the parity mode was built for: config.parity_infer defaults to True and the
-    # engine Trainer.test built ran a plan whose GEMM launches captured the blocked accumulation
-    assert Cfg().parity_infer is True and tr._last_infer.parity and tr._last_infer.plan.accum == 1
+    # scoring passes (test.py:67-86) run ordered by default since round 6: eval-mode plans measured no gain from blocked accumulation
+    # (1.851e-4 mm from the oracle either way, profiles/r05_parity_report.json) and paid ~3 % for it; config.parity_infer opts in
+    assert Cfg().parity_infer is False and not tr._last_infer.parity and tr._last_infer.plan.accum == 0
+    assert tr.engine.plan.accum == {"ordered": 0, "blocked": 1, "auto": 2}[Cfg().accum]
     tr.train()
     work = os.path.join(str(tmp_path), "nyu", "checkpoint_t")
     log = open(os.path.join(work, "resnet_18_dense.log")).read()
@@ -669,12 +693,28 @@ def test_trainer_end_to_end(amd, dev, tmp_path):
     assert torch.equal(tr2.engine.m, tr.engine.m) and abs(tr2.engine.lr - 1e-3) < 1e-12       # LR force-reset (train.py:94-96)
     assert abs(tr2.test(1) - tr.test(1)) < 1e-5       # (mm, of ~80: two engines, independently autotuned tiles = different summation orders)
 
-    class Cfg3(Cfg2):      # opting out: the throughput mode (ordered accumulation) for scoring
-        parity_infer = False
+    class Cfg3(Cfg2):      # opting in: the parity mode (blocked accumulation) for scoring
+        parity_infer = True
         exp_id = "t3"
     tr3 = Trainer(Cfg3(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
     m3 = tr3.test(1)
-    assert not tr3._last_infer.parity and tr3._last_infer.plan.accum == 0 and abs(m3 - tr.test(1)) < 1e-3
+    assert tr3._last_infer.parity and tr3._last_infer.plan.accum == 1 and abs(m3 - tr.test(1)) < 1e-3
+
+    # the split-operand mode has no blocked kernel -- a scoring pass that asks for parity there must run (ordered, with a
+    # warning), not fail at its first launch; a training engine's "auto" degrades to ordered the same way
+    class Cfg4(Cfg3):
+        gemm_products = 6
+        exp_id = "t4"
+    try:
+        with pytest.warns(UserWarning, match="blocked accumulation is not available"):
+            tr4 = Trainer(Cfg4(), SyntheticHands(32, seed=1), SyntheticHands(12, seed=2))
+            m4 = tr4.test(1)
+        assert not tr4._last_infer.parity and tr4._last_infer.plan.accum == 0 and abs(m4 - m3) < 1e-2
+        from awr_amd._lib import AwrError
+        with pytest.raises(AwrError, match="blocked accumulation"):
+            tr4.net.get_plan(8, 128, False, accum="blocked")
+    finally:
+        amd.set_gemm_products(1)
 
 
 @pytest.mark.parametrize("net,streams", [("resnet_18", 0), ("resnet_18", 2), ("hourglass_1", 2)])
@@ -830,6 +870,30 @@ def test_native_rccl_communicator_through_the_c_abi(amd, dev):
     plan.forward()
     plan.backward()
     torch.cuda.synchronize()
+    # the HOST's bucket callback survives lost communicator -> re-attach -> detach (the re-attach used to save the plan's own
+    # callback over it, after which gradients were silently no longer handed to the host)
+    seen = []
+    plan.bucket_hook = lambda lo, hi: seen.append((lo, hi))
+    dp2 = DpComm(0, 1, DpComm.unique_id())
+    plan.set_dp(dp2)
+    dp2.close()
+    plan.forward()
+    with pytest.raises(AwrError):
+        plan.backward()
+    torch.cuda.synchronize()
+    dp3 = DpComm(0, 1, DpComm.unique_id())
+    plan.set_dp(dp3)                     # re-attach while the lost communicator's callback is still installed
+    plan.forward()
+    plan.backward()
+    torch.cuda.synchronize()
+    assert not seen                      # buckets went to the communicator
+    plan.set_dp(None)
+    dp3.close()
+    plan.forward()
+    plan.backward()
+    torch.cuda.synchronize()
+    assert len(seen) == 4 and seen[-1][1] > seen[-1][0], seen
+    plan.bucket_hook = None
 
 
 @pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
@@ -1090,6 +1154,7 @@ def test_tuning_cache_round_trip(amd, dev, tmp_path, monkeypatch):
     assert algos and algos <= {0, 1, 2, 3} and (algos & {1, 3})
 
 
+@study_only
 @pytest.mark.parametrize("net,streams", [("resnet_18", 2), ("resnet_18", 0), ("hourglass_1", 2)])
 def test_half_batch_batchnorm_backward_wavefront(amd, dev, net, streams, monkeypatch):
     """Round 5: where half a batch still fills the chip the BatchNorm-backward apply is written half by half -- half A on the

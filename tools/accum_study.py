@@ -104,18 +104,18 @@ def step_ms(mode, net_name="resnet_18", B=64, steps=20, warmup=8):
 
 def main():
     res = {"fast_stats": os.environ.get("AWR_FAST_STATS", "0")}
-    modes = [("ordered", None), ("auto", 2304), ("auto", 1152), ("auto", 1024), ("auto", 576), ("blocked", None)]
-    for mode, k in modes:
+    modes = [("ordered", None, 0), ("auto", 2304, 0), ("auto", 1152, 0), ("auto", 1024, 0), ("auto", 576, 0), ("auto", 1152, 1), ("blocked", None, 0)]
+    for mode, k, dg in modes:
         if k:
-            L.call("awr_set_gemm_accum_auto_k", k)
-        name = mode + ("_k%d" % k if k else "")
+            L.call("awr_set_gemm_accum_auto", k, dg)
+        name = mode + ("_k%d%s" % (k, "_dgrad" if dg else "") if k else "")
         ent = {"fixtures": fixtures(mode)}
         ent["r18_b64_ms"] = step_ms(mode)
         if "--hg" in sys.argv:
             ent["hg1_b64_ms"] = step_ms(mode, "hourglass_1")
         res[name] = ent
         print(name, json.dumps(ent), flush=True)
-    L.call("awr_set_gemm_accum_auto_k", 1024)
+    L.call("awr_set_gemm_accum_auto", 1152, 0)
     print(json.dumps(res))
 
 
