@@ -43,6 +43,19 @@ def set_gemm_accum(mode):
     L.call("awr_set_gemm_accum", {"ordered": 0, "blocked": 1, "auto": 2}.get(mode, mode))
 
 
+def set_conv_winograd(on):
+    """Process-wide: plans built afterwards run the FORWARD of every eligible stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the FP32 matrix
+    pipe (include/awr_hip.h: awr_set_conv_winograd; csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-0.6x the direct kernel's rounding error,
+    not bit-compatible with it."""
+    from . import _lib as L
+    L.call("awr_set_conv_winograd", 2 if on == "force" else int(bool(on)))        # "force": tests (every layer the kernel can run, whatever its size)
+
+
+def get_conv_winograd():
+    from . import _lib as L
+    return bool(L.lib.awr_get_conv_winograd())
+
+
 def get_gemm_accum():
     from . import _lib as L
     return ("ordered", "blocked", "auto")[int(L.lib.awr_get_gemm_accum())]

@@ -195,6 +195,14 @@ _SIGS = {
     "awr_dp_broadcast": ([_P, _P, _L, _I, _P], C.c_int),
     "awr_dp_wait": ([_P, _P], C.c_int),
     "awr_plan_set_dp": ([_P, _P], C.c_int),
+    # Winograd F(2x2, 3x3) (csrc/awr_wino.hip)
+    "awr_wino_weights": ([_P, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "awr_wino_conv3x3": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "awr_wino2_conv3x3": ([_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "awr_set_conv_winograd": ([_I], C.c_int),
+    "awr_get_conv_winograd": ([], C.c_int),
+    "awr_wino_eligible": ([_I, _I, _I, _I, _I], C.c_int),
+    "awr_plan_winograd": ([_P, C.POINTER(_I), C.POINTER(_D)], C.c_int),
     # NYU data path (csrc/awr_nyu.hip)
     "awr_nyu_crop": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P], C.c_int),
     "awr_nyu_warp": ([_P, _I, _I, _P, _I, _F, _I, _I, _I, _P, _P], C.c_int),

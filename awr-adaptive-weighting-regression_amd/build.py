@@ -26,11 +26,16 @@ SOURCES = {
     "awr_gemm_t11.hip": [],
     "awr_conv.hip": [],       # conv dispatch, register-staged GEMM, fused pairs
     "awr_wgrad.hip": [],      # weight gradients
+    "awr_wino.hip": [],       # Winograd F(2x2, 3x3) forward of the stride-1 3x3 convolutions
     "awr_stem.hip": [],
     "awr_net.hip": [],        # host-only: network-level plan builder / runner
     "awr_dp.hip": [],         # host-only: RCCL communicators through dlopen (no link-time dependency)
     "awr_nyu.hip": ["-ffp-contract=off"],     # NYU data path: numpy's / OpenCV's arithmetic, no fused multiply-adds
 }
+
+
+# translation units of study builds only (AWR_BUILD_STUDY=1): measured, not adopted
+STUDY_SOURCES = {}
 
 
 def _hipcc():
@@ -56,7 +61,16 @@ def build_lib(force=False, verbose=True, study=None):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "awr_hip.h"))
     objs, jobs = [], []
-    for src, extra in SOURCES.items():
+    sources = dict(SOURCES)
+    if study:
+        sources.update(STUDY_SOURCES)
+    for stale_obj in (os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in STUDY_SOURCES):
+        if not study and os.path.exists(stale_obj):
+            os.remove(stale_obj)            # (an object of an earlier study build must not be linked into the default library)
+    marker = os.path.join(LIBDIR, ".study")
+    if os.path.exists(marker) != study:      # switching between the two kinds of build recompiles everything
+        force = True
+    for src, extra in sources.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
@@ -75,6 +89,10 @@ def build_lib(force=False, verbose=True, study=None):
             subprocess.check_call(cmd)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
+    if study:
+        open(marker, "w").close()
+    elif os.path.exists(marker):
+        os.remove(marker)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:

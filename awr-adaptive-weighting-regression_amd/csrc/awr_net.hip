@@ -675,6 +675,9 @@ struct awr_plan {
     std::vector<Op> fwd, bwd, pack_ops;
     std::vector<std::function<int()>> nodes;       // backward emitters, in forward order
     std::vector<ConvLayer*> layers;                // layers whose packed copies this plan refreshes
+    int n_wino = 0;
+    double wino_macs = 0;            // algorithmic multiply-adds of those launches (they execute 16 / 36 of them)
+    std::vector<std::pair<ConvLayer*, float*>> wino;      // ... and whose forward runs as Winograd F(2x2, 3x3): (layer, U[16][cin_pad][cout_pad])
     std::vector<DualLayer*> dual_layers;
     std::deque<Tn> tensors;
     std::deque<awr_conv_args> cargs;
@@ -907,6 +910,35 @@ struct Builder {
             o.in_scale = x->lz_scale;
             o.in_shift = x->lz_shift;
             o.relu_in = x->lz_relu;
+        }
+        // Winograd F(2x2, 3x3) forward (round 6, awr_set_conv_winograd; csrc/awr_wino.hip): stride-1 3x3 convolutions whose epilogue is bias /
+        // ReLU / statistics.  2.25x fewer multiplies, chains of Cin terms instead of 9 Cin (so no blocked accumulation is needed).  Weight and
+        // data gradients stay direct: they only need x and d(y).
+        if (awr_get_conv_winograd() && !P.det && awr_get_gemm_products() == 1 && !spec.deconv && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
+            !o.res && !o.out_scale && (o.in_scale == nullptr) == (o.in_shift == nullptr) &&
+            awr_wino_eligible(B, x->H, x->W, spec.cin_pad, spec.cout_pad)) {
+            float* U = nullptr;
+            for (auto& wl : P.wino)
+                if (wl.first == layer) U = wl.second;
+            if (!U) {
+                U = alloc<float>((int64_t)16 * spec.cin_pad * spec.cout_pad);
+                P.wino.push_back({layer, U});
+            }
+            const float *in = x->buf, *isc = o.in_scale, *ish = o.in_shift;
+            float* out = y->buf;
+            double* st = y->stats.p;
+            const int nsl = y->stats.p ? y->stats.nslots : 0, rin = o.relu_in, rout = o.relu_out, H = x->H, W = x->W, C = spec.cin_pad, Nn = spec.cout_pad;
+            const std::string name = "awr_conv_gemm:" + layer->name;
+            Op& op = f(name, [=](void* s) { return awr_wino2_conv3x3(in, U, bias, isc, ish, rin, out, st, nsl, B, H, W, C, Nn, rout, s); });
+            op.gemm = true;
+            op.macs = gemm_macs(prob, B, spec);
+            P.n_wino++;
+            P.wino_macs += op.macs;
+            if (P.training) {
+                const bool has_bias = bias != nullptr;
+                P.nodes.push_back([=]() { return conv_bwd(x, y, layer, nullptr, has_bias); });
+            }
+            return y;
         }
         P.cargs.emplace_back();
         awr_conv_args* a = &P.cargs.back();
@@ -1968,6 +2000,8 @@ static int refresh_weights(awr_plan& P, void* stream) {
     // 14.04 ms -- profiles/r03_summary.md -- so both tables go to the caller's stream)
     if (P.pack_njobs[ws][1])
         NET_CHECK(awr_pack_weights_batched((const awr_pack_job*)P.pack_tab[ws][1], P.pack_njobs[ws][1], P.pack_rows[ws][1], stream));
+    for (auto& wl : P.wino)
+        NET_CHECK(awr_wino_weights(wl.first->w, wl.first->spec.cout, wl.first->spec.cin, wl.first->spec.cout_pad, wl.first->spec.cin_pad, 0, wl.second, stream));
     hipStream_t st = awr::as_stream(stream);
     for (auto* l : P.layers) {
         if (!l->head) continue;
@@ -2387,6 +2421,13 @@ int awr_plan_info(const awr_plan* p, int64_t* bytes, int* deterministic, int* n_
         for (auto& o : p->fwd) c += o.name == "awr_bn_finalize";
         *n_bn = c;
     }
+    return AWR_OK;
+}
+
+int awr_plan_winograd(const awr_plan* p, int* n, double* macs) {
+    AWR_REQUIRE(p, "plan_winograd: null pointer");
+    if (n) *n = p->n_wino;
+    if (macs) *macs = p->wino_macs;
     return AWR_OK;
 }
 

@@ -1,0 +1,530 @@
+// Round-6 study: fused Winograd F(2x2, 3x3) on the FP32 matrix pipe for stride-1 3x3 convolutions (the forward and,
+// with mirrored weights, the data gradient of model/resnet_deconv.py:139-142,:161-165 BasicBlock convs and model/hourglass.py:35 Residual
+// conv2).  2.25x fewer multiplies than the direct implicit GEMM: per 2x2 output patch and channel pair 16 products instead of 36.
+//
+//   U[pos][c][n] = (G g G^T)[pos]           weights, transformed once per optimiser step (wino_weight_kernel)
+//   V[pos][patch][c] = (B^T d B)[pos]       the 4x4 input window of the patch, transformed while it is staged into LDS
+//   M[pos][patch][n] = sum_c V * U          16 independent GEMMs (one per position) on v_mfma_f32_32x32x2_f32
+//   Y[patch] = A^T M A                      2x2 outputs, after an exchange of the accumulators through LDS
+//
+// Workgroup = 4 waves; tile = 64 patches (256 output pixels) x 32 output channels; wave w owns positions 4w .. 4w+3 (each a 64 x 32
+// accumulator = two 32x32 MFMA tiles: 128 accumulator registers per lane).  K loop over input channels in stages of KB: the transformed
+// window (16 x 64 x KB) and the weight slice (16 x KB x 32) live in one single-buffered LDS stage of 52 KB; the exchange of the epilogue
+// reuses it (64 KB): two workgroups per CU, whose transform / MFMA phases interleave.  Operator level only (tools/microbench_wino.py,
+// tests/test_wino_gpu.py); the go / no-go numbers are in profiles/r06_winograd.txt.
+#include <stdlib.h>
+
+#include "awr_common.h"
+
+namespace awr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int W_TP = 64, W_TN = 32;
+
+struct wino_args {
+    const float* in;      // (B, H, W, C) NHWC
+    const float* U;       // [16][C][N]
+    const float* bias;    // [N] or null
+    float* out;           // (B, H, W, N)
+    int B, H, W, C, N, relu;
+};
+
+// w: OIHW (N, C, 3, 3); mirror != 0: the data-gradient form (taps mirrored, roles of N and C swapped by the caller's indexing)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int N, int C, int Npad, int Cpad, int mirror, float* __restrict__ U) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cpad * Npad) return;
+    const int c = idx / Npad, n = idx % Npad;
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = 0.f;
+            if (n < N && c < C) v = mirror ? w[((int64_t)c * N + n) * 9 + (2 - i) * 3 + (2 - j)] : w[((int64_t)n * C + c) * 9 + i * 3 + j];
+            g[i][j] = v;
+        }
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t[0][j] = g[0][j];
+        t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        t[3][j] = g[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+        U[((int64_t)(i * 4 + 0) * Cpad + c) * Npad + n] = u0;
+        U[((int64_t)(i * 4 + 1) * Cpad + c) * Npad + n] = u1;
+        U[((int64_t)(i * 4 + 2) * Cpad + c) * Npad + n] = u2;
+        U[((int64_t)(i * 4 + 3) * Cpad + c) * Npad + n] = u3;
+    }
+}
+
+template <int KB, int NW, int PROBE = 0>      // NW waves per workgroup, 16 / NW positions per wave; PROBE (timing only, wrong results): 1 = no input
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2))) void wino_fwd_kernel(const wino_args a) {
+    constexpr int NT = 64 * NW, QP = 16 / NW;
+    constexpr int VROW = KB + 1;                       // odd pitch: conflict-free A-fragment reads
+    constexpr int V_FLOATS = 16 * W_TP * VROW, U_FLOATS = 16 * KB * W_TN;
+    constexpr int X_FLOATS = 16 * 32 * 32;             // epilogue exchange: 16 positions x 32 patches x 32 channels
+    constexpr int LDS_FLOATS = (V_FLOATS + U_FLOATS) > X_FLOATS ? (V_FLOATS + U_FLOATS) : X_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* const Vs = lds;
+    float* const Us = lds + V_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int PH = a.H >> 1, PW = a.W >> 1;
+    const int64_t P_total = (int64_t)a.B * PH * PW;
+    const int64_t p0 = (int64_t)blockIdx.x * W_TP;
+    const int n0 = blockIdx.y * W_TN;
+
+    // ---- input-transform items of this thread: channel tid % KB of patches tid / KB + (256 / KB) * pass ----
+    constexpr int PPP = NT / KB < W_TP ? NT / KB : W_TP, PASSES = W_TP / PPP;     // patches per pass, passes per stage
+    const bool titem = tid < PPP * KB;                     // (KB = 4 with 512 threads: half of them have no transform item)
+    const int ch = tid % KB, psub = tid / KB;
+    int64_t base[PASSES];
+    unsigned vmask[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int64_t p = p0 + psub + PPP * ps;
+        vmask[ps] = 0;
+        base[ps] = 0;
+        if (p < P_total) {
+            const int b = (int)(p / (PH * PW)), rem = (int)(p % (PH * PW)), py = rem / PW, px = rem % PW;
+            const int y0 = 2 * py - 1, x0 = 2 * px - 1;
+            base[ps] = (((int64_t)b * a.H + y0) * a.W + x0) * a.C;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int y = y0 + (t >> 2), x = x0 + (t & 3);
+                if (y >= 0 && y < a.H && x >= 0 && x < a.W) vmask[ps] |= 1u << t;
+            }
+        }
+    }
+    float d[PASSES][16];
+    constexpr int UQ = U_FLOATS / 4 / NT > 0 ? U_FLOATS / 4 / NT : 1;      // float4 weight loads per thread and stage
+    const bool uitem = tid < U_FLOATS / 4;
+    float4 ureg[UQ];
+
+    auto load_stage = [&](int k0) {
+        if (PROBE >= 3 && k0) return;                       // probe: nothing travels after the first stage
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if (PROBE == 1 && k0) break;                    // probe: the input window is loaded once
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                d[ps][t] = (titem && ((vmask[ps] >> t) & 1u)) ? a.in[base[ps] + ((int64_t)(t >> 2) * a.W + (t & 3)) * a.C + k0 + ch] : 0.f;
+        }
+        if (PROBE == 2 && k0) return;                       // probe: the weights are loaded once
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int f = tid + NT * q, n4 = f % (W_TN / 4), k = (f / (W_TN / 4)) % KB, pos = f / ((W_TN / 4) * KB);
+            if (uitem) ureg[q] = ld4(a.U + ((int64_t)pos * a.C + k0 + k) * a.N + n0 + 4 * n4);
+        }
+    };
+    auto store_stage = [&]() {
+        if (PROBE == 4) return;                             // probe: no transform, no LDS writes either (MFMA + fragment reads + barriers only)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if (!titem) break;
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[ps][0 + j] - d[ps][8 + j];
+                t[1][j] = d[ps][4 + j] + d[ps][8 + j];
+                t[2][j] = d[ps][8 + j] - d[ps][4 + j];
+                t[3][j] = d[ps][4 + j] - d[ps][12 + j];
+            }
+            float* v = Vs + (psub + PPP * ps) * VROW + ch;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[(i * 4 + 0) * W_TP * VROW] = t[i][0] - t[i][2];
+                v[(i * 4 + 1) * W_TP * VROW] = t[i][1] + t[i][2];
+                v[(i * 4 + 2) * W_TP * VROW] = t[i][2] - t[i][1];
+                v[(i * 4 + 3) * W_TP * VROW] = t[i][1] - t[i][3];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q)
+            if (uitem) st4(Us + (tid + NT * q) * 4, ureg[q]);
+    };
+
+    f32x16 acc[QP][2];
+#pragma unroll
+    for (int q = 0; q < QP; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][h][r] = 0.f;
+
+    load_stage(0);
+    if (PROBE != 4) store_stage();
+    __syncthreads();
+    for (int k0 = 0; k0 < a.C; k0 += KB) {
+        const bool more = k0 + KB < a.C;
+        if (more) load_stage(k0 + KB);                 // the next stage's operands travel while this stage multiplies
+#pragma unroll
+        for (int s = 0; s < KB / 2; ++s)
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const int pos = QP * wave + q;
+                const float b = Us[(pos * KB + 2 * s + half) * W_TN + l31];
+                const float a0 = Vs[(pos * W_TP + l31) * VROW + 2 * s + half];
+                const float a1 = Vs[(pos * W_TP + 32 + l31) * VROW + 2 * s + half];
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[q][1], 0, 0, 0);
+            }
+        __syncthreads();                               // everyone is done reading the stage
+        if (more) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: exchange through LDS (32 patches at a time), output transform, bias / ReLU, 16-byte stores ----
+    // item = (patch of the half, channel quad, output row): 512 items per half
+    float* const X = lds;
+    const int n4 = tid & 7, pi = (tid >> 3) & 31;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[((QP * wave + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[q][h][r];
+        __syncthreads();
+        const int64_t p = p0 + 32 * h + pi;
+        for (int rr = tid >> 8; rr < 2; rr += NT / 256) {          // output row of the patch (both rows for a 256-thread workgroup)
+            if (p >= P_total || n0 + 4 * n4 >= a.N) break;
+            float4 s[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 m1 = ld4(X + ((4 + j) * 32 + pi) * 32 + 4 * n4), m2 = ld4(X + ((8 + j) * 32 + pi) * 32 + 4 * n4);
+                const float4 m03 = ld4(X + ((rr ? 12 + j : j) * 32 + pi) * 32 + 4 * n4);
+                if (rr == 0) s[j] = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z, m03.w + m1.w + m2.w);
+                else s[j] = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z, m1.w - m2.w - m03.w);
+            }
+            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) bs = ld4(a.bias + n0 + 4 * n4);
+            float4 y0 = make_float4(s[0].x + s[1].x + s[2].x + bs.x, s[0].y + s[1].y + s[2].y + bs.y, s[0].z + s[1].z + s[2].z + bs.z, s[0].w + s[1].w + s[2].w + bs.w);
+            float4 y1 = make_float4(s[1].x - s[2].x - s[3].x + bs.x, s[1].y - s[2].y - s[3].y + bs.y, s[1].z - s[2].z - s[3].z + bs.z, s[1].w - s[2].w - s[3].w + bs.w);
+            if (a.relu) {
+                y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+            }
+            const int b = (int)(p / (PH * PW)), rem = (int)(p % (PH * PW)), py = rem / PW, px = rem % PW;
+            float* o = a.out + (((int64_t)b * a.H + 2 * py + rr) * a.W + 2 * px) * a.N + n0 + 4 * n4;
+            st4(o, y0);
+            st4(o + a.N, y1);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// v2: the RAW input tile goes through LDS.  v1's probes (profiles/r06_winograd.txt): its MFMA loop alone runs at 135 TF executed (303
+// algorithmic), but the 4x4 windows of neighbouring patches overlap -- every input pixel was requested four times, 32 bytes at a time, and those
+// requests cost 44 % of the launch.  Here a tile is a 2-D block of patches of ONE image (or whole small images), its input region is loaded
+// ONCE per stage with 16-byte requests into LDS, and the transform reads its windows from there.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct wino2_args {
+    const float* in;
+    const float* U;
+    const float* bias;
+    const float* in_scale;   // optional fused input affine (+ ReLU): the previous BatchNorm, applied to valid pixels only (padding stays zero)
+    const float* in_shift;
+    float* out;
+    double* stats;           // optional: per-channel sum / sum of squares of the stored output, [nslots][2][N] (awr_bn_finalize's layout)
+    int B, H, W, C, N, relu, relu_in, nslots;
+    int PRt, PCt, nimg;      // tile: nimg images x PRt x PCt patches = 64
+};
+
+template <int KB, int RITEMS>      // RITEMS: 16-byte raw-tile requests per thread and stage (2 covers 512 pixels, 3 the 576 of sixteen 4x4 maps)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void wino2_fwd_kernel(const wino2_args a) {
+    // (a k-pair-interleaved layout with 8-byte LDS accesses -- Vs[pos][k / 2][patch][2], Raw[pixel][KB + 2], 256 transform items of two
+    // channels -- was built and measured SLOWER: 568 vs 528 us on 128 -> 128 @ 64 x 64 x 64; profiles/r06_winograd.txt)
+    constexpr int NT = 512, QP = 2;
+    constexpr int VROW = KB + 1, RP = KB + 1;          // odd pitches: conflict-free A-fragment reads, 2-way window reads
+    constexpr int V_FLOATS = 16 * W_TP * VROW, U_FLOATS = 16 * KB * W_TN;
+    constexpr int RAW_MAX_PX = 576;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Vs = lds;
+    float* const Us = lds + V_FLOATS;
+    float* const Raw = lds + V_FLOATS + U_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int PH = a.H >> 1, PW = a.W >> 1;
+    const int RH = 2 * a.PRt + 2, RW = 2 * a.PCt + 2;
+    // 1-D grid, XCD-aware: the hardware deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2); the remap gives every XCD
+    // a contiguous run of logical ids, and the channel tile varies fastest -- the N / 32 workgroups that read the SAME input tile run on one XCD,
+    // back to back, so the tile comes from HBM once
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int ntiles_n = a.N / W_TN, tile = logical / ntiles_n;
+    const int n0 = (logical % ntiles_n) * W_TN;
+    // tile -> (first image, first patch row, first patch column)
+    const int tiles_x = PW / a.PCt, tiles_y = PH / a.PRt;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tb = tile / (tiles_x * tiles_y);
+    const int img0 = tb * a.nimg, pr0 = ty * a.PRt, pc0 = tx * a.PCt;
+
+    // ---- raw-tile items of this thread (fixed over the K loop): pixel of the region x channel quad ----
+    constexpr int QUADS = KB / 4;
+    static_assert(RAW_MAX_PX * QUADS <= 3 * NT, "raw tile");
+    const int nraw = a.nimg * RH * RW * QUADS;
+    int roff[RITEMS];              // element offsets (the host checks that the tensor has < 2^31 elements); < 0: padding / outside the batch
+    int rlds[RITEMS];
+#pragma unroll
+    for (int r = 0; r < RITEMS; ++r) {
+        const int i = tid + NT * r, px = i / QUADS, quad = i % QUADS;
+        rlds[r] = i < nraw ? px * RP + 4 * quad : -1;
+        const int il = px / (RH * RW), rr = (px / RW) % RH, cc = px % RW;
+        const int b = img0 + il, y = 2 * pr0 - 1 + rr, x = 2 * pc0 - 1 + cc;
+        const bool ok = i < nraw && b < a.B && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        roff[r] = ok ? ((b * a.H + y) * a.W + x) * a.C + 4 * quad : -1;
+    }
+    // ---- transform item: patch tid / KB, channel tid % KB ----
+    const int ch = tid % KB, lp = tid / KB;                                   // (NT / KB == 64 patches: one item per thread)
+    const int lil = lp / (a.PRt * a.PCt), lpr = (lp / a.PCt) % a.PRt, lpc = lp % a.PCt;
+    const int tbase = ((lil * RH + 2 * lpr) * RW + 2 * lpc) * RP + ch;
+    constexpr int UQ = U_FLOATS / 4 / NT;
+    float4 rreg[RITEMS], ureg[UQ];
+
+    auto load_stage = [&](int k0) {
+        // (the channel quad of a thread's raw items is the same for all of them: NT is a multiple of QUADS -> one scale / shift pair per stage)
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.in_scale) {
+            sc = ld4(a.in_scale + k0 + 4 * (tid % QUADS));
+            sh = ld4(a.in_shift + k0 + 4 * (tid % QUADS));
+        }
+#pragma unroll
+        for (int r = 0; r < RITEMS; ++r) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (roff[r] >= 0) {
+                v = ld4(a.in + roff[r] + k0);
+                if (a.in_scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                if (a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            }
+            rreg[r] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int f = tid + NT * q, n4 = f % (W_TN / 4), k = (f / (W_TN / 4)) % KB, pos = f / ((W_TN / 4) * KB);
+            ureg[q] = ld4(a.U + ((int64_t)pos * a.C + k0 + k) * a.N + n0 + 4 * n4);
+        }
+    };
+    auto store_raw = [&]() {
+#pragma unroll
+        for (int r = 0; r < RITEMS; ++r)
+            if (rlds[r] >= 0) {
+                float* p = Raw + rlds[r];
+                p[0] = rreg[r].x; p[1] = rreg[r].y; p[2] = rreg[r].z; p[3] = rreg[r].w;
+            }
+    };
+    auto store_u = [&]() {
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) st4(Us + (tid + NT * q) * 4, ureg[q]);
+    };
+    auto transform = [&]() {
+        float d[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) d[t] = Raw[tbase + ((t >> 2) * RW + (t & 3)) * RP];
+        float t4[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t4[0][j] = d[0 + j] - d[8 + j];
+            t4[1][j] = d[4 + j] + d[8 + j];
+            t4[2][j] = d[8 + j] - d[4 + j];
+            t4[3][j] = d[4 + j] - d[12 + j];
+        }
+        float* v = Vs + lp * VROW + ch;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[(i * 4 + 0) * W_TP * VROW] = t4[i][0] - t4[i][2];
+            v[(i * 4 + 1) * W_TP * VROW] = t4[i][1] + t4[i][2];
+            v[(i * 4 + 2) * W_TP * VROW] = t4[i][2] - t4[i][1];
+            v[(i * 4 + 3) * W_TP * VROW] = t4[i][1] - t4[i][3];
+        }
+    };
+
+    f32x16 acc[QP][2];
+#pragma unroll
+    for (int q = 0; q < QP; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][h][r] = 0.f;
+
+    load_stage(0);
+    store_raw();
+    store_u();
+    __syncthreads();
+    transform();
+    __syncthreads();
+    for (int k0 = 0; k0 < a.C; k0 += KB) {
+        const bool more = k0 + KB < a.C;
+        if (more) load_stage(k0 + KB);
+#pragma unroll
+        for (int s = 0; s < KB / 2; ++s)
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const int pos = QP * wave + q;
+                const float b = Us[(pos * KB + 2 * s + half) * W_TN + l31];
+                const float a0 = Vs[(pos * W_TP + l31) * VROW + 2 * s + half];
+                const float a1 = Vs[(pos * W_TP + 32 + l31) * VROW + 2 * s + half];
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[q][1], 0, 0, 0);
+            }
+        if (more) store_raw();            // (nobody reads Raw now: the previous transform finished before the previous barrier)
+        __syncthreads();                  // everyone is done reading Vs / Us
+        if (more) {
+            store_u();
+            transform();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: exchange through LDS (32 patches at a time), output transform, bias / ReLU / statistics, 16-byte stores ----
+    float* const X = lds;
+    const int n4 = tid & 7, pi = (tid >> 3) & 31, rr = tid >> 8;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[((QP * wave + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[q][h][r];
+        __syncthreads();
+        const int p = 32 * h + pi;
+        const int il = p / (a.PRt * a.PCt), pr = (p / a.PCt) % a.PRt, pc = p % a.PCt;
+        const int b = img0 + il;
+        if (b < a.B) {
+            float4 s[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 m1 = ld4(X + ((4 + j) * 32 + pi) * 32 + 4 * n4), m2 = ld4(X + ((8 + j) * 32 + pi) * 32 + 4 * n4);
+                const float4 m03 = ld4(X + ((rr ? 12 + j : j) * 32 + pi) * 32 + 4 * n4);
+                if (rr == 0) s[j] = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z, m03.w + m1.w + m2.w);
+                else s[j] = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z, m1.w - m2.w - m03.w);
+            }
+            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) bs = ld4(a.bias + n0 + 4 * n4);
+            float4 y0 = make_float4(s[0].x + s[1].x + s[2].x + bs.x, s[0].y + s[1].y + s[2].y + bs.y, s[0].z + s[1].z + s[2].z + bs.z, s[0].w + s[1].w + s[2].w + bs.w);
+            float4 y1 = make_float4(s[1].x - s[2].x - s[3].x + bs.x, s[1].y - s[2].y - s[3].y + bs.y, s[1].z - s[2].z - s[3].z + bs.z, s[1].w - s[2].w - s[3].w + bs.w);
+            if (a.relu) {
+                y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+            }
+            if (a.stats) {
+                ssum.x += y0.x + y1.x; ssum.y += y0.y + y1.y; ssum.z += y0.z + y1.z; ssum.w += y0.w + y1.w;
+                ssq.x += y0.x * y0.x + y1.x * y1.x; ssq.y += y0.y * y0.y + y1.y * y1.y; ssq.z += y0.z * y0.z + y1.z * y1.z; ssq.w += y0.w * y0.w + y1.w * y1.w;
+            }
+            float* o = a.out + (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + n0 + 4 * n4;
+            st4(o, y0);
+            st4(o + a.N, y1);
+        }
+    }
+    if (a.stats) {
+        // lanes with the same channel quad (tid & 7) of one wave hold 8 patches: reduce over them, then one atomic per (wave, channel)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            ssum.x += __shfl_xor(ssum.x, o, 64); ssum.y += __shfl_xor(ssum.y, o, 64); ssum.z += __shfl_xor(ssum.z, o, 64); ssum.w += __shfl_xor(ssum.w, o, 64);
+            ssq.x += __shfl_xor(ssq.x, o, 64); ssq.y += __shfl_xor(ssq.y, o, 64); ssq.z += __shfl_xor(ssq.z, o, 64); ssq.w += __shfl_xor(ssq.w, o, 64);
+        }
+        if (lane < 8) {
+            const int slot = (tile * 8 + wave) % a.nslots;
+            double* st = a.stats + (int64_t)slot * 2 * a.N + n0 + 4 * n4;
+            atomicAdd(st + 0, (double)ssum.x); atomicAdd(st + 1, (double)ssum.y); atomicAdd(st + 2, (double)ssum.z); atomicAdd(st + 3, (double)ssum.w);
+            atomicAdd(st + a.N + 0, (double)ssq.x); atomicAdd(st + a.N + 1, (double)ssq.y); atomicAdd(st + a.N + 2, (double)ssq.z); atomicAdd(st + a.N + 3, (double)ssq.w);
+        }
+    }
+}
+
+}  // namespace awr
+
+using namespace awr;
+
+extern "C" {
+
+int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirror, float* U, void* stream) {
+    AWR_REQUIRE(w && U && N > 0 && C > 0 && Npad >= N && Npad % 32 == 0 && Cpad >= C && Cpad % 8 == 0,
+                "wino_weights: N=%d C=%d Npad=%d Cpad=%d (Npad: a multiple of 32 >= N, Cpad: a multiple of 8 >= C)", N, C, Npad, Cpad);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((Cpad * Npad + 255) / 256), dim3(256), 0, as_stream(stream), w, N, C, Npad, Cpad, mirror, U);
+    return check_launch("wino_weight_kernel");
+}
+
+static int g_winograd = []() { const char* e = getenv("AWR_WINOGRAD"); return e ? atoi(e) : 0; }();
+
+int awr_set_conv_winograd(int on) {
+    AWR_REQUIRE(on >= 0 && on <= 2, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible) or "
+                                    "2 (tests: wherever the kernel can run, whatever the launch size)");
+    g_winograd = on;
+    return AWR_OK;
+}
+
+int awr_get_conv_winograd(void) { return g_winograd; }
+
+int awr_wino_eligible(int B, int H, int W, int C, int N) {
+    const int minside = g_winograd == 2 ? 4 : 16;
+    if (H < minside || W < minside || (H & (H - 1)) || (W & (W - 1)) || C % 8 || N % 32) return 0;
+    if ((int64_t)B * H * W * C >= (1LL << 31)) return 0;
+    const int PH = H / 2, PW = W / 2, PCt = PW < 32 ? PW : 32, PRt = PH < W_TP / PCt ? PH : W_TP / PCt, nimg = W_TP / (PRt * PCt);
+    const int64_t wgs = (int64_t)(PW / PCt) * (PH / PRt) * ((B + nimg - 1) / nimg) * (N / W_TN);
+    return g_winograd == 2 || wgs >= 256;      // (fewer workgroups than half the chip's slots: the direct kernel's smaller tiles win, profiles/r06_winograd.txt)
+}
+
+int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream) {
+    AWR_REQUIRE(in && U && out, "wino_conv3x3: NULL pointer");
+    AWR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "wino_conv3x3: even map sizes only (H=%d, W=%d)", H, W);
+    AWR_REQUIRE(C % 8 == 0 && N % 32 == 0, "wino_conv3x3: C %% 8 == 0 and N %% 32 == 0 (C=%d, N=%d)", C, N);
+    const int64_t P = (int64_t)B * (H / 2) * (W / 2);
+    wino_args a{in, U, bias, out, B, H, W, C, N, relu};
+    const dim3 grid((unsigned)((P + W_TP - 1) / W_TP), N / W_TN);
+    // kb: channels per LDS stage (4 / 8); + 100: the 256-thread form (4 positions per wave) instead of the 512-thread one (2 per wave)
+    if (kb == 104) hipLaunchKernelGGL((wino_fwd_kernel<4, 4>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (kb == 108) hipLaunchKernelGGL((wino_fwd_kernel<8, 4>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (kb == 4) hipLaunchKernelGGL((wino_fwd_kernel<4, 8>), grid, dim3(512), 0, as_stream(stream), a);
+    else if (kb == 1008) hipLaunchKernelGGL((wino_fwd_kernel<8, 8, 1>), grid, dim3(512), 0, as_stream(stream), a);
+    else if (kb == 2008) hipLaunchKernelGGL((wino_fwd_kernel<8, 8, 2>), grid, dim3(512), 0, as_stream(stream), a);
+    else if (kb == 3008) hipLaunchKernelGGL((wino_fwd_kernel<8, 8, 3>), grid, dim3(512), 0, as_stream(stream), a);
+    else if (kb == 4008) hipLaunchKernelGGL((wino_fwd_kernel<8, 8, 4>), grid, dim3(512), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino_fwd_kernel<8, 8>), grid, dim3(512), 0, as_stream(stream), a);
+    return check_launch("wino_fwd_kernel");
+}
+
+
+int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const float* in_scale, const float* in_shift, int relu_in, float* out,
+                      double* stats, int nslots, int B, int H, int W, int C, int N, int relu, void* stream) {
+    AWR_REQUIRE(in && U && out, "wino2_conv3x3: NULL pointer");
+    AWR_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "wino2_conv3x3: even map sizes only (H=%d, W=%d)", H, W);
+    AWR_REQUIRE(C % 8 == 0 && N % 32 == 0, "wino2_conv3x3: C %% 8 == 0 and N %% 32 == 0 (C=%d, N=%d)", C, N);
+    AWR_REQUIRE((int64_t)B * H * W * C < (1LL << 31), "wino2_conv3x3: the input tensor must have fewer than 2^31 elements (32-bit offsets)");
+    AWR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino2_conv3x3: in_scale / in_shift come together");
+    AWR_REQUIRE(!stats || nslots > 0, "wino2_conv3x3: statistics need nslots > 0");
+    const int PH = H / 2, PW = W / 2;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    AWR_REQUIRE(pow2(PH) && pow2(PW), "wino2_conv3x3: power-of-two maps only (H=%d, W=%d)", H, W);
+    wino2_args a{in, U, bias, in_scale, in_shift, out, stats, B, H, W, C, N, relu, relu_in, nslots, 0, 0, 0};
+    a.PCt = PW < 32 ? PW : 32;
+    a.PRt = PH < W_TP / a.PCt ? PH : W_TP / a.PCt;
+    a.nimg = W_TP / (a.PRt * a.PCt);
+    AWR_REQUIRE(a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) <= 576, "wino2_conv3x3: raw tile of %d x %d x %d patches exceeds the LDS region", a.nimg, a.PRt, a.PCt);
+    const int tiles = (PW / a.PCt) * (PH / a.PRt) * ((B + a.nimg - 1) / a.nimg);
+    constexpr int KB = 8;
+    const size_t lds_v = (size_t)(16 * W_TP * (KB + 1) + 16 * KB * W_TN + 576 * (KB + 1)) * 4, lds_x = 16 * 32 * 32 * 4;
+    const size_t lds = lds_v > lds_x ? lds_v : lds_x;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) { set_error("wino2_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AWR_ERR_HIP; }
+        attr_done = true;
+    }
+    if (a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) * (KB / 4) <= 2 * 512)
+        hipLaunchKernelGGL((wino2_fwd_kernel<KB, 2>), dim3(tiles * (N / W_TN)), dim3(512), lds, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL((wino2_fwd_kernel<KB, 3>), dim3(tiles * (N / W_TN)), dim3(512), lds, as_stream(stream), a);
+    return check_launch("wino2_fwd_kernel");
+}
+
+}  // extern "C"

@@ -148,7 +148,7 @@ class AwrBackbone(nn.Module):
             self._counters.zero_()
 
     # ---- execution ----------------------------------------------------------------------------------
-    def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1, accum=None):
+    def get_plan(self, B, H, training, supervised="all", bn_repeat=1, n_buckets=1, accum=None, winograd=None):
         """accum: None = the process-wide mode (awr_amd.set_gemm_accum), "ordered" / "blocked" / "auto" = this plan's own (awr_conv_args.accum;
         "auto" blocks the forward launches whose K extent reaches awr_get_gemm_accum_auto()'s threshold, include/awr_hip.h)."""
         if not self._arena.is_cuda:
@@ -162,16 +162,22 @@ class AwrBackbone(nn.Module):
             if acc == 1:
                 raise L.AwrError("blocked accumulation (the parity mode) needs gemm_products = 1 and LDS-DMA staging; this process runs "
                                  "products = %d, staging = %d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging()))
+        wino = int(L.lib.awr_get_conv_winograd()) if winograd is None else (2 if winograd == "force" else int(bool(winograd)))      # captured when the plan is built, like accum
         key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets, L.lib.awr_get_deterministic(), acc,
-               _auto_rule() if acc == 2 else 0)
+               _auto_rule() if acc == 2 else 0, wino)
         plan = self._plans.get(key)
         if plan is None:
-            was = int(L.lib.awr_get_gemm_accum())
-            L.call("awr_set_gemm_accum", acc)          # plans capture the mode when they are built
+            was, was_w = int(L.lib.awr_get_gemm_accum()), int(L.lib.awr_get_conv_winograd())
+            L.call("awr_set_gemm_accum", acc)          # plans capture the modes when they are built
+            L.call("awr_set_conv_winograd", wino)
             try:
                 plan = Plan(self, B, H, H // getattr(self, "downsample", 2), self.J, training, supervised, bn_repeat, n_buckets)
             finally:
                 L.call("awr_set_gemm_accum", was)
+                L.call("awr_set_conv_winograd", was_w)
+            nw, wm = L.C.c_int(0), L.C.c_double(0)
+            L.call("awr_plan_winograd", plan.h, L.C.byref(nw), L.C.byref(wm))
+            plan.n_winograd, plan.winograd_macs = nw.value, wm.value       # forward launches that run as Winograd F(2x2, 3x3); their algorithmic MACs
             plan.accum = acc          # 0 = ordered, 1 = blocked, 2 = auto (blocked per launch by K extent): what the plan's GEMM launches captured
             self._plans[key] = plan
         return plan

@@ -63,11 +63,13 @@ class GradSync:
 class TrainEngine:
     def __init__(self, net, batch_size, img_size, kernel_size, coord_weight=0.0, dense_weight=1.0, lr=1e-3, weight_decay=0.0,
                  optimizer="adam", momentum=0.9, process_group=None, use_graph=False, n_buckets=4, autotune=True, wgrad_streams=2,
-                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, accum="auto", _share=None):
+                 nhwc_boundary=None, trace_buckets=False, native_rccl=None, accum="auto", winograd=None, _share=None):
         """accum: "auto" (default) | "ordered" | "blocked" | None (the process-wide mode, awr_amd.set_gemm_accum) -- accumulation order of the
         forward / data-gradient GEMMs of this engine's plan.  "blocked" is the parity mode (a conv's rounding error at torch-CPU's level, a few %
         slower); "auto" blocks only the launches with a long K extent (include/awr_hip.h: awr_set_gemm_accum), where an ordered chain's error
-        is largest and blocking is cheapest; "ordered" is one chain per output element everywhere."""
+        is largest and blocking is cheapest; "ordered" is one chain per output element everywhere.
+        winograd: None (the process-wide mode, awr_amd.set_conv_winograd) | True | False -- Winograd F(2x2, 3x3) forward of the eligible stride-1
+        3x3 convolutions (include/awr_hip.h)."""
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size
@@ -84,8 +86,8 @@ class TrainEngine:
         # (single GPU: scattering the packed weight gradients bucket by bucket during the backward, like the data-parallel plans do, instead
         # of in one launch at the tail of the step was measured slower: 14.28-14.32 vs 14.00-14.05 ms, profiles/r03_summary.md)
         self.plan = net.get_plan(batch_size, img_size, True, supervised=(self.stage,), bn_repeat=net.nstage,
-                                 n_buckets=n_buckets if self.dp else 1, accum=accum)
-        self._accum = accum
+                                 n_buckets=n_buckets if self.dp else 1, accum=accum, winograd=winograd)
+        self._accum, self._winograd = accum, winograd
         # weight-gradient GEMMs on extra HIP stream(s): co-resident DIFFERENT kernels fill each other's bubbles (0 = off); data
         # parallel: one more stream that finished gradient buckets (scatter + all-reduce) are handed to
         self.plan.set_streams(wgrad_streams, comm=(wgrad_streams > 0 and self.dp))
@@ -269,7 +271,7 @@ class TrainEngine:
         if eng is None:
             eng = TrainEngine(self.net, b, self.H, self.ks, self.cw, self.dw, self.lr, self.wd, self.opt, self.momentum,
                               process_group=self.sync.pg, use_graph=False, n_buckets=self._n_buckets, autotune=False,
-                              wgrad_streams=0, accum=self._accum, _share=self)
+                              wgrad_streams=0, accum=self._accum, winograd=self._winograd, _share=self)
             self._children[b] = eng
         eng.lr, eng.step_count = self.lr, self.step_count
         return eng
@@ -583,7 +585,8 @@ class Trainer:
             set_gemm_products(config.gemm_products)
         self.engine = TrainEngine(self.net, config.batch_size, config.img_size, config.kernel_size, config.coord_weight, config.dense_weight,
                                   config.lr, config.weight_decay, config.optimizer, process_group=process_group,
-                                  use_graph=getattr(config, "use_hipgraph", False), accum=getattr(config, "accum", "auto"))
+                                  use_graph=getattr(config, "use_hipgraph", False), accum=getattr(config, "accum", "auto"),
+                                  winograd=getattr(config, "winograd", None))
         if config.load_model and os.path.exists(config.load_model):
             self._msg("loading model from {}".format(config.load_model))
             pth = torch.load(config.load_model, map_location="cpu", weights_only=False)     # trusted project artefact (best_records may hold numpy scalars)

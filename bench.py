@@ -296,14 +296,14 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
             "mfma_frac": round(flop_mult * 2 * macs / (el / steps) / 1e12 / peak_tf, 4)}
 
 
-def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, peak_tf, workload, accum=None):
+def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, peak_tf, workload, accum="auto", winograd=None):
     """Sub-record for one more single-GPU BASELINE training shape (same protocol as the headline: inputs resident in HBM, `warmup` untimed
     steps, `steps` steps between two synchronisations, the FULL fused step -- GT map, forward, head, Huber, backward, Adam)."""
     import time as _t
     from awr_amd.trainer import TrainEngine
     torch.manual_seed(0)
     net = (awr_amd.get_deconv_net(18, J, 2) if net_name.startswith("resnet") else awr_amd.PoseNet(net_name, J)).cuda()
-    eng = TrainEngine(net, batch, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False, accum=accum)
+    eng = TrainEngine(net, batch, H, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, use_graph=False, accum=accum, winograd=winograd)
     img, jt = O.synth_batch(batch, H, J, seed=977)
     img, jt = img.to(dev), jt.to(dev)
     eng.compile(img, jt)
@@ -320,6 +320,12 @@ def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, pea
     rec = {"workload": workload, "value": round(batch / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
            "plan_gb": round(eng.plan.bytes / 1e9, 1), "algorithmic_gflop_per_image": round(2e-9 * macs / batch, 3),
            "step_mfma_frac": round(2.0 * macs / dt / 1e12 / peak_tf, 4), "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) < 1e30)}
+    if eng.plan.n_winograd:
+        # Winograd F(2x2, 3x3) forward launches execute 16 / 36 of their algorithmic multiplies: BOTH fractions are stated -- step_mfma_frac above is
+        # algorithmic FLOPs over the FP32-MFMA peak (it may legitimately exceed what the pipe executed), step_mfma_frac_executed what the matrix pipe ran
+        executed = macs - eng.plan.winograd_macs * (1.0 - 16.0 / 36.0)
+        rec.update({"winograd_forward_launches": int(eng.plan.n_winograd), "winograd_algorithmic_gflop_per_image": round(2e-9 * eng.plan.winograd_macs / batch, 3),
+                    "mfma_flops_per_algorithmic_flop": round(executed / macs, 4), "step_mfma_frac_executed": round(2.0 * executed / dt / 1e12 / peak_tf, 4)})
     del eng, net
     torch.cuda.empty_cache()
     return rec
@@ -454,6 +460,7 @@ def main():
     ap.add_argument("--no-hourglass-train", action="store_true", help="skip the Hourglass training sub-records 'hg1_train_b64' and 'config5'")
     ap.add_argument("--no-b256", action="store_true", help="skip the config-4 per-GPU shape (batch 256) sub-record")
     ap.add_argument("--no-data-path", action="store_true", help="skip the 'data_path' sub-record (host loader vs device loader, train step fed by the device path)")
+    ap.add_argument("--no-winograd", action="store_true", help="skip the 'winograd_mode' sub-record (Winograd F(2x2, 3x3) forward of the 3x3 convolutions)")
     ap.add_argument("--no-accurate-mode", action="store_true", help="skip the blocked-accumulation (parity mode) sub-record 'accurate_mode'")
     ap.add_argument("--no-native-rccl", action="store_true", help="N > 1: skip the 'native_rccl' sub-record (same steps, gradient buckets exchanged by the "
                                                                   "library's own RCCL communicator instead of torch.distributed work objects)")
@@ -750,6 +757,21 @@ def main():
                 out["data_path"] = measure_data_path(awr_amd, O, dev, out["ms_per_step"], max(args.steps, 20), 5)
             except Exception as e:          # (the headline has been measured: report, do not lose the line)
                 out["data_path"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if world == 1 and nprod == 1 and not args.no_winograd and not args.deterministic:
+            # Winograd F(2x2, 3x3) forward of the stride-1 3x3 convolutions (awr_amd.set_conv_winograd, opt-in): the headline's step and the Hourglass-1
+            # step, same protocol; joints against the oracle in that mode
+            eng = None
+            torch.cuda.empty_cache()
+            wm = {"mode": "forward of the eligible stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (csrc/awr_wino.hip); weight and "
+                          "data gradients direct; NOT the headline (value above is the direct path)",
+                  "train": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
+                                         "%s train step, batch %d, TrainEngine(winograd=True)" % (args.net, args.batch), winograd=True)}
+            wm["train"]["vs_headline"] = round(wm["train"]["value"] / out["value"], 4)
+            if args.net == "resnet_18" and not args.no_hourglass_train and "hg1_train_b64" in out:
+                wm["hg1_train_b64"] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
+                                                    "hourglass_1 train step, batch 64, TrainEngine(winograd=True)", winograd=True)
+                wm["hg1_train_b64"]["vs_direct"] = round(wm["hg1_train_b64"]["value"] / out["hg1_train_b64"]["value"], 4)
+            out["winograd_mode"] = wm
         if world == 1 and nprod == 1 and not args.no_accurate_mode and not args.deterministic:
             # the parity mode (blocked accumulation: awr_conv_args.accum = 1, what Trainer.test scores with and TrainEngine(accum="blocked") trains
             # with): the headline's step at the same batch, the scoring pass at batch 128, and the joint error against the oracle in that mode

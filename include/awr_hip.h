@@ -497,6 +497,9 @@ int awr_plan_create(awr_net* net, int B, int H, int training, unsigned supervise
 int awr_plan_destroy(awr_plan* plan);
 int awr_plan_info(const awr_plan* plan, int64_t* bytes, int* deterministic, int* n_fwd, int* n_bwd,
                   int* n_buckets, int* n_gemm, int* n_bn);
+/* forward launches of the plan that run as Winograd F(2x2, 3x3) (awr_set_conv_winograd): how many, and their ALGORITHMIC multiply-adds per replay
+ * (the matrix pipe executes 16 / 36 of them) */
+int awr_plan_winograd(const awr_plan* plan, int* n, double* macs);
 int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* ready_op);
 /* op i of the forward (list 0) / backward (list 1) launch list: name, algorithmic MACs (GEMM-family launches),
  * flags bit 0 = weight gradient that may run on a side stream, bit 1 = conv / stem family (the launches a roofline is quoted for) */
@@ -570,6 +573,31 @@ int awr_dp_wait(awr_dp* dp, void* stream);
  * NULL detaches.  Replaces the bucket callback while set.  Lifetime: the plan keeps the pointer, not a reference -- detach (NULL) before
  * awr_dp_destroy; a backward that finds its communicator destroyed fails with AWR_ERR_ARG instead of calling into it. */
 int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
+
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) on the FP32 matrix pipe (round 6, csrc/awr_wino.hip): stride-1 pad-1 3x3 convolutions with 2.25x fewer multiplies than the
+ * direct implicit GEMM -- nn.Conv2d(C, N, 3, 1, 1) of model/resnet_deconv.py:139-142,:161-165 / model/hourglass.py:35.
+ *   U[pos][c][n] = (G g G^T)[pos]            awr_wino_weights: from the checkpoint tensor (OIHW), once per optimiser step; mirror != 0 = the
+ *                                            data-gradient form (N = the layer's Cin, C = its Cout)
+ *   V = B^T d B per 4x4 input window, M[pos] = sum_c V U (16 independent GEMMs on v_mfma_f32_32x32x2_f32), Y = A^T M A per 2x2 output patch
+ * awr_wino2_conv3x3: out (B, H, W, N) = conv([relu](in * in_scale + in_shift)) [+ bias] [ReLU], NHWC; the raw input tile of a workgroup (a 2-D
+ * block of 64 patches of one image, or several small images) is staged in LDS once per K stage, padding stays zero under the fused input affine;
+ * `stats` (optional) += per-channel sum / sum of squares of the stored output ([nslots][2][N] doubles, awr_bn_finalize's layout).  Power-of-two map
+ * sizes >= 4, C % 8 == 0, N % 32 == 0, fewer than 2^31 input elements.  Results are NOT bit-compatible with awr_conv_gemm: Winograd's
+ * rounding differs -- measured 0.3-0.6x the direct kernel's error against float64 (chains of Cin terms instead of 9 Cin).
+ * awr_wino_conv3x3 is the first form (windows gathered from global memory; kb = channels per stage, + 100 = 256-thread workgroups), kept for the
+ * measurements in profiles/r06_winograd.txt.
+ * Plans: awr_set_conv_winograd(1) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0) makes plan builders run the FORWARD
+ * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
+ * awr_wino2_conv3x3; weight and data gradients stay direct.
+ * -----------------------------------------------------------------------------------------*/
+int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirror, float* U, void* stream);
+int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream);
+int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const float* in_scale, const float* in_shift, int relu_in, float* out,
+                      double* stats, int nslots, int B, int H, int W, int C, int N, int relu, void* stream);
+int awr_set_conv_winograd(int on);
+int awr_get_conv_winograd(void);
+int awr_wino_eligible(int B, int H, int W, int C, int N);
 
 /* ------------------------------------------------------------------------------------------
  * NYU data path on the device (csrc/awr_nyu.hip).  Replaces the IMAGE work of the reference's per-sample loader --

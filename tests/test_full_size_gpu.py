@@ -29,18 +29,25 @@ def _net(amd, name, J, sd):
     return m.cuda()
 
 
-def test_config2_resnet18_train_step_batch64_vs_oracle(amd, dev):
+_ORACLE_STEP = {}       # the oracle's batch-64 step is a dozen seconds of host time: computed once per session, shared by the modes
+
+
+@pytest.mark.parametrize("winograd", [False, True])
+def test_config2_resnet18_train_step_batch64_vs_oracle(amd, dev, winograd):
     """BASELINE configs[1] (the headline shape): one fused train step at batch 64 -- loss, joints, BatchNorm running statistics and
-    the parameters after Adam -- against the oracle's step on the same 64 images."""
+    the parameters after Adam -- against the oracle's step on the same 64 images; direct forward and Winograd F(2x2, 3x3) forward."""
     from awr_amd.trainer import TrainEngine
     J, B, ks = 14, 64, 1.0
     img, jt_gt = O.synth_batch(B, 128, J, seed=301)
     sd = O.reference_init_state("resnet_18", J, seed=3)
     m = _net(amd, "resnet_18", J, sd)
-    eng = TrainEngine(m, B, 128, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3)
+    eng = TrainEngine(m, B, 128, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, winograd=winograd)
+    assert (eng.plan.n_winograd >= 4) == winograd, eng.plan.n_winograd
     losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
-    sdo, ost = {k: v.clone() for k, v in sd.items()}, {"step": 0, "m": {}, "v": {}}
-    ref = O.train_step("resnet_18", sdo, ost, img, jt_gt, ks, 0.0, 1.0)
+    if "c2" not in _ORACLE_STEP:
+        sdo, ost = {k: v.clone() for k, v in sd.items()}, {"step": 0, "m": {}, "v": {}}
+        _ORACLE_STEP["c2"] = (O.train_step("resnet_18", sdo, ost, img, jt_gt, ks, 0.0, 1.0), sdo)
+    ref, sdo = _ORACLE_STEP["c2"]
     loss_ref, jt_ref = float(ref[0]), ref[-1]
     assert abs(float(losses[2]) - loss_ref) <= 1e-5 * abs(loss_ref), (float(losses[2]), loss_ref)
     d = (jt.cpu() - jt_ref).norm(dim=-1) * 150.0

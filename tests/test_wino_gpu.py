@@ -1,0 +1,112 @@
+"""GPU: the Winograd F(2x2, 3x3) study kernel (csrc/awr_wino.hip, operator level) against float64 torch-CPU convolutions: forward with bias /
+ReLU, ragged tiles (patch counts that are not a multiple of 64), several maps per tile (4x4 maps), and the data-gradient form (mirrored
+weights) against autograd.  Winograd is not bit-compatible with the direct kernel: the bar is a relative error against float64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import awr_amd  # noqa: F401
+    from awr_amd import _lib as L, ops
+    return L, ops, torch.device("cuda:0")
+
+
+def wino(L, x_nhwc, w, bias, relu, kb, mirror=False):
+    dev = x_nhwc.device
+    B, H, W, C = x_nhwc.shape
+    N = w.shape[1] if mirror else w.shape[0]
+    Npad = (N + 31) // 32 * 32
+    U = torch.zeros(16, C, Npad, device=dev)
+    L.call("awr_wino_weights", L.ptr(w.to(dev).contiguous()), N, C, Npad, C, int(mirror), L.ptr(U), L.stream())
+    out = torch.full((B, H, W, Npad), float("nan"), device=dev)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(Npad, device=dev)
+        bp[:N] = bias.to(dev)
+    L.call("awr_wino_conv3x3", L.ptr(x_nhwc), L.ptr(U), L.ptr(bp), L.ptr(out), B, H, W, C, Npad, int(relu), kb, L.stream())
+    torch.cuda.synchronize()
+    return out[..., :N].cpu()
+
+
+@pytest.mark.parametrize("kb", [8, 4, 108, 104])
+@pytest.mark.parametrize("B,H,W,cin,cout,bias,relu", [(2, 16, 16, 64, 64, True, True), (3, 8, 12, 32, 96, False, False), (5, 4, 4, 128, 40, True, False),
+                                                       (1, 2, 2, 8, 32, False, True), (2, 32, 32, 16, 128, True, False)])
+def test_winograd_forward_matches_float64(env, kb, B, H, W, cin, cout, bias, relu):
+    L, ops, dev = env
+    g = torch.Generator().manual_seed(B * 100 + H + cin)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    got = wino(L, x.permute(0, 2, 3, 1).contiguous().to(dev), w, b, relu, kb).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+
+
+def test_winograd_data_gradient_form(env):
+    """mirror = 1: d(x) = conv(d(y), w mirrored, channel roles swapped) -- against autograd in float64"""
+    L, ops, dev = env
+    g = torch.Generator().manual_seed(7)
+    B, H, cin, cout = 2, 16, 48 + 16, 32
+    x = torch.randn(B, cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(B, cout, H, H, generator=g)
+    (gx,) = torch.autograd.grad((torch.nn.functional.conv2d(x, w.double(), padding=1) * dy.double()).sum(), x)
+    got = wino(L, dy.permute(0, 2, 3, 1).contiguous().to(dev), w, None, False, 8, mirror=True).permute(0, 3, 1, 2)
+    err = float((got.double() - gx).abs().max()) / float(gx.abs().max())
+    assert err < 2e-5, err
+
+
+def wino2(L, x_nhwc, w, bias, relu, in_affine=None, relu_in=False, stats=False):
+    dev = x_nhwc.device
+    B, H, W, C = x_nhwc.shape
+    N = w.shape[0]
+    Npad = (N + 31) // 32 * 32
+    U = torch.zeros(16, C, Npad, device=dev)
+    L.call("awr_wino_weights", L.ptr(w.to(dev).contiguous()), N, C, Npad, C, 0, L.ptr(U), L.stream())
+    out = torch.full((B, H, W, Npad), float("nan"), device=dev)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(Npad, device=dev)
+        bp[:N] = bias.to(dev)
+    st = torch.zeros(16, 2, Npad, device=dev, dtype=torch.float64) if stats else None
+    sc, sh = (in_affine[0].to(dev), in_affine[1].to(dev)) if in_affine is not None else (None, None)
+    L.call("awr_wino2_conv3x3", L.ptr(x_nhwc), L.ptr(U), L.ptr(bp), L.ptr(sc), L.ptr(sh), int(relu_in), L.ptr(out), L.ptr(st), 16 if stats else 0,
+           B, H, W, C, Npad, int(relu), L.stream())
+    torch.cuda.synchronize()
+    return out[..., :N].cpu(), (st.sum(0)[:, :N].cpu() if stats else None)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,bias,relu,affine", [(2, 16, 16, 64, 64, True, True, False), (3, 8, 16, 32, 96, False, False, True), (5, 4, 4, 128, 40, True, False, True),
+                                                              (18, 4, 4, 8, 32, False, True, False), (2, 64, 64, 16, 32, True, False, True), (1, 128, 128, 8, 32, False, False, False),
+                                                              (3, 32, 8, 24, 64, True, False, True)])
+def test_winograd_v2_forward_prologue_and_statistics(env, B, H, W, cin, cout, bias, relu, affine):
+    """the raw-tile form: 2-D patch tiles (several small images per tile, ragged last tile), fused input affine + ReLU with zero padding kept
+    zero, per-channel statistics of the stored output"""
+    L, ops, dev = env
+    g = torch.Generator().manual_seed(B * 100 + H + cin)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    sc, sh = (torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3) if affine else (None, None)
+    xin = x.double()
+    if affine:
+        xin = (xin * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).clamp(min=0)
+    ref = torch.nn.functional.conv2d(xin, w.double(), None if b is None else b.double(), padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    got, st = wino2(L, x.permute(0, 2, 3, 1).contiguous().to(dev), w, b, relu, (sc, sh) if affine else None, relu_in=affine, stats=True)
+    got = got.permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+    s1, s2 = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
+    assert float((st[0] - s1).abs().max()) <= 2e-5 * float(ref.abs().max()) * ref[:, 0].numel()
+    assert float((st[1] - s2).abs().max()) <= 2e-5 * float(s2.abs().max())
