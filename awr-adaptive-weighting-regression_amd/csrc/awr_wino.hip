@@ -386,7 +386,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
     // ---- epilogue: exchange through LDS (32 patches at a time), output transform, bias / ReLU / statistics, 16-byte stores ----
     float* const X = lds;
     const int n4 = tid & 7, pi = (tid >> 3) & 31, rr = tid >> 8;
-    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+    // statistics in double from the first product on: sum x^2 of a nearly constant channel (std << |mean|) loses its variance to the rounding of x^2
+    // in fp32 (the direct kernel sums x - c for the same reason, csrc/awr_conv_kernels.inc)
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
@@ -416,8 +418,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
                 y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
             }
             if (a.stats) {
-                ssum.x += y0.x + y1.x; ssum.y += y0.y + y1.y; ssum.z += y0.z + y1.z; ssum.w += y0.w + y1.w;
-                ssq.x += y0.x * y0.x + y1.x * y1.x; ssq.y += y0.y * y0.y + y1.y * y1.y; ssq.z += y0.z * y0.z + y1.z * y1.z; ssq.w += y0.w * y0.w + y1.w * y1.w;
+                const float* p0 = &y0.x;
+                const float* p1 = &y1.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double u = (double)p0[e], v = (double)p1[e];
+                    ssum[e] += u + v;
+                    ssq[e] += u * u + v * v;
+                }
             }
             float* o = a.out + (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + n0 + 4 * n4;
             st4(o, y0);
@@ -427,15 +435,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
     if (a.stats) {
         // lanes with the same channel quad (tid & 7) of one wave hold 8 patches: reduce over them, then one atomic per (wave, channel)
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-            ssum.x += __shfl_xor(ssum.x, o, 64); ssum.y += __shfl_xor(ssum.y, o, 64); ssum.z += __shfl_xor(ssum.z, o, 64); ssum.w += __shfl_xor(ssum.w, o, 64);
-            ssq.x += __shfl_xor(ssq.x, o, 64); ssq.y += __shfl_xor(ssq.y, o, 64); ssq.z += __shfl_xor(ssq.z, o, 64); ssq.w += __shfl_xor(ssq.w, o, 64);
-        }
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
         if (lane < 8) {
             const int slot = (tile * 8 + wave) % a.nslots;
             double* st = a.stats + (int64_t)slot * 2 * a.N + n0 + 4 * n4;
-            atomicAdd(st + 0, (double)ssum.x); atomicAdd(st + 1, (double)ssum.y); atomicAdd(st + 2, (double)ssum.z); atomicAdd(st + 3, (double)ssum.w);
-            atomicAdd(st + a.N + 0, (double)ssq.x); atomicAdd(st + a.N + 1, (double)ssq.y); atomicAdd(st + a.N + 2, (double)ssq.z); atomicAdd(st + a.N + 3, (double)ssq.w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(st + e, ssum[e]);
+                atomicAdd(st + a.N + e, ssq[e]);
+            }
         }
     }
 }

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 export AWR_TUNE_CACHE=$OUT/tune_cache_prof_$TAG.json
 export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-parity --no-split-mode --no-extras --no-b256 --no-accurate-mode"
+COMMON="--no-cpu-baseline --no-parity --no-split-mode --no-extras --no-b256 --no-accurate-mode --no-data-path --no-winograd"
 python bench.py --steps 20 --warmup 5 --no-split-mode > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; cut -c1-250 $OUT/bench_$TAG.json
 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --per-layer $OUT/per_layer_${TAG}_f32.txt > /dev/null 2>> $OUT/bench_$TAG.err
 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_${TAG}_hg1_train.txt > /dev/null 2>> $OUT/bench_$TAG.err
