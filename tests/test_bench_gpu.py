@@ -42,12 +42,18 @@ def test_bench_single_process_line():
     am = d["accurate_mode"]
     assert am["train"]["value"] > 0 and 0.5 < am["train"]["vs_headline"] < 1.2 and am["infer_b128"]["value"] > 0
     assert am["joint_err_mm_vs_oracle"]["mean"] < 1e-3
+    # round 6: the opt-in Winograd forward mode with BOTH roofline fractions (batch 8 has few eligible launches: the record must still be there)
+    wm = d["winograd_mode"]["train"]
+    assert wm["value"] > 0 and 0.5 < wm["vs_headline"] < 1.5
+    if wm.get("winograd_forward_launches"):
+        assert wm["mfma_flops_per_algorithmic_flop"] < 1.0 and wm["step_mfma_frac_executed"] < wm["step_mfma_frac"]
 
 
 def test_bench_under_torchrun_with_forced_dp_path():
     env = dict(os.environ, AWR_FORCE_DP="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"]
+           "--master-port", "29541", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline",
+           "--no-extras", "--no-winograd", "--no-accurate-mode", "--no-split-mode"]      # (those sub-records are test_bench_single_process_line's)
     out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)

@@ -1181,6 +1181,41 @@ def test_streaming_output_stores_write_the_same_bits(ops, L, dev, kind, cin, cou
         L.call("awr_conv_gemm", C.byref(a), L.stream())
 
 
+@pytest.mark.parametrize("tile", [(1, 1), (2, 1), (1, 2)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_blocked_accumulation_in_the_deep_pipeline_is_bit_identical(ops, L, dev, tile, affine):
+    """Round 6: launches that cannot fill the chip (<= 384 workgroups: layer4 at batch 64, the two-image fixtures) take the deep pipeline (four stage
+    buffers) in the BLOCKED accumulation mode too -- same k order, same fold points every 128 k, so the same bits as the two-buffer blocked kernel;
+    and blocked differs from ordered (otherwise the flag did nothing).  3x3, K = 1152, statistics epilogue, with / without the fused input affine."""
+    import ctypes as C
+    B, H, cin, cout = 2, 8, 128, 128
+    spec = ops.ConvSpec("conv", cin, cout, 3, 1, 1)
+    x, w = rnd(B, cin, H, H, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    prob = spec.fwd_problem(H, H)
+    xin = ops.nhwc(x).to(dev).contiguous()
+    wp = ops.pack_weight(w.to(dev), spec.fwd_pack())
+    sc, sh = (rnd(cin, seed=5).abs().to(dev) + 0.5, rnd(cin, seed=6).to(dev)) if affine else (None, None)
+    got = {}
+    L.call("awr_debug_force_tile", *tile)
+    try:
+        for accum, deep in ((1, 1), (1, 0), (0, 1)):
+            L.call("awr_debug_set_knob", b"deep", deep)
+            out = torch.full((B, H, H, prob["N"]), float("nan"), device=dev)
+            st = torch.zeros(16, 2, prob["N"], device=dev, dtype=torch.float64)
+            a = ops.make_conv_args(prob, B, xin, wp, out, in_scale=sc, in_shift=sh, relu_in=affine, stats=st, T=spec.T)
+            a.accum = accum
+            L.call("awr_conv_gemm", C.byref(a), L.stream())
+            torch.cuda.synchronize()
+            got[(accum, deep)] = (out.clone(), st.sum(0).clone())
+    finally:
+        L.call("awr_debug_set_knob", b"deep", 1)
+        L.call("awr_debug_force_tile", 0, 0)
+    assert not torch.isnan(got[(1, 1)][0]).any()
+    assert torch.equal(got[(1, 1)][0], got[(1, 0)][0]) and torch.equal(got[(1, 1)][1], got[(1, 0)][1])
+    assert not torch.equal(got[(1, 1)][0], got[(0, 1)][0])
+    assert rel_err(got[(1, 1)][0].cpu(), got[(0, 1)][0].cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("tile", [(1, 1), (2, 1), (1, 2), (2, 2)])
 def test_statistics_from_the_accumulators_match_the_row_layout_form(ops, L, dev, tile):
     """EM 5 (round 5): a statistics launch whose stored value is accumulator + bias on tiles wholly inside M sums x - c and (x - c)^2 in the ACCUMULATOR
