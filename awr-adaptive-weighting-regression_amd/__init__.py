@@ -48,12 +48,18 @@ def set_conv_winograd(on):
     pipe (include/awr_hip.h: awr_set_conv_winograd; csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-0.6x the direct kernel's rounding error,
     not bit-compatible with it."""
     from . import _lib as L
-    L.call("awr_set_conv_winograd", 2 if on == "force" else int(bool(on)))        # "force": tests (every layer the kernel can run, whatever its size)
+    L.call("awr_set_conv_winograd", _winograd_code(on))
+
+
+def _winograd_code(on):
+    """False / None -> 0, True / "forward" -> 1 (forward launches), "full" -> 2 (forward + data gradients), "force" -> 6 (tests: "full" on every layer the
+    kernel can run, whatever the launch size)"""
+    return {"forward": 1, "full": 2, "force": 6}.get(on, 1 if on else 0) if not isinstance(on, int) or isinstance(on, bool) else int(on)
 
 
 def get_conv_winograd():
     from . import _lib as L
-    return bool(L.lib.awr_get_conv_winograd())
+    return int(L.lib.awr_get_conv_winograd())
 
 
 def get_gemm_accum():

@@ -80,6 +80,13 @@ class WgradArgs(C.Structure):
                 ("dy", C.c_int8 * 16), ("dx", C.c_int8 * 16), ("split_stride", C.c_int64), ("max_split", C.c_int)]
 
 
+class WinoArgs(C.Structure):
+    """awr_wino_args (include/awr_hip.h)"""
+    _fields_ = [("in_", C.c_void_p), ("U", C.c_void_p), ("bias", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("out", C.c_void_p),
+                ("stats", C.c_void_p), ("res", C.c_void_p), ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p), ("bnr_act", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("N", C.c_int), ("relu", C.c_int), ("relu_in", C.c_int), ("nslots", C.c_int)]
+
+
 class NyuSample(C.Structure):
     """awr_nyu_sample (include/awr_hip.h): one image of a device-side NYU batch."""
     _fields_ = [("frame", C.c_int64), ("ustart", C.c_int32), ("vstart", C.c_int32), ("cw", C.c_int32), ("ch", C.c_int32),
@@ -199,6 +206,9 @@ _SIGS = {
     "awr_wino_weights": ([_P, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "awr_wino_conv3x3": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "awr_wino2_conv3x3": ([_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "awr_wino_conv": ([C.POINTER(WinoArgs), _P], C.c_int),
+    "awr_wino_dgrad_or_direct": ([C.POINTER(ConvArgs), _P, _P], C.c_int),
+    "awr_wino_dgrad_supported": ([C.POINTER(ConvArgs)], C.c_int),
     "awr_set_conv_winograd": ([_I], C.c_int),
     "awr_get_conv_winograd": ([], C.c_int),
     "awr_wino_eligible": ([_I, _I, _I, _I, _I], C.c_int),

@@ -675,7 +675,9 @@ struct awr_plan {
     std::vector<Op> fwd, bwd, pack_ops;
     std::vector<std::function<int()>> nodes;       // backward emitters, in forward order
     std::vector<ConvLayer*> layers;                // layers whose packed copies this plan refreshes
-    int n_wino = 0;
+    int n_wino = 0;      // forward launches that run as Winograd F(2x2, 3x3)
+    std::vector<std::pair<ConvLayer*, float*>> wino_d;      // (layer, mirrored U[16][cout_pad][cin_pad])
+    std::vector<std::pair<const awr_conv_args*, double>> wino_dg;      // candidate data-gradient launches (argument block, MACs): Winograd if the COMPLETED block is supported
     double wino_macs = 0;            // algorithmic multiply-adds of those launches (they execute 16 / 36 of them)
     std::vector<std::pair<ConvLayer*, float*>> wino;      // ... and whose forward runs as Winograd F(2x2, 3x3): (layer, U[16][cin_pad][cout_pad])
     std::vector<DualLayer*> dual_layers;
@@ -1228,7 +1230,20 @@ struct Builder {
                     Op& hw = b("__halfwait__", nullptr);
                     hw.kind = OP_HALFWAIT;
                 }
-                Op& dop = b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
+                // Winograd data gradient (round 6): same eligibility as the forward; the launch decides from the COMPLETED argument block whether it
+                // implements its epilogue (plain, accumulate, BatchNorm-backward reduction) and runs the direct kernel otherwise
+                float* Ud = nullptr;
+                if ((awr_get_conv_winograd() & 3) == 2 && !P.det && awr_get_gemm_products() == 1 && !spec.deconv && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
+                    dp.full && !y->lz_g && awr_wino_eligible(B, dp.Hin, dp.Win, spec.cout_pad, spec.cin_pad)) {
+                    for (auto& wl : P.wino_d)
+                        if (wl.first == layer) Ud = wl.second;
+                    if (!Ud) {
+                        Ud = alloc<float>((int64_t)16 * spec.cout_pad * spec.cin_pad);
+                        P.wino_d.push_back({layer, Ud});
+                    }
+                    P.wino_dg.push_back({da, layer_macs});
+                }
+                Op& dop = Ud ? b(dname, [da, Ud](void* s) { return awr_wino_dgrad_or_direct(da, Ud, s); }) : b(dname, [da](void* s) { return awr_conv_gemm(da, s); });
                 dop.gemm = true;
                 dop.macs = layer_macs;
             }
@@ -2002,6 +2017,8 @@ static int refresh_weights(awr_plan& P, void* stream) {
         NET_CHECK(awr_pack_weights_batched((const awr_pack_job*)P.pack_tab[ws][1], P.pack_njobs[ws][1], P.pack_rows[ws][1], stream));
     for (auto& wl : P.wino)
         NET_CHECK(awr_wino_weights(wl.first->w, wl.first->spec.cout, wl.first->spec.cin, wl.first->spec.cout_pad, wl.first->spec.cin_pad, 0, wl.second, stream));
+    for (auto& wl : P.wino_d)        // data-gradient form: output channels = the layer's Cin, contraction over its Cout, taps mirrored
+        NET_CHECK(awr_wino_weights(wl.first->w, wl.first->spec.cin, wl.first->spec.cout, wl.first->spec.cin_pad, wl.first->spec.cout_pad, 1, wl.second, stream));
     hipStream_t st = awr::as_stream(stream);
     for (auto* l : P.layers) {
         if (!l->head) continue;
@@ -2426,8 +2443,12 @@ int awr_plan_info(const awr_plan* p, int64_t* bytes, int* deterministic, int* n_
 
 int awr_plan_winograd(const awr_plan* p, int* n, double* macs) {
     AWR_REQUIRE(p, "plan_winograd: null pointer");
-    if (n) *n = p->n_wino;
-    if (macs) *macs = p->wino_macs;
+    int nd = 0;
+    double md = 0;
+    for (auto& c : p->wino_dg)
+        if (awr_wino_dgrad_supported(c.first)) { ++nd; md += c.second; }
+    if (n) *n = p->n_wino + nd;
+    if (macs) *macs = p->wino_macs + md;
     return AWR_OK;
 }
 

@@ -13,6 +13,7 @@
 // reuses it (64 KB): two workgroups per CU, whose transform / MFMA phases interleave.  Operator level only (tools/microbench_wino.py,
 // tests/test_wino_gpu.py); the go / no-go numbers are in profiles/r06_winograd.txt.
 #include <stdlib.h>
+#include <string.h>
 
 #include "awr_common.h"
 
@@ -235,6 +236,11 @@ struct wino2_args {
     const float* in_shift;
     float* out;
     double* stats;           // optional: per-channel sum / sum of squares of the stored output, [nslots][2][N] (awr_bn_finalize's layout)
+    // data-gradient epilogue (awr_conv_args.res / bnr_y / bnr_coef / bnr_act of the direct kernel): out = mask(acc + res), stats += (sum g, sum g * xhat)
+    const float* res;
+    const float* bnr_y;
+    const float* bnr_coef;   // [scale | shift | mean | invstd][N]
+    const float* bnr_act;
     int B, H, W, C, N, relu, relu_in, nslots;
     int PRt, PCt, nimg;      // tile: nimg images x PRt x PCt patches = 64
 };
@@ -413,11 +419,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
             if (a.bias) bs = ld4(a.bias + n0 + 4 * n4);
             float4 y0 = make_float4(s[0].x + s[1].x + s[2].x + bs.x, s[0].y + s[1].y + s[2].y + bs.y, s[0].z + s[1].z + s[2].z + bs.z, s[0].w + s[1].w + s[2].w + bs.w);
             float4 y1 = make_float4(s[1].x - s[2].x - s[3].x + bs.x, s[1].y - s[2].y - s[3].y + bs.y, s[1].z - s[2].z - s[3].z + bs.z, s[1].w - s[2].w - s[3].w + bs.w);
+            const int64_t ooff = (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + n0 + 4 * n4;
+            if (a.res) {
+                const float4 r0 = ld4(a.res + ooff), r1 = ld4(a.res + ooff + a.N);
+                y0.x += r0.x; y0.y += r0.y; y0.z += r0.z; y0.w += r0.w;
+                y1.x += r1.x; y1.y += r1.y; y1.z += r1.z; y1.w += r1.w;
+            }
+            if (a.bnr_y) {
+                // the value is the gradient w.r.t. relu(bn(y) [+ residual]): mask it with the re-derived ReLU (or the stored activation's sign) and reduce
+                // sum g, sum g * xhat for that BatchNorm's backward -- the EM 3 / 4 epilogues of the direct kernel (csrc/awr_conv_kernels.inc)
+                const int nn = n0 + 4 * n4;
+                const float4 ksc = ld4(a.bnr_coef + nn), ksh = ld4(a.bnr_coef + a.N + nn), kmu = ld4(a.bnr_coef + 2 * a.N + nn), kis = ld4(a.bnr_coef + 3 * a.N + nn);
+                const float4 q0 = ld4(a.bnr_y + ooff), q1 = ld4(a.bnr_y + ooff + a.N);
+                if (a.bnr_act) {
+                    const float4 a0 = ld4(a.bnr_act + ooff), a1 = ld4(a.bnr_act + ooff + a.N);
+                    y0.x = a0.x > 0.f ? y0.x : 0.f; y0.y = a0.y > 0.f ? y0.y : 0.f; y0.z = a0.z > 0.f ? y0.z : 0.f; y0.w = a0.w > 0.f ? y0.w : 0.f;
+                    y1.x = a1.x > 0.f ? y1.x : 0.f; y1.y = a1.y > 0.f ? y1.y : 0.f; y1.z = a1.z > 0.f ? y1.z : 0.f; y1.w = a1.w > 0.f ? y1.w : 0.f;
+                } else {
+                    y0.x = q0.x * ksc.x + ksh.x > 0.f ? y0.x : 0.f; y0.y = q0.y * ksc.y + ksh.y > 0.f ? y0.y : 0.f;
+                    y0.z = q0.z * ksc.z + ksh.z > 0.f ? y0.z : 0.f; y0.w = q0.w * ksc.w + ksh.w > 0.f ? y0.w : 0.f;
+                    y1.x = q1.x * ksc.x + ksh.x > 0.f ? y1.x : 0.f; y1.y = q1.y * ksc.y + ksh.y > 0.f ? y1.y : 0.f;
+                    y1.z = q1.z * ksc.z + ksh.z > 0.f ? y1.z : 0.f; y1.w = q1.w * ksc.w + ksh.w > 0.f ? y1.w : 0.f;
+                }
+                const float* g0 = &y0.x;
+                const float* g1 = &y1.x;
+                const float* t0 = &q0.x;
+                const float* t1 = &q1.x;
+                const float* mu = &kmu.x;
+                const float* is = &kis.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ssum[e] += (double)g0[e] + (double)g1[e];
+                    ssq[e] += (double)(g0[e] * ((t0[e] - mu[e]) * is[e])) + (double)(g1[e] * ((t1[e] - mu[e]) * is[e]));
+                }
+            }
             if (a.relu) {
                 y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
                 y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
             }
-            if (a.stats) {
+            if (a.stats && !a.bnr_y) {
                 const float* p0 = &y0.x;
                 const float* p1 = &y1.x;
 #pragma unroll
@@ -427,7 +467,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
                     ssq[e] += u * u + v * v;
                 }
             }
-            float* o = a.out + (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + n0 + 4 * n4;
+            float* o = a.out + ooff;
             st4(o, y0);
             st4(o + a.N, y1);
         }
@@ -469,8 +509,8 @@ int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirro
 static int g_winograd = []() { const char* e = getenv("AWR_WINOGRAD"); return e ? atoi(e) : 0; }();
 
 int awr_set_conv_winograd(int on) {
-    AWR_REQUIRE(on >= 0 && on <= 2, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible) or "
-                                    "2 (tests: wherever the kernel can run, whatever the launch size)");
+    AWR_REQUIRE(on >= 0 && (on & 3) <= 2 && on < 8, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible), "
+                                                     "2 (forward and data gradient); + 4 (tests: wherever the kernel can run, whatever the launch size)");
     g_winograd = on;
     return AWR_OK;
 }
@@ -478,12 +518,12 @@ int awr_set_conv_winograd(int on) {
 int awr_get_conv_winograd(void) { return g_winograd; }
 
 int awr_wino_eligible(int B, int H, int W, int C, int N) {
-    const int minside = g_winograd == 2 ? 4 : 16;
+    const int minside = (g_winograd & 4) ? 4 : 16;
     if (H < minside || W < minside || (H & (H - 1)) || (W & (W - 1)) || C % 8 || N % 32) return 0;
     if ((int64_t)B * H * W * C >= (1LL << 31)) return 0;
     const int PH = H / 2, PW = W / 2, PCt = PW < 32 ? PW : 32, PRt = PH < W_TP / PCt ? PH : W_TP / PCt, nimg = W_TP / (PRt * PCt);
     const int64_t wgs = (int64_t)(PW / PCt) * (PH / PRt) * ((B + nimg - 1) / nimg) * (N / W_TN);
-    return g_winograd == 2 || wgs >= 256;      // (fewer workgroups than half the chip's slots: the direct kernel's smaller tiles win, profiles/r06_winograd.txt)
+    return (g_winograd & 4) || wgs >= 256;      // (fewer workgroups than half the chip's slots: the direct kernel's smaller tiles win, profiles/r06_winograd.txt)
 }
 
 int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream) {
@@ -506,22 +546,25 @@ int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* 
 }
 
 
-int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const float* in_scale, const float* in_shift, int relu_in, float* out,
-                      double* stats, int nslots, int B, int H, int W, int C, int N, int relu, void* stream) {
-    AWR_REQUIRE(in && U && out, "wino2_conv3x3: NULL pointer");
-    AWR_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "wino2_conv3x3: even map sizes only (H=%d, W=%d)", H, W);
-    AWR_REQUIRE(C % 8 == 0 && N % 32 == 0, "wino2_conv3x3: C %% 8 == 0 and N %% 32 == 0 (C=%d, N=%d)", C, N);
-    AWR_REQUIRE((int64_t)B * H * W * C < (1LL << 31), "wino2_conv3x3: the input tensor must have fewer than 2^31 elements (32-bit offsets)");
-    AWR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino2_conv3x3: in_scale / in_shift come together");
-    AWR_REQUIRE(!stats || nslots > 0, "wino2_conv3x3: statistics need nslots > 0");
+int awr_wino_conv(const awr_wino_args* p, void* stream) {
+    AWR_REQUIRE(p && p->in && p->U && p->out, "wino_conv: NULL pointer");
+    const int B = p->B, H = p->H, W = p->W, C = p->C, N = p->N;
+    AWR_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "wino_conv: even map sizes only (H=%d, W=%d)", H, W);
+    AWR_REQUIRE(C % 8 == 0 && N % 32 == 0, "wino_conv: C %% 8 == 0 and N %% 32 == 0 (C=%d, N=%d)", C, N);
+    AWR_REQUIRE((int64_t)B * H * W * C < (1LL << 31), "wino_conv: the input tensor must have fewer than 2^31 elements (32-bit offsets)");
+    AWR_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "wino_conv: in_scale / in_shift come together");
+    AWR_REQUIRE(!p->stats || p->nslots > 0, "wino_conv: statistics need nslots > 0");
+    AWR_REQUIRE(!p->bnr_y || (p->bnr_coef && p->stats && !p->bias && !p->relu), "wino_conv: the BatchNorm-backward reduction needs bnr_coef and stats, and excludes bias / ReLU");
+    AWR_REQUIRE(!p->bnr_act || p->bnr_y, "wino_conv: bnr_act without bnr_y");
     const int PH = H / 2, PW = W / 2;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    AWR_REQUIRE(pow2(PH) && pow2(PW), "wino2_conv3x3: power-of-two maps only (H=%d, W=%d)", H, W);
-    wino2_args a{in, U, bias, in_scale, in_shift, out, stats, B, H, W, C, N, relu, relu_in, nslots, 0, 0, 0};
+    AWR_REQUIRE(pow2(PH) && pow2(PW), "wino_conv: power-of-two maps only (H=%d, W=%d)", H, W);
+    wino2_args a{p->in, p->U, p->bias, p->in_scale, p->in_shift, p->out, p->stats, p->res, p->bnr_y, p->bnr_coef, p->bnr_act,
+                 B, H, W, C, N, p->relu, p->relu_in, p->nslots, 0, 0, 0};
     a.PCt = PW < 32 ? PW : 32;
     a.PRt = PH < W_TP / a.PCt ? PH : W_TP / a.PCt;
     a.nimg = W_TP / (a.PRt * a.PCt);
-    AWR_REQUIRE(a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) <= 576, "wino2_conv3x3: raw tile of %d x %d x %d patches exceeds the LDS region", a.nimg, a.PRt, a.PCt);
+    AWR_REQUIRE(a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) <= 576, "wino_conv: raw tile of %d x %d x %d patches exceeds the LDS region", a.nimg, a.PRt, a.PCt);
     const int tiles = (PW / a.PCt) * (PH / a.PRt) * ((B + a.nimg - 1) / a.nimg);
     constexpr int KB = 8;
     const size_t lds_v = (size_t)(16 * W_TP * (KB + 1) + 16 * KB * W_TN + 576 * (KB + 1)) * 4, lds_x = 16 * 32 * 32 * 4;
@@ -530,7 +573,7 @@ int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const 
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) { set_error("wino2_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AWR_ERR_HIP; }
+        if (e != hipSuccess) { set_error("wino_conv: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AWR_ERR_HIP; }
         attr_done = true;
     }
     if (a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) * (KB / 4) <= 2 * 512)
@@ -538,6 +581,35 @@ int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const 
     else
         hipLaunchKernelGGL((wino2_fwd_kernel<KB, 3>), dim3(tiles * (N / W_TN)), dim3(512), lds, as_stream(stream), a);
     return check_launch("wino2_fwd_kernel");
+}
+
+int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const float* in_scale, const float* in_shift, int relu_in, float* out,
+                      double* stats, int nslots, int B, int H, int W, int C, int N, int relu, void* stream) {
+    awr_wino_args p;
+    memset(&p, 0, sizeof p);
+    p.in = in; p.U = U; p.bias = bias; p.in_scale = in_scale; p.in_shift = in_shift; p.out = out; p.stats = stats;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.N = N; p.relu = relu; p.relu_in = relu_in; p.nslots = nslots;
+    return awr_wino_conv(&p, stream);
+}
+
+// The data gradient of a stride-1 3x3 convolution as described by the direct kernel's argument block (plans): whatever of its epilogue this kernel
+// implements runs as Winograd (U = the MIRRORED transform, awr_wino_weights(..., mirror = 1)), anything else falls back to awr_conv_gemm.
+int awr_wino_dgrad_supported(const awr_conv_args* d) {
+    if (!d) return 0;
+    const bool plain = !d->in_scale && !d->relu_in && !d->bias && !d->out_scale && !d->relu_out && !d->in2 && !d->w2 && !d->partial && !d->in_bnb_y && !d->bnr2_y &&
+                       !d->in_split && !d->pool_out && (!d->res || d->res == d->out) && (!d->bnr_y || (d->bnr_coef && d->stats)) && (d->bnr_y || !d->stats);
+    return plain ? 1 : 0;
+}
+
+int awr_wino_dgrad_or_direct(const awr_conv_args* d, const float* U, void* stream) {
+    AWR_REQUIRE(d && U, "wino_dgrad: NULL pointer");
+    if (!awr_wino_dgrad_supported(d)) return awr_conv_gemm(d, stream);
+    awr_wino_args p;
+    memset(&p, 0, sizeof p);
+    p.in = d->in; p.U = U; p.out = d->out; p.res = d->res; p.bnr_y = d->bnr_y; p.bnr_coef = d->bnr_coef; p.bnr_act = d->bnr_act; p.stats = d->stats;
+    p.nslots = d->stats ? (d->stat_slots > 0 ? d->stat_slots : AWR_STAT_SLOTS) : 0;
+    p.B = d->B; p.H = d->Hin; p.W = d->Win; p.C = d->Cin; p.N = d->N;
+    return awr_wino_conv(&p, stream);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .engine import PARAM_KINDS, NetHandle, Plan
+from . import _winograd_code
 
 
 def _auto_rule():
@@ -162,7 +163,7 @@ class AwrBackbone(nn.Module):
             if acc == 1:
                 raise L.AwrError("blocked accumulation (the parity mode) needs gemm_products = 1 and LDS-DMA staging; this process runs "
                                  "products = %d, staging = %d" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging()))
-        wino = int(L.lib.awr_get_conv_winograd()) if winograd is None else (2 if winograd == "force" else int(bool(winograd)))      # captured when the plan is built, like accum
+        wino = int(L.lib.awr_get_conv_winograd()) if winograd is None else _winograd_code(winograd)      # captured when the plan is built, like accum
         key = (B, H, bool(training), supervised if isinstance(supervised, str) else tuple(supervised), bn_repeat, n_buckets, L.lib.awr_get_deterministic(), acc,
                _auto_rule() if acc == 2 else 0, wino)
         plan = self._plans.get(key)

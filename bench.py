@@ -324,7 +324,7 @@ def measure_train(awr_amd, O, net_name, J, H, batch, ks, dev, steps, warmup, pea
         # Winograd F(2x2, 3x3) forward launches execute 16 / 36 of their algorithmic multiplies: BOTH fractions are stated -- step_mfma_frac above is
         # algorithmic FLOPs over the FP32-MFMA peak (it may legitimately exceed what the pipe executed), step_mfma_frac_executed what the matrix pipe ran
         executed = macs - eng.plan.winograd_macs * (1.0 - 16.0 / 36.0)
-        rec.update({"winograd_forward_launches": int(eng.plan.n_winograd), "winograd_algorithmic_gflop_per_image": round(2e-9 * eng.plan.winograd_macs / batch, 3),
+        rec.update({"winograd_launches": int(eng.plan.n_winograd), "winograd_algorithmic_gflop_per_image": round(2e-9 * eng.plan.winograd_macs / batch, 3),
                     "mfma_flops_per_algorithmic_flop": round(executed / macs, 4), "step_mfma_frac_executed": round(2.0 * executed / dt / 1e12 / peak_tf, 4)})
     del eng, net
     torch.cuda.empty_cache()
@@ -762,15 +762,20 @@ def main():
             # step, same protocol; joints against the oracle in that mode
             eng = None
             torch.cuda.empty_cache()
-            wm = {"mode": "forward of the eligible stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (csrc/awr_wino.hip); weight and "
-                          "data gradients direct; NOT the headline (value above is the direct path)",
+            wm = {"mode": "eligible stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (csrc/awr_wino.hip): 'forward' = their forward "
+                          "launches, 'full' = forward and data gradients (a Winograd data gradient leaves less room for the weight gradients that run beside it: "
+                          "ResNet18 prefers 'forward', the Hourglass 'full'); weight gradients direct; NOT the headline (value above is the direct path)",
                   "train": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
-                                         "%s train step, batch %d, TrainEngine(winograd=True)" % (args.net, args.batch), winograd=True)}
-            wm["train"]["vs_headline"] = round(wm["train"]["value"] / out["value"], 4)
+                                         "%s train step, batch %d, TrainEngine(winograd=True)" % (args.net, args.batch), winograd=True),
+                  "train_full": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
+                                              "%s train step, batch %d, TrainEngine(winograd='full')" % (args.net, args.batch), winograd="full")}
+            for k in ("train", "train_full"):
+                wm[k]["vs_headline"] = round(wm[k]["value"] / out["value"], 4)
             if args.net == "resnet_18" and not args.no_hourglass_train and "hg1_train_b64" in out:
-                wm["hg1_train_b64"] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
-                                                    "hourglass_1 train step, batch 64, TrainEngine(winograd=True)", winograd=True)
-                wm["hg1_train_b64"]["vs_direct"] = round(wm["hg1_train_b64"]["value"] / out["hg1_train_b64"]["value"], 4)
+                for k, mode in (("hg1_train_b64", True), ("hg1_train_b64_full", "full")):
+                    wm[k] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
+                                          "hourglass_1 train step, batch 64, TrainEngine(winograd=%r)" % (mode,), winograd=mode)
+                    wm[k]["vs_direct"] = round(wm[k]["value"] / out["hg1_train_b64"]["value"], 4)
             out["winograd_mode"] = wm
         if world == 1 and nprod == 1 and not args.no_accurate_mode and not args.deterministic:
             # the parity mode (blocked accumulation: awr_conv_args.accum = 1, what Trainer.test scores with and TrainEngine(accum="blocked") trains

@@ -497,7 +497,7 @@ int awr_plan_create(awr_net* net, int B, int H, int training, unsigned supervise
 int awr_plan_destroy(awr_plan* plan);
 int awr_plan_info(const awr_plan* plan, int64_t* bytes, int* deterministic, int* n_fwd, int* n_bwd,
                   int* n_buckets, int* n_gemm, int* n_bn);
-/* forward launches of the plan that run as Winograd F(2x2, 3x3) (awr_set_conv_winograd): how many, and their ALGORITHMIC multiply-adds per replay
+/* forward and data-gradient launches of the plan that run as Winograd F(2x2, 3x3) (awr_set_conv_winograd): how many, and their ALGORITHMIC multiply-adds per replay
  * (the matrix pipe executes 16 / 36 of them) */
 int awr_plan_winograd(const awr_plan* plan, int* n, double* macs);
 int awr_plan_bucket(const awr_plan* plan, int i, int64_t* lo, int64_t* hi, int* ready_op);
@@ -587,14 +587,31 @@ int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
  * rounding differs -- measured 0.3-0.6x the direct kernel's error against float64 (chains of Cin terms instead of 9 Cin).
  * awr_wino_conv3x3 is the first form (windows gathered from global memory; kb = channels per stage, + 100 = 256-thread workgroups), kept for the
  * measurements in profiles/r06_winograd.txt.
- * Plans: awr_set_conv_winograd(1) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0) makes plan builders run the FORWARD
+ * Plans: awr_set_conv_winograd(1 | 2) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0; 2 = also the data gradients, + 4 =
+ * ignore the launch-size rule: tests) makes plan builders run the FORWARD
  * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
- * awr_wino2_conv3x3; weight and data gradients stay direct.
+ * awr_wino2_conv3x3, and the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
+ * awr_wino_dgrad_or_direct; weight gradients stay direct.
  * -----------------------------------------------------------------------------------------*/
 int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirror, float* U, void* stream);
 int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream);
 int awr_wino2_conv3x3(const float* in, const float* U, const float* bias, const float* in_scale, const float* in_shift, int relu_in, float* out,
                       double* stats, int nslots, int B, int H, int W, int C, int N, int relu, void* stream);
+/* the same kernel through an argument block, with the data-gradient epilogue forms of awr_conv_args (res = accumulate in place, bnr_y / bnr_coef /
+ * bnr_act = mask with the re-derived ReLU and reduce sum g, sum g * xhat into `stats` for the BatchNorm backward) */
+typedef struct awr_wino_args {
+    const float *in, *U, *bias, *in_scale, *in_shift;
+    float* out;
+    double* stats;
+    const float *res, *bnr_y, *bnr_coef, *bnr_act;
+    int B, H, W, C, N, relu, relu_in, nslots;
+} awr_wino_args;
+int awr_wino_conv(const awr_wino_args* a, void* stream);
+/* plans: the data gradient of a stride-1 3x3 convolution described by the DIRECT kernel's argument block `d` -- as Winograd (U = awr_wino_weights(...,
+ * mirror = 1)) when this kernel implements everything `d` asks for, through awr_conv_gemm(d) otherwise (decided at launch: plan builders complete
+ * `d` after they have created the launch) */
+int awr_wino_dgrad_or_direct(const awr_conv_args* d, const float* U, void* stream);
+int awr_wino_dgrad_supported(const awr_conv_args* d);
 int awr_set_conv_winograd(int on);
 int awr_get_conv_winograd(void);
 int awr_wino_eligible(int B, int H, int W, int C, int N);

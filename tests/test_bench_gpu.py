@@ -45,7 +45,7 @@ def test_bench_single_process_line():
     # round 6: the opt-in Winograd forward mode with BOTH roofline fractions (batch 8 has few eligible launches: the record must still be there)
     wm = d["winograd_mode"]["train"]
     assert wm["value"] > 0 and 0.5 < wm["vs_headline"] < 1.5
-    if wm.get("winograd_forward_launches"):
+    if wm.get("winograd_launches"):
         assert wm["mfma_flops_per_algorithmic_flop"] < 1.0 and wm["step_mfma_frac_executed"] < wm["step_mfma_frac"]
 
 

@@ -1020,7 +1020,7 @@ def test_winograd_forward_mode_meets_the_same_golden_bars(amd, dev, golden_dir, 
         J = 14
         m = make_net(amd, net, J, O.procedural_state(O.manifest_for(net, J), seed=0))
         nw = m.get_plan(2, 128, True).n_winograd
-        report("%s/winograd_forward_launches" % net, nw)
+        report("%s/winograd_launches" % net, nw)
         assert nw >= 4, nw
         test_backbone_forward_golden(amd, dev, golden_dir, net)
         test_fused_train_step_golden(amd, dev, golden_dir, net, "c1", 1.0)
@@ -1031,6 +1031,10 @@ def test_winograd_forward_mode_meets_the_same_golden_bars(amd, dev, golden_dir, 
     nw2 = TrainEngine(m, 2, 128, 1.0, winograd=True, use_graph=False, autotune=False).plan.n_winograd
     assert nw2 < nw and (nw2 == 0 or net != "resnet_18"), (nw2, nw)
     assert not amd.get_conv_winograd()
+    # "forward" (= True) replaces forward launches only, "full" the data gradients as well
+    m64 = make_net(amd, net, 14, O.reference_init_state(net, 14, seed=3))
+    nf, nfull = m64.get_plan(64, 128, True, winograd=True).n_winograd, m64.get_plan(64, 128, True, winograd="full").n_winograd
+    assert 0 < nf < nfull, (nf, nfull)
 
 
 def test_train_and_test_entry_points(dev, tmp_path):

@@ -110,3 +110,61 @@ def test_winograd_v2_forward_prologue_and_statistics(env, B, H, W, cin, cout, bi
     s1, s2 = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
     assert float((st[0] - s1).abs().max()) <= 2e-5 * float(ref.abs().max()) * ref[:, 0].numel()
     assert float((st[1] - s2).abs().max()) <= 2e-5 * float(s2.abs().max())
+
+
+@pytest.mark.parametrize("use_res,use_bnr,use_act", [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, True, True)])
+def test_winograd_data_gradient_epilogues(env, use_res, use_bnr, use_act):
+    """awr_wino_conv with the data-gradient epilogue forms plans use (include/awr_hip.h: awr_wino_args): mirrored weights, accumulate onto the gradient
+    already in `out`, mask with the re-derived ReLU (or the stored activation's sign) and reduce sum g / sum g * xhat for the BatchNorm backward --
+    against float64 autograd + the same formulas in torch."""
+    import ctypes as C
+    L, ops, dev = env
+    g = torch.Generator().manual_seed(11 + use_res + 2 * use_bnr + 4 * use_act)
+    B, H, W, cin, cout = 3, 16, 32, 64, 96
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(B, cout, H, W, generator=g)
+    x = torch.zeros(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    (dx,) = torch.autograd.grad((torch.nn.functional.conv2d(x, w.double(), padding=1) * dy.double()).sum(), x)
+    r = torch.randn(B, cin, H, W, generator=g)
+    yb = torch.randn(B, cin, H, W, generator=g)
+    act = torch.randn(B, cin, H, W, generator=g)
+    sc, sh, mu, istd = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3, torch.randn(cin, generator=g) * 0.2, torch.rand(cin, generator=g) + 0.5
+    v = dx + (r.double() if use_res else 0)
+    if use_bnr:
+        mask = (act > 0) if use_act else (yb.double() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) > 0)
+        v = v * mask
+        s1 = v.sum((0, 2, 3))
+        s2 = (v * ((yb.double() - mu.view(1, -1, 1, 1)) * istd.view(1, -1, 1, 1))).sum((0, 2, 3))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().float().to(dev)      # noqa: E731
+    U = torch.zeros(16, cout, cin, device=dev)
+    L.call("awr_wino_weights", L.ptr(w.to(dev).contiguous()), cin, cout, cin, cout, 1, L.ptr(U), L.stream())
+    out = nhwc(r) if use_res else torch.full((B, H, W, cin), float("nan"), device=dev)
+    din, yy, aa = nhwc(dy), nhwc(yb), nhwc(act)
+    coef = torch.cat([sc, sh, mu, istd]).to(dev).contiguous()
+    st = torch.zeros(16, 2, cin, device=dev, dtype=torch.float64)
+    a = L.WinoArgs()
+    a.in_, a.U, a.out = L.ptr(din), L.ptr(U), L.ptr(out)
+    a.B, a.H, a.W, a.C, a.N = B, H, W, cout, cin
+    if use_res:
+        a.res = L.ptr(out)
+    if use_bnr:
+        a.bnr_y, a.bnr_coef, a.stats, a.nslots = L.ptr(yy), L.ptr(coef), L.ptr(st), 16
+        if use_act:
+            a.bnr_act = L.ptr(aa)
+    L.call("awr_wino_conv", C.byref(a), L.stream())
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    scale = float(v.abs().max())
+    # a mask decided by a float32 sign may flip where the float64 argument is within rounding of zero: compare where both agree
+    diff = (got - v).abs()
+    assert float((diff > 2e-5 * scale).float().mean()) < 1e-4 and float(diff.max()) < 1.0 * scale
+    if use_bnr:
+        tot = st.sum(0).cpu()
+        assert float((tot[0] - s1).abs().max()) <= 1e-4 * float(v.abs().sum((0, 2, 3)).max())
+        assert float((tot[1] - s2).abs().max()) <= 1e-4 * float(v.abs().sum((0, 2, 3)).max()) * 3
+    # and the dispatcher: an argument block this kernel does not implement goes through the direct kernel (same numbers within fp32)
+    from awr_amd._lib import ConvArgs
+    d = ConvArgs()
+    assert L.lib.awr_wino_dgrad_supported(C.byref(d)) == 1
+    d.relu_out = 1
+    assert L.lib.awr_wino_dgrad_supported(C.byref(d)) == 0
