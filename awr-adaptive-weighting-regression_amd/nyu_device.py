@@ -133,7 +133,7 @@ class FrameStore:
         self.data = torch.empty((self.n, self.fh, self.fw), dtype=tdt, device=device)
         for lo in range(0, self.n, chunk):                    # chunked: the memmap is never materialised on the host at once
             hi = min(self.n, lo + chunk)
-            self.data[lo:hi].copy_(torch.from_numpy(np.ascontiguousarray(frames[lo:hi])), non_blocking=False)
+            self.data[lo:hi].copy_(torch.from_numpy(np.array(frames[lo:hi])), non_blocking=False)      # (np.array: a writable copy of the memmap chunk)
 
     @property
     def nbytes(self):

