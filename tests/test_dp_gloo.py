@@ -91,3 +91,55 @@ def test_evaluator_matches_golden(golden_dir):
     assert abs(mpe - float(g["mpe"])) < 1e-3 and abs(auc - float(g["auc"])) < 1e-6 and abs(med - float(g["med"])) < 1e-3
     np.testing.assert_allclose(pck, g["pck"], atol=1e-9)
     np.testing.assert_allclose(np.array(ev.jt_uvd_pred), g["uvd"], atol=2e-3)
+
+
+def _loader_worker(rank, world, port, q):
+    """one rank of a 2-rank job iterating the parameter-block dataset the way Trainer._loader does (DistributedSampler, same epoch seed)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import awr_amd  # noqa: F401
+    from awr_amd import nyu_device as DV
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(4)
+        n = 22
+        centers = np.stack([rng.uniform(-100, 100, n), rng.uniform(-80, 80, n), rng.uniform(600, 900, n)], 1)
+        labels = centers[:, None, :] + rng.uniform(-60, 60, (n, 14, 3))
+        data = DV.DeviceNYU.from_arrays((n, 480, 640), labels, centers, "test", img_size=128)
+        sampler = torch.utils.data.distributed.DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, drop_last=False)
+        sampler.set_epoch(3)
+        seen = []
+        for blocks, jt_xyz, jt_uvd, center, M, cube in torch.utils.data.DataLoader(data, batch_size=4, sampler=sampler, num_workers=0):
+            assert blocks.dtype == torch.uint8 and blocks.shape[1] == DV.BLOCK_BYTES
+            for b in blocks:
+                blk = awr_amd._lib.NyuSample.from_buffer_copy(bytes(b.numpy()))
+                seen.append(int(blk.frame))
+        # every rank steps the same number of batches (the gradient all-reduce of the step needs that)
+        counts = [None] * world
+        torch.distributed.all_gather_object(counts, len(seen))
+        q.put((rank, seen, counts))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_device_loader_blocks_shard_over_two_ranks_gloo():
+    """Data parallel + device data path: each rank draws its 1 / world shard of the epoch's permutation as parameter blocks (every rank holds the whole
+    frame store, a block addresses its frame by index); together the ranks cover the dataset, with equal batch counts."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loader_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, c0), (r1, s1, c1) = res
+    assert c0 == c1 == [11, 11]
+    assert sorted(set(s0) | set(s1)) == list(range(22)) and not (set(s0) & set(s1))
