@@ -687,6 +687,13 @@ def main():
         b256 = {"workload": "resnet_18-deconv train step, batch 256/GPU = BASELINE configs[3] per-GPU shape", "value": round(world * 256 * k2 / el2, 2), "unit": "images/s",
                 "n_gpus": world, "steps": k2, "warmup": 3, "ms_per_step": round(1e3 * el2 / k2, 3), "plan_gb": round(eng2.plan.bytes / 1e9, 1),
                 "step_mfma_frac": round(flop_mult * (tot_fl / max(nsteps_timed, 1)) * (256 / args.batch) / (el2 / k2) / 1e12 / peak_tf, 4)}
+        # the HBM-bound head / loss launches at the batch where they have work (batch 64 moves 118 MB in 35 us: launch-ramp-bound)
+        hb2 = eng2.timed_hbm()
+        pb2, db2 = 4 * 14 * 64 * 64 * 4, 64 * 64 * 4
+        alg2 = {"head_forward_nhwc": 256 * (pb2 + db2 + 14 * 12), "head_forward": 256 * (pb2 + db2 + 14 * 12), "head_backward": 256 * (2 * pb2 + db2),
+                "dense_loss": 256 * (2 * pb2 + db2), "head_loss_step_nhwc": 256 * ((2 if args.coord_weight == 0.0 else 3) * pb2 + db2)}
+        b256["roofline_hbm"] = {k: {"bytes_algorithmic": alg2[k], "avg_us": round(1e6 * v, 2), "gbps": round(alg2[k] / v / 1e9, 1), "frac_of_8TBps": round(alg2[k] / v / 8e12, 4)}
+                                for k, v in hb2.items() if k in alg2}
         if pg is not None:          # north_star's scaling target is stated at this shape: the replicas must still agree bit for bit after its steps
             b256["dp_selftest"] = {"replicas_bitwise_equal_after_steps": _replicas_equal(net), "steps_checked": k2 + 3}
         del eng2

@@ -38,6 +38,7 @@ def test_bench_single_process_line():
         assert v["bytes_algorithmic"] > 0 and v["avg_us"] > 0 and abs(v["frac_of_8TBps"] - v["gbps"] / 8000.0) < 2e-3, (k, v)
     assert "adam_step" in d["roofline_hbm"] and ("head_loss_step_nhwc" in d["roofline_hbm"] or "dense_loss" in d["roofline_hbm"])
     assert d["b256"]["n_gpus"] == 1 and abs(d["b256"]["value"] - 256 * 1e3 / d["b256"]["ms_per_step"]) < 1e-2 * d["b256"]["value"]
+    assert all(v["gbps"] > 0 for v in d["b256"]["roofline_hbm"].values()) and len(d["b256"]["roofline_hbm"]) >= 2      # round 6: the head kernels where they have work
     # round 5: the parity mode (blocked accumulation) in the driver-run line -- the headline's step, the scoring pass, the joint error in that mode
     am = d["accurate_mode"]
     assert am["train"]["value"] > 0 and 0.5 < am["train"]["vs_headline"] < 1.2 and am["infer_b128"]["value"] > 0
