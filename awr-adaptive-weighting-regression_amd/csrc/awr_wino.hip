@@ -245,11 +245,14 @@ struct wino2_args {
     int PRt, PCt, nimg;      // tile: nimg images x PRt x PCt patches = 64
 };
 
-template <int KB, int RITEMS>      // RITEMS: 16-byte raw-tile requests per thread and stage (2 covers 512 pixels, 3 the 576 of sixteen 4x4 maps)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void wino2_fwd_kernel(const wino2_args a) {
+// RITEMS: 16-byte raw-tile requests per thread and stage; TN: output channels per workgroup (32: 8 waves x 2 positions, two workgroups per CU;
+// 64: 16 waves x 1 position, one workgroup per CU -- every transformed window feeds twice as many multiplies)
+template <int KB, int RITEMS, int TN = 32>
+__global__ __launch_bounds__(TN == 64 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(4))) void wino2_fwd_kernel(const wino2_args a) {
     // (a k-pair-interleaved layout with 8-byte LDS accesses -- Vs[pos][k / 2][patch][2], Raw[pixel][KB + 2], 256 transform items of two
     // channels -- was built and measured SLOWER: 568 vs 528 us on 128 -> 128 @ 64 x 64 x 64; profiles/r06_winograd.txt)
-    constexpr int NT = 512, QP = 2;
+    constexpr int NT = TN == 64 ? 1024 : 512, QP = TN == 64 ? 1 : 2, NTT = TN / 32;      // threads, positions per wave, 32-channel tiles per position
+    constexpr int W_TN = TN;
     constexpr int VROW = KB + 1, RP = KB + 1;          // odd pitches: conflict-free A-fragment reads, 2-way window reads
     constexpr int V_FLOATS = 16 * W_TP * VROW, U_FLOATS = 16 * KB * W_TN;
     constexpr int RAW_MAX_PX = 576;
@@ -289,7 +292,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
         roff[r] = ok ? ((b * a.H + y) * a.W + x) * a.C + 4 * quad : -1;
     }
     // ---- transform item: patch tid / KB, channel tid % KB ----
-    const int ch = tid % KB, lp = tid / KB;                                   // (NT / KB == 64 patches: one item per thread)
+    const bool titem = tid < W_TP * KB;                                      // (512 items: the wide form's upper half of the workgroup has none)
+    const int ch = tid % KB, lp = (tid / KB) % W_TP;
     const int lil = lp / (a.PRt * a.PCt), lpr = (lp / a.PCt) % a.PRt, lpc = lp % a.PCt;
     const int tbase = ((lil * RH + 2 * lpr) * RW + 2 * lpc) * RP + ch;
     constexpr int UQ = U_FLOATS / 4 / NT;
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
         for (int q = 0; q < UQ; ++q) st4(Us + (tid + NT * q) * 4, ureg[q]);
     };
     auto transform = [&]() {
+        if (!titem) return;
         float d[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) d[t] = Raw[tbase + ((t >> 2) * RW + (t & 3)) * RP];
@@ -352,13 +357,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
         }
     };
 
-    f32x16 acc[QP][2];
+    f32x16 acc[QP][2][NTT];
 #pragma unroll
     for (int q = 0; q < QP; ++q)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][h][r] = 0.f;
+            for (int jt = 0; jt < NTT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][h][jt][r] = 0.f;
 
     load_stage(0);
     store_raw();
@@ -374,11 +381,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
 #pragma unroll
             for (int q = 0; q < QP; ++q) {
                 const int pos = QP * wave + q;
-                const float b = Us[(pos * KB + 2 * s + half) * W_TN + l31];
                 const float a0 = Vs[(pos * W_TP + l31) * VROW + 2 * s + half];
                 const float a1 = Vs[(pos * W_TP + 32 + l31) * VROW + 2 * s + half];
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[q][0], 0, 0, 0);
-                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[q][1], 0, 0, 0);
+#pragma unroll
+                for (int jt = 0; jt < NTT; ++jt) {
+                    const float b = Us[(pos * KB + 2 * s + half) * W_TN + 32 * jt + l31];
+                    acc[q][0][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[q][0][jt], 0, 0, 0);
+                    acc[q][1][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[q][1][jt], 0, 0, 0);
+                }
             }
         if (more) store_raw();            // (nobody reads Raw now: the previous transform finished before the previous barrier)
         __syncthreads();                  // everyone is done reading Vs / Us
@@ -391,22 +401,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
 
     // ---- epilogue: exchange through LDS (32 patches at a time), output transform, bias / ReLU / statistics, 16-byte stores ----
     float* const X = lds;
-    const int n4 = tid & 7, pi = (tid >> 3) & 31, rr = tid >> 8;
+    const int n4 = tid & 7, pi = (tid >> 3) & 31, rr = (tid >> 8) & 1;
+    const bool oitem = tid < 512;                      // 32 patches x 8 channel quads x 2 output rows per exchange round
     // statistics in double from the first product on: sum x^2 of a nearly constant channel (std << |mean|) loses its variance to the rounding of x^2
     // in fp32 (the direct kernel sums x - c for the same reason, csrc/awr_conv_kernels.inc)
-    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
+    double ssum[NTT][4], ssq[NTT][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
+    for (int jt = 0; jt < NTT; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[jt][e] = ssq[jt][e] = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int jt = 0; jt < NTT; ++jt) {
+        if (h || jt) __syncthreads();
 #pragma unroll
         for (int q = 0; q < QP; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[((QP * wave + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[q][h][r];
+            for (int r = 0; r < 16; ++r) X[((QP * wave + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[q][h][jt][r];
         __syncthreads();
         const int p = 32 * h + pi;
         const int il = p / (a.PRt * a.PCt), pr = (p / a.PCt) % a.PRt, pc = p % a.PCt;
         const int b = img0 + il;
-        if (b < a.B) {
+        const int nq = n0 + 32 * jt + 4 * n4;          // first of this thread's four output channels
+        if (oitem && b < a.B) {
             float4 s[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -416,10 +434,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
                 else s[j] = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z, m1.w - m2.w - m03.w);
             }
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) bs = ld4(a.bias + n0 + 4 * n4);
+            if (a.bias) bs = ld4(a.bias + nq);
             float4 y0 = make_float4(s[0].x + s[1].x + s[2].x + bs.x, s[0].y + s[1].y + s[2].y + bs.y, s[0].z + s[1].z + s[2].z + bs.z, s[0].w + s[1].w + s[2].w + bs.w);
             float4 y1 = make_float4(s[1].x - s[2].x - s[3].x + bs.x, s[1].y - s[2].y - s[3].y + bs.y, s[1].z - s[2].z - s[3].z + bs.z, s[1].w - s[2].w - s[3].w + bs.w);
-            const int64_t ooff = (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + n0 + 4 * n4;
+            const int64_t ooff = (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + nq;
             if (a.res) {
                 const float4 r0 = ld4(a.res + ooff), r1 = ld4(a.res + ooff + a.N);
                 y0.x += r0.x; y0.y += r0.y; y0.z += r0.z; y0.w += r0.w;
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
             if (a.bnr_y) {
                 // the value is the gradient w.r.t. relu(bn(y) [+ residual]): mask it with the re-derived ReLU (or the stored activation's sign) and reduce
                 // sum g, sum g * xhat for that BatchNorm's backward -- the EM 3 / 4 epilogues of the direct kernel (csrc/awr_conv_kernels.inc)
-                const int nn = n0 + 4 * n4;
+                const int nn = nq;
                 const float4 ksc = ld4(a.bnr_coef + nn), ksh = ld4(a.bnr_coef + a.N + nn), kmu = ld4(a.bnr_coef + 2 * a.N + nn), kis = ld4(a.bnr_coef + 3 * a.N + nn);
                 const float4 q0 = ld4(a.bnr_y + ooff), q1 = ld4(a.bnr_y + ooff + a.N);
                 if (a.bnr_act) {
@@ -449,8 +467,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
                 const float* is = &kis.x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ssum[e] += (double)g0[e] + (double)g1[e];
-                    ssq[e] += (double)(g0[e] * ((t0[e] - mu[e]) * is[e])) + (double)(g1[e] * ((t1[e] - mu[e]) * is[e]));
+                    ssum[jt][e] += (double)g0[e] + (double)g1[e];
+                    ssq[jt][e] += (double)(g0[e] * ((t0[e] - mu[e]) * is[e])) + (double)(g1[e] * ((t1[e] - mu[e]) * is[e]));
                 }
             }
             if (a.relu) {
@@ -463,8 +481,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const double u = (double)p0[e], v = (double)p1[e];
-                    ssum[e] += u + v;
-                    ssq[e] += u * u + v * v;
+                    ssum[jt][e] += u + v;
+                    ssq[jt][e] += u * u + v * v;
                 }
             }
             float* o = a.out + ooff;
@@ -472,22 +490,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void w
             st4(o + a.N, y1);
         }
     }
-    if (a.stats) {
+    if (a.stats && oitem) {
         // lanes with the same channel quad (tid & 7) of one wave hold 8 patches: reduce over them, then one atomic per (wave, channel)
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1)
+        for (int jt = 0; jt < NTT; ++jt) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ssum[e] += __shfl_xor(ssum[e], o, 64);
-                ssq[e] += __shfl_xor(ssq[e], o, 64);
-            }
-        if (lane < 8) {
-            const int slot = (tile * 8 + wave) % a.nslots;
-            double* st = a.stats + (int64_t)slot * 2 * a.N + n0 + 4 * n4;
+            for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(st + e, ssum[e]);
-                atomicAdd(st + a.N + e, ssq[e]);
+                for (int e = 0; e < 4; ++e) {
+                    ssum[jt][e] += __shfl_xor(ssum[jt][e], o, 64);
+                    ssq[jt][e] += __shfl_xor(ssq[jt][e], o, 64);
+                }
+            if (lane < 8) {
+                const int slot = (tile * 8 + wave) % a.nslots;
+                double* st = a.stats + (int64_t)slot * 2 * a.N + n0 + 32 * jt + 4 * n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(st + e, ssum[jt][e]);
+                    atomicAdd(st + a.N + e, ssq[jt][e]);
+                }
             }
         }
     }
@@ -509,8 +530,8 @@ int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirro
 static int g_winograd = []() { const char* e = getenv("AWR_WINOGRAD"); return e ? atoi(e) : 0; }();
 
 int awr_set_conv_winograd(int on) {
-    AWR_REQUIRE(on >= 0 && (on & 3) <= 2 && on < 8, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible), "
-                                                     "2 (forward and data gradient); + 4 (tests: wherever the kernel can run, whatever the launch size)");
+    AWR_REQUIRE(on >= 0 && (on & 3) <= 2 && on < 16, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible), "
+                                                     "2 (forward and data gradient); + 4 (tests: wherever the kernel can run, whatever the launch size); + 8 (A/B: never the 64-channel tile form)");
     g_winograd = on;
     return AWR_OK;
 }
@@ -567,16 +588,24 @@ int awr_wino_conv(const awr_wino_args* p, void* stream) {
     AWR_REQUIRE(a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) <= 576, "wino_conv: raw tile of %d x %d x %d patches exceeds the LDS region", a.nimg, a.PRt, a.PCt);
     const int tiles = (PW / a.PCt) * (PH / a.PRt) * ((B + a.nimg - 1) / a.nimg);
     constexpr int KB = 8;
-    const size_t lds_v = (size_t)(16 * W_TP * (KB + 1) + 16 * KB * W_TN + 576 * (KB + 1)) * 4, lds_x = 16 * 32 * 32 * 4;
+    // the wide form (64 output channels per workgroup, 16 waves, one workgroup per CU): every transformed window feeds twice the multiplies -- 174 instead of
+    // 163 algorithmic TF on 128 -> 128 @ 64 x 64, 188 instead of 162 on 256 -> 256 @ 16 x 16 (profiles/r06_winograd.txt); needs N % 64 == 0 and enough
+    // workgroups to fill the chip at one per CU
+    const bool wide = !(g_winograd & 8) && N % 64 == 0 && ((g_winograd & 4) || (int64_t)tiles * (N / 64) >= 256);
+    const int TNsel = wide ? 64 : W_TN;
+    const size_t lds_v = (size_t)(16 * W_TP * (KB + 1) + 16 * KB * TNsel + 576 * (KB + 1)) * 4, lds_x = 16 * 32 * 32 * 4;
     const size_t lds = lds_v > lds_x ? lds_v : lds_x;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2_fwd_kernel<KB, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) { set_error("wino_conv: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AWR_ERR_HIP; }
         attr_done = true;
     }
-    if (a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) * (KB / 4) <= 2 * 512)
+    if (wide)
+        hipLaunchKernelGGL((wino2_fwd_kernel<KB, 2, 64>), dim3(tiles * (N / 64)), dim3(1024), lds, as_stream(stream), a);
+    else if (a.nimg * (2 * a.PRt + 2) * (2 * a.PCt + 2) * (KB / 4) <= 2 * 512)
         hipLaunchKernelGGL((wino2_fwd_kernel<KB, 2>), dim3(tiles * (N / W_TN)), dim3(512), lds, as_stream(stream), a);
     else
         hipLaunchKernelGGL((wino2_fwd_kernel<KB, 3>), dim3(tiles * (N / W_TN)), dim3(512), lds, as_stream(stream), a);

@@ -588,7 +588,7 @@ int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
  * awr_wino_conv3x3 is the first form (windows gathered from global memory; kb = channels per stage, + 100 = 256-thread workgroups), kept for the
  * measurements in profiles/r06_winograd.txt.
  * Plans: awr_set_conv_winograd(1 | 2) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0; 2 = also the data gradients, + 4 =
- * ignore the launch-size rule: tests) makes plan builders run the FORWARD
+ * ignore the launch-size rule: tests, + 8 = never the 64-channel tile form: A/B) makes plan builders run the FORWARD
  * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
  * awr_wino2_conv3x3, and the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
  * awr_wino_dgrad_or_direct; weight gradients stay direct.

@@ -87,7 +87,8 @@ def wino2(L, x_nhwc, w, bias, relu, in_affine=None, relu_in=False, stats=False):
 @pytest.mark.parametrize("B,H,W,cin,cout,bias,relu,affine", [(2, 16, 16, 64, 64, True, True, False), (3, 8, 16, 32, 96, False, False, True), (5, 4, 4, 128, 40, True, False, True),
                                                               (18, 4, 4, 8, 32, False, True, False), (2, 64, 64, 16, 32, True, False, True), (1, 128, 128, 8, 32, False, False, False),
                                                               (3, 32, 8, 24, 64, True, False, True)])
-def test_winograd_v2_forward_prologue_and_statistics(env, B, H, W, cin, cout, bias, relu, affine):
+@pytest.mark.parametrize("wide", [False, True])
+def test_winograd_v2_forward_prologue_and_statistics(env, B, H, W, cin, cout, bias, relu, affine, wide):
     """the raw-tile form: 2-D patch tiles (several small images per tile, ragged last tile), fused input affine + ReLU with zero padding kept
     zero, per-channel statistics of the stored output"""
     L, ops, dev = env
@@ -102,7 +103,11 @@ def test_winograd_v2_forward_prologue_and_statistics(env, B, H, W, cin, cout, bi
     ref = torch.nn.functional.conv2d(xin, w.double(), None if b is None else b.double(), padding=1)
     if relu:
         ref = ref.clamp(min=0)
-    got, st = wino2(L, x.permute(0, 2, 3, 1).contiguous().to(dev), w, b, relu, (sc, sh) if affine else None, relu_in=affine, stats=True)
+    L.call("awr_set_conv_winograd", 4 if wide else 12)       # + 4: the 64-channel tile form whenever N % 64 == 0 (whatever the launch size); + 8: never
+    try:
+        got, st = wino2(L, x.permute(0, 2, 3, 1).contiguous().to(dev), w, b, relu, (sc, sh) if affine else None, relu_in=affine, stats=True)
+    finally:
+        L.call("awr_set_conv_winograd", 0)
     got = got.permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     err = float((got.double() - ref).abs().max()) / float(ref.abs().max())

@@ -50,13 +50,20 @@ def run(name, B, H, cin, cout, err_b=2):
         res[kb] = time_us(lambda: L.call("awr_wino_conv3x3", L.ptr(xin), L.ptr(U), None, L.ptr(out_w), B, H, H, cin, cout, 0, kb, L.stream()))
     pow2 = H & (H - 1) == 0
     if pow2:
+        L.call("awr_set_conv_winograd", 8)           # 32-channel tiles only
         res[2] = time_us(lambda: L.call("awr_wino2_conv3x3", L.ptr(xin), L.ptr(U), None, None, None, 0, L.ptr(out_w), None, 0, B, H, H, cin, cout, 0, L.stream()))
+        if cout % 64 == 0:           # the 64-channel tile form (16 waves, one workgroup per CU)
+            L.call("awr_set_conv_winograd", 0)       # automatic: the 64-channel tile form where it fills the chip
+            res[3] = time_us(lambda: L.call("awr_wino2_conv3x3", L.ptr(xin), L.ptr(U), None, None, None, 0, L.ptr(out_w), None, 0, B, H, H, cin, cout, 0, L.stream()))
+            L.call("awr_set_conv_winograd", 0)
     best = min((k for k in res if k < 1000), key=res.get)
-    if best == 2:
+    if best in (2, 3):
+        L.call("awr_set_conv_winograd", 0 if best == 3 else 8)
         L.call("awr_wino2_conv3x3", L.ptr(xin), L.ptr(U), None, None, None, 0, L.ptr(out_w), None, 0, B, H, H, cin, cout, 0, L.stream())
     else:
         L.call("awr_wino_conv3x3", L.ptr(xin), L.ptr(U), None, L.ptr(out_w), B, H, H, cin, cout, 0, best, L.stream())
     torch.cuda.synchronize()
+    L.call("awr_set_conv_winograd", 0)
     ref = torch.nn.functional.conv2d(x[:err_b].double(), w.double(), padding=1).permute(0, 2, 3, 1)
     scale = float(ref.abs().max())
     e_d = float((out_d[:err_b].cpu().double() - ref).abs().max()) / scale
@@ -64,7 +71,7 @@ def run(name, B, H, cin, cout, err_b=2):
     rms_d = float((out_d[:err_b].cpu().double() - ref).pow(2).mean().sqrt()) / scale
     rms_w = float((out_w[:err_b].cpu().double() - ref).pow(2).mean().sqrt()) / scale
     fl = 2.0 * 9 * cin * cout * B * H * H
-    print("%-28s B=%3d %3dx%-3d %3d->%-3d | direct %7.1f us %6.1f TF | winograd(form %3d; 2 = v2) %7.1f us  %6.1f TF algorithmic  %6.1f TF executed | "
+    print("%-28s B=%3d %3dx%-3d %3d->%-3d | direct %7.1f us %6.1f TF | winograd(form %3d; 2 = v2, 3 = v2 wide) %7.1f us  %6.1f TF algorithmic  %6.1f TF executed | "
           "x%.2f | max err / max|y|: direct %.2e  wino %.2e (x%.1f) | rms: %.2e  %.2e (x%.1f) | all kb: %s" % (
               name, B, H, H, cin, cout, t_direct, fl / t_direct / 1e6, best, res[best], fl / res[best] / 1e6, fl * 16 / 36 / res[best] / 1e6,
               t_direct / res[best], e_d, e_w, e_w / e_d, rms_d, rms_w, rms_w / rms_d, {k: round(v, 1) for k, v in res.items()}), flush=True)
