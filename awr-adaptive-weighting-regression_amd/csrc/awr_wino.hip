@@ -7,11 +7,11 @@
 //   M[pos][patch][n] = sum_c V * U          16 independent GEMMs (one per position) on v_mfma_f32_32x32x2_f32
 //   Y[patch] = A^T M A                      2x2 outputs, after an exchange of the accumulators through LDS
 //
-// Workgroup = 4 waves; tile = 64 patches (256 output pixels) x 32 output channels; wave w owns positions 4w .. 4w+3 (each a 64 x 32
-// accumulator = two 32x32 MFMA tiles: 128 accumulator registers per lane).  K loop over input channels in stages of KB: the transformed
-// window (16 x 64 x KB) and the weight slice (16 x KB x 32) live in one single-buffered LDS stage of 52 KB; the exchange of the epilogue
-// reuses it (64 KB): two workgroups per CU, whose transform / MFMA phases interleave.  Operator level only (tools/microbench_wino.py,
-// tests/test_wino_gpu.py); the go / no-go numbers are in profiles/r06_winograd.txt.
+// Three generations live here (profiles/r06_winograd.txt has the numbers): wino_fwd_kernel (v1: every patch gathers its own 4x4 window from global
+// memory -- kept for the measurements), wino2_fwd_kernel<.., 32> (v2: the RAW input tile of a 2-D block of 64 patches goes through LDS once per K stage;
+// 8 waves x 2 positions, two workgroups per CU) and wino2_fwd_kernel<.., 64> (v2 wide: 64 output channels per workgroup, 16 waves x 1 position, one
+// workgroup per CU -- 174 / 188 algorithmic TFLOP/s on 128 -> 128 @ 64 x 64 / 256 -> 256 @ 16 x 16).  Plans use v2 (awr_wino_conv) for the forward and,
+// with the mirrored transform, for the data gradients of eligible layers (awr_set_conv_winograd); tests/test_wino_gpu.py, tools/microbench_wino.py.
 #include <stdlib.h>
 #include <string.h>
 
