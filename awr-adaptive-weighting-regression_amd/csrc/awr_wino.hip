@@ -490,26 +490,38 @@ __global__ __launch_bounds__(TN == 64 ? 1024 : 512) __attribute__((amdgpu_waves_
             st4(o + a.N, y1);
         }
     }
-    if (a.stats && oitem) {
-        // lanes with the same channel quad (tid & 7) of one wave hold 8 patches: reduce over them, then one atomic per (wave, channel)
+    if (a.stats) {
+        // lanes with the same channel quad (tid & 7) of one wave hold 8 patches: reduce over them in the wave, combine the eight participating waves through
+        // LDS, then ONE fp64 atomic per channel and statistic (the exchange tile is dead: reuse it)
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);      // [wave 0..7][jt][stat][channel 0..31]
+        if (oitem) {
 #pragma unroll
-        for (int jt = 0; jt < NTT; ++jt) {
+            for (int jt = 0; jt < NTT; ++jt) {
 #pragma unroll
-            for (int o = 8; o < 64; o <<= 1)
+                for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ssum[jt][e] += __shfl_xor(ssum[jt][e], o, 64);
-                    ssq[jt][e] += __shfl_xor(ssq[jt][e], o, 64);
-                }
-            if (lane < 8) {
-                const int slot = (tile * 8 + wave) % a.nslots;
-                double* st = a.stats + (int64_t)slot * 2 * a.N + n0 + 32 * jt + 4 * n4;
+                    for (int e = 0; e < 4; ++e) {
+                        ssum[jt][e] += __shfl_xor(ssum[jt][e], o, 64);
+                        ssq[jt][e] += __shfl_xor(ssq[jt][e], o, 64);
+                    }
+                if (lane < 8) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(st + e, ssum[jt][e]);
-                    atomicAdd(st + a.N + e, ssq[jt][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        red[((wave * NTT + jt) * 2 + 0) * 32 + 4 * n4 + e] = ssum[jt][e];
+                        red[((wave * NTT + jt) * 2 + 1) * 32 + 4 * n4 + e] = ssq[jt][e];
+                    }
                 }
             }
+        }
+        __syncthreads();
+        if (tid < NTT * 2 * 32) {
+            const int c = tid & 31, stt = (tid >> 5) & 1, jt = tid >> 6;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[((w * NTT + jt) * 2 + stt) * 32 + c];
+            const int slot = tile % a.nslots;
+            atomicAdd(a.stats + (int64_t)slot * 2 * a.N + (int64_t)stt * a.N + n0 + 32 * jt + c, v);
         }
     }
 }
