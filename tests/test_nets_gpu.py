@@ -536,7 +536,7 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     stem_kink = Y.stem_allowance(ref) if net.startswith("resnet") else 0.0
     pkeys = O.params_of(sd, O.manifest_for(net, J))
     gmax = max(float(ref["grads"][k].norm()) for k in pkeys if ref["grads"][k] is not None)
-    rows = []
+    rows, bad = [], []
     for k in pkeys:
         if ref["grads"][k] is None:
             assert k in m._unused
@@ -547,7 +547,8 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
         e_raw = Y.rel_l2(m.grad_view(k).cpu(), ref["grads"][k], floor)
         rows.append((e_hip / max(e_f32, 1e-7), k, e_hip, e_f32, e_raw))
         allow = 1.5 * stem_kink if k.startswith("pre.") else 0.0
-        assert e_hip <= 3.0 * e_f32 + allow + 2e-5, (k, e_hip, e_f32, stem_kink)
+        if not e_hip <= 3.0 * e_f32 + allow + 2e-5:
+            bad.append((k, e_hip, e_f32, stem_kink))
     ratios = [r[0] for r in rows]
     tagp = "%s/cw%d/grad_vs_fp64/" % (net, int(cw))
     report(tagp + "median_ratio_hip_over_fp32_oracle", float(np.median(ratios)))
@@ -561,6 +562,7 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
           (float(np.median(ratios)), max(r[2] for r in rows), max(r[4] for r in rows), max(r[3] for r in rows), rep))
     for r in sorted(rows, reverse=True)[:4]:
         print("  %6.2f  %-40s hip %.2e  fp32 oracle %.2e  (raw %.2e)" % r)
+    assert not bad, bad[:8]
 
 
 def test_dropin_loop_sees_every_optimizer_step(amd, dev):

@@ -196,7 +196,10 @@ def decisions_from_plan(ref64, plan_tensors):
             on = ent[0] > 0
         else:                                  # lazy: value * scale + shift (what the consumers' loaders compute)
             val, _, sc, sh, _relu = ent
-            on = torch.addcmul(sh, val, sc) > 0
+            # the kernels' masks are ONE fused multiply-add (`y * scale + shift > 0`, contracted): its sign is the sign of the exact
+            # value, which float64 holds (24 + 24 product bits); torch.addcmul rounds the product first and differs on elements
+            # within an ulp of the kink (seen once the Winograd mode perturbed the forward by 2e-7)
+            on = (val.double() * sc.double() + sh.double()) > 0
         on = on.permute(0, 3, 1, 2).cpu()
         m = on != (x64 > 0)
         flips[tag] = m
