@@ -44,15 +44,15 @@ def set_gemm_accum(mode):
 
 
 def set_conv_winograd(on):
-    """Process-wide: plans built afterwards run the FORWARD of every eligible stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the FP32 matrix
-    pipe (include/awr_hip.h: awr_set_conv_winograd; csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-0.6x the direct kernel's rounding error,
-    not bit-compatible with it."""
+    """Process-wide: plans built afterwards run the FORWARD (True / "forward") or the forward, the data gradient and the weight gradient ("full") of
+    every eligible stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the FP32 matrix pipe (include/awr_hip.h: awr_set_conv_winograd;
+    csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-1.2x the direct kernels' rounding error, not bit-compatible with them."""
     from . import _lib as L
     L.call("awr_set_conv_winograd", _winograd_code(on))
 
 
 def _winograd_code(on):
-    """False / None -> 0, True / "forward" -> 1 (forward launches), "full" -> 2 (forward + data gradients), "force" -> 6 (tests: "full" on every layer the
+    """False / None -> 0, True / "forward" -> 1 (forward launches), "full" -> 2 (forward + data gradients + weight gradients), "force" -> 6 (tests: "full" on every layer the
     kernel can run, whatever the launch size)"""
     return {"forward": 1, "full": 2, "force": 6}.get(on, 1 if on else 0) if not isinstance(on, int) or isinstance(on, bool) else int(on)
 

@@ -212,6 +212,9 @@ _SIGS = {
     "awr_set_conv_winograd": ([_I], C.c_int),
     "awr_get_conv_winograd": ([], C.c_int),
     "awr_wino_eligible": ([_I, _I, _I, _I, _I], C.c_int),
+    "awr_wino_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P], C.c_int),
+    "awr_wino_wgrad_scratch": ([_I, _I, _I, _I, _I], C.c_int64),
+    "awr_wino_wgrad_eligible": ([_I, _I, _I, _I, _I], C.c_int),
     "awr_plan_winograd": ([_P, C.POINTER(_I), C.POINTER(_D)], C.c_int),
     # NYU data path (csrc/awr_nyu.hip)
     "awr_nyu_crop": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P], C.c_int),

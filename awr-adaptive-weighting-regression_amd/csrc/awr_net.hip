@@ -675,7 +675,7 @@ struct awr_plan {
     std::vector<Op> fwd, bwd, pack_ops;
     std::vector<std::function<int()>> nodes;       // backward emitters, in forward order
     std::vector<ConvLayer*> layers;                // layers whose packed copies this plan refreshes
-    int n_wino = 0;      // forward launches that run as Winograd F(2x2, 3x3)
+    int n_wino = 0;      // forward (and weight-gradient) launches that run as Winograd F(2x2, 3x3)
     std::vector<std::pair<ConvLayer*, float*>> wino_d;      // (layer, mirrored U[16][cout_pad][cin_pad])
     std::vector<std::pair<const awr_conv_args*, double>> wino_dg;      // candidate data-gradient launches (argument block, MACs): Winograd if the COMPLETED block is supported
     double wino_macs = 0;            // algorithmic multiply-adds of those launches (they execute 16 / 36 of them)
@@ -1158,7 +1158,21 @@ struct Builder {
             aop.side_ok = (res == nullptr);
             aop.pair_next = true;
         }
-        Op& wop = b(wname, [wa](void* s) { return awr_conv_wgrad(wa, s); });      // (reference into the op vector: do not use after the next push)
+        // Winograd-domain weight gradient (winograd = "full"; csrc/awr_wino.hip): stride-1 3x3 layers with channel counts in multiples of 64 whose K loop
+        // is long enough to pay for the per-split copies; writes the same packed R (and slot 0 of the bias column sums) the direct kernel accumulates into
+        const bool wino_w = (awr_get_conv_winograd() & 3) == 2 && !P.det && awr_get_wgrad_products() == 1 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
+                            !spec.deconv && !layer->head && wp.d_is_dy && awr_wino_wgrad_eligible(B, H, W, spec.cin_pad, spec.cout_pad);
+        float* wscratch = nullptr;
+        if (wino_w) {
+            wscratch = alloc<float>(awr_wino_wgrad_scratch(B, H, W, spec.cin_pad, spec.cout_pad));
+            if (err) return err;
+            P.n_wino++;
+            P.wino_macs += layer_macs;
+        }
+        const float *wx = x->buf, *wsc = x->lazy ? x->lz_scale : nullptr, *wsh = x->lazy ? x->lz_shift : nullptr;
+        const int wrelu = x->lazy ? x->lz_relu : 0, wC = spec.cin_pad, wN = spec.cout_pad;
+        Op& wop = wino_w ? b(wname, [=](void* s) { return awr_wino_wgrad(wx, dy, wsc, wsh, wrelu, B, H, W, wC, wN, wscratch, R, ld, bsum, s); })
+                         : b(wname, [wa](void* s) { return awr_conv_wgrad(wa, s); });      // (reference into the op vector: do not use after the next push)
         wop.gemm = true;
         wop.macs = layer_macs;
         // safe to run beside the main chain when dY is written once before this node and nobody touches it again.  With a fused
@@ -1170,7 +1184,7 @@ struct Builder {
         if (!P.det && awr_get_wgrad_products() == 1 && spec.k == 3 && spec.stride == 1 && !spec.deconv && spec.cin == 128 && spec.cout == 128 &&
             H * W >= 4096 && (int64_t)B * H * W >= (1 << 17) && x->lazy)      // (a plain input takes the kernel-row kernel: awr_conv_wgrad's default)
             wa->algo = 2;
-        P.gemms.push_back({nullptr, wa, wname});
+        if (!wino_w) P.gemms.push_back({nullptr, wa, wname});      // (tunable launches: tiles / algorithm of the direct kernel)
         // scattered back to checkpoint layout by a batched launch (end of backward / end of its bucket)
         auto add_job = [&](const float* packed, float* grad, int d0, int d1, int T_, int ld_, int slots, int stride, int64_t numel) {
             awr_unpack_job j;

@@ -526,6 +526,229 @@ __global__ __launch_bounds__(TN == 64 ? 1024 : 512) __attribute__((amdgpu_waves_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd domain:  dg = G^T [ sum_patches (B^T d B) (.) (A dY A^T) ] G   (the transpose of the forward's three steps).
+//   V[pos][patch][c] = B^T d B of the 4x4 input window (the forward's transform), W[pos][patch][n] = A dY A^T of the patch's 2x2 output gradients,
+//   dU[pos][c][n] = sum_patches V * W: 16 GEMMs with K = patches -- 2.25x fewer multiplies than the nine taps of the direct weight gradient.
+// A workgroup owns a 64 x 64 (c, n) tile of ALL 16 positions and a contiguous range of patches (split-K); per stage it takes a 2 x 4 block of patches,
+// every thread transforms one input window (16 loads, 32 adds) and one patch of output gradients (4 loads, 12 adds) straight from global memory (64
+// consecutive channels per wave = 256-byte requests; the window overlap is served by L1 / L2) into a double-buffered pair of LDS operand tiles.  Every split
+// stores its dU tile (no atomics: wino_wgrad_reduce_kernel sums the copies in order, applies G^T . G and writes the packed [N][9][C] gradient the direct
+// kernel would have written); the bias gradient is sum_patches W[1][1].
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct wino_wgrad_args {
+    const float* x;          // (B, H, W, C) NHWC: the convolution's input ...
+    const float* dy;         // (B, H, W, N): ... and the gradient of its output
+    const float* x_scale;    // optional fused affine (+ ReLU) of the input (a BatchNorm that was never materialised); padding stays zero
+    const float* x_shift;
+    float* part;             // [S][16][C][N]
+    float* bpart;            // [S][N] or null
+    int B, H, W, C, N, x_relu;
+    int lg_bpr, lg_bpi;      // log2 of the 2x4 patch blocks per block row / per image
+    int nblocks, S;
+};
+
+constexpr int WG_KT = 8;     // patches per stage
+
+// Eight waves, two positions per wave (eight 32x32 accumulators), two waves per SIMD with 256 registers each.  (A first form -- 16 waves x one position,
+// the transform of a stage in front of its MFMAs, operands requested one stage ahead -- ran at 459 us on 128 -> 128 @ 64 x 64 x 64 where this one takes
+// 4xx: all waves of a SIMD ran their transform phase together, right behind the barrier, with the matrix pipe idle; profiles/r06_winograd.txt.)
+//   - the transform of stage i + 1 is cut into four slices, one behind the eight MFMAs of each k-step of stage i, in program order -- the vector work of a
+//     wave issues while its own MFMAs occupy the matrix pipe;
+//   - two operand register sets: a set is refilled (stage i + 3) as soon as its last slice is consumed, a full stage before its next use.
+// AFF / RELU: the input sits behind a fused per-channel affine / ReLU (compile-time: a runtime flag costs a select per element on top of the operation)
+template <bool AFF, bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void wino_wgrad_kernel(const wino_wgrad_args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Vs = lds;                              // [2][16][8][64]
+    float* const Ws = lds + 2 * 16 * WG_KT * 64;        // [2][16][8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int nct = a.C >> 6, nnt = a.N >> 6;
+    const int split = logical / (nct * nnt), c0 = ((logical / nnt) % nct) << 6, n0 = (logical % nnt) << 6;
+    // whole PAIRS of stages per split (the block count is even: maps of at least 8 x 8): the loop body below is two stages, nothing conditional in it
+    const int npairs = a.nblocks >> 1;
+    const int g_lo = 2 * (int)((int64_t)npairs * split / a.S), g_hi = 2 * (int)((int64_t)npairs * (split + 1) / a.S);
+    const int PH = a.H >> 1;
+    // the patch of a thread is its WAVE's: everything about its position is wave-uniform -- told to the compiler (readfirstlane), the address arithmetic of
+    // the twenty operand requests of a stage runs on the scalar unit and the requests take the (scalar base + lane offset) form
+    const int t = __builtin_amdgcn_readfirstlane(wave), tr = t >> 2, tc = t & 3;
+    float sc = 1.f, sh = 0.f;
+    if (AFF) { sc = a.x_scale[c0 + lane]; sh = a.x_shift[c0 + lane]; }
+
+    struct Regs { float v[16]; float w[4]; unsigned mask; };
+    auto load = [&](int g, Regs& q) {
+        const int b = g >> a.lg_bpi, rem = g & ((1 << a.lg_bpi) - 1), pr = 2 * (rem >> a.lg_bpr) + tr, pc = 4 * (rem & ((1 << a.lg_bpr) - 1)) + tc;
+        // borders: clamp the address (always a valid element), zero the value at transform time -- sixteen unconditional loads, no branches
+        const bool r0 = pr > 0, r3 = pr < PH - 1, q0 = pc > 0, q3 = 2 * pc + 2 < a.W;
+        const int rowoff[4] = {r0 ? -a.W : 0, 0, a.W, r3 ? 2 * a.W : a.W}, coloff[4] = {q0 ? -1 : 0, 0, 1, q3 ? 2 : 1};
+        const float* px = a.x + ((int64_t)(b * a.H + 2 * pr) * a.W + 2 * pc) * a.C + c0;
+        q.mask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (i == 0 ? r0 : i == 3 ? r3 : true) && (j == 0 ? q0 : j == 3 ? q3 : true);
+                q.v[i * 4 + j] = (px + (rowoff[i] + coloff[j]) * a.C)[lane];
+                q.mask |= ok ? 1u << (i * 4 + j) : 0u;
+            }
+        const float* pg = a.dy + ((int64_t)(b * a.H + 2 * pr) * a.W + 2 * pc) * a.N + n0;
+        q.w[0] = pg[lane];
+        q.w[1] = (pg + a.N)[lane];
+        q.w[2] = (pg + a.W * a.N)[lane];
+        q.w[3] = (pg + a.W * a.N + a.N)[lane];
+    };
+    float bsum = 0.f;
+    float d[16], tv[4][4], tw[4][2];
+    auto in_row = [&](const Regs& q, int r) {          // row r of the window: affine, ReLU, zero padding
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = q.v[r * 4 + j];
+            if (AFF) v = v * sc + sh;
+            if (RELU) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));      // (fmaxf costs a canonicalising v_max on top; the value is a finite activation)
+            d[r * 4 + j] = ((q.mask >> (r * 4 + j)) & 1u) ? v : 0.f;
+        }
+    };
+    // slice s of the transform of one stage (s = the row of the 4 x 4 transformed tiles it stores)
+    auto slice = [&](const Regs& q, int buf, int s, bool live = true) {
+        if (s == 0) {
+            in_row(q, 0);
+            in_row(q, 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[0][j] = d[0 + j] - d[8 + j];
+            tw[0][0] = q.w[0];          tw[0][1] = q.w[1];
+            tw[1][0] = q.w[0] + q.w[2]; tw[1][1] = q.w[1] + q.w[3];
+            tw[2][0] = q.w[0] - q.w[2]; tw[2][1] = q.w[1] - q.w[3];
+            tw[3][0] = -q.w[2];         tw[3][1] = -q.w[3];
+            bsum += live ? tw[1][0] + tw[1][1] : 0.f;
+        } else if (s == 1) {
+            in_row(q, 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tv[1][j] = d[4 + j] + d[8 + j];
+                tv[2][j] = d[8 + j] - d[4 + j];
+            }
+        } else if (s == 3) {
+            in_row(q, 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[3][j] = d[4 + j] - d[12 + j];
+        }
+        float* ov = Vs + buf * (16 * WG_KT * 64) + t * 64 + lane;
+        float* ow = Ws + buf * (16 * WG_KT * 64) + t * 64 + lane;
+        ov[(s * 4 + 0) * (WG_KT * 64)] = tv[s][0] - tv[s][2];
+        ov[(s * 4 + 1) * (WG_KT * 64)] = tv[s][1] + tv[s][2];
+        ov[(s * 4 + 2) * (WG_KT * 64)] = tv[s][2] - tv[s][1];
+        ov[(s * 4 + 3) * (WG_KT * 64)] = tv[s][1] - tv[s][3];
+        ow[(s * 4 + 0) * (WG_KT * 64)] = tw[s][0];
+        ow[(s * 4 + 1) * (WG_KT * 64)] = tw[s][0] + tw[s][1];
+        ow[(s * 4 + 2) * (WG_KT * 64)] = tw[s][0] - tw[s][1];
+        ow[(s * 4 + 3) * (WG_KT * 64)] = -tw[s][1];
+    };
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+
+    const int nst = g_hi - g_lo;           // even, >= 2 (the host caps the split count at the number of stage pairs)
+    const int g_last = g_hi - 1;
+    Regs A, B;
+    load(g_lo, A);
+    load(g_lo + 1, B);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) slice(A, 0, s);
+    load(min(g_lo + 2, g_last), A);
+    __syncthreads();
+    // stage i multiplies out of buffer `buf` while the slices of stage i + 1 (operands in q) go into the other one; q is refilled with stage i + 3
+    // (past the end the operand requests are clamped to the last stage and its slices go into the buffer nobody reads any more: the waits the compiler
+    // derives stay "everything but the twenty newest requests" -- with a conditional request in the loop it falls back to vmcnt(0) at every use)
+    auto stage = [&](int i, int buf, Regs& q) {
+#pragma unroll
+        for (int s = 0; s < WG_KT / 2; ++s) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float* va = Vs + (buf * 16 + 2 * wave + p) * (WG_KT * 64) + half * 64 + l31 + s * 128;
+                const float* wb = Ws + (buf * 16 + 2 * wave + p) * (WG_KT * 64) + half * 64 + l31 + s * 128;
+                const float a0 = va[0], a1 = va[32], b0 = wb[0], b1 = wb[32];
+                acc[p][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[p][0][0], 0, 0, 0);
+                acc[p][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[p][0][1], 0, 0, 0);
+                acc[p][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[p][1][0], 0, 0, 0);
+                acc[p][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[p][1][1], 0, 0, 0);
+            }
+            slice(q, buf ^ 1, s, i + 1 < nst);
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler would hoist the NEXT stage's slices up here, and with them the wait for the newest requests)
+        }
+        load(min(g_lo + i + 3, g_last), q);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = 0; i < nst; i += 2) {
+        stage(i, 0, B);
+        stage(i + 1, 1, A);
+    }
+
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float* o = a.part + ((int64_t)(split * 16 + 2 * wave + q) * a.C + c0) * a.N + n0 + l31;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(int64_t)(32 * ci + (r & 3) + 8 * (r >> 2) + 4 * half) * a.N + 32 * ni] = acc[q][ci][ni][r];
+    }
+    if (a.bpart && c0 == 0) {
+        float* red = lds;
+        red[t * 64 + lane] = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += red[k * 64 + tid];
+            a.bpart[(int64_t)split * a.N + n0 + tid] = v;
+        }
+    }
+}
+
+// grid (N / 16, C), 256 threads = 16 positions x 16 output channels: sum the split copies in order, then dg = G^T dU G -> R[n][tap][c] (+ bias gradient)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int S, int C, int N,
+                                                                float* __restrict__ R, int ld, float* __restrict__ bias_out) {
+    __shared__ float dU[16][17];
+    const int tid = threadIdx.x, pos = tid >> 4, ni = tid & 15, c = blockIdx.y, n0 = blockIdx.x * 16;
+    const float* p = part + ((int64_t)pos * C + c) * N + n0 + ni;
+    const int64_t sstride = (int64_t)16 * C * N;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += p[s * sstride];
+    dU[pos][ni] = v;
+    __syncthreads();
+    if (tid < 144) {
+        const int tap = tid >> 4, i = tap / 3, j = tap % 3;
+        // rows of G^T: (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
+        const float gi[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
+        float r = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float rowv = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) rowv += dU[u * 4 + w][ni] * gi[j][w];
+            r += gi[i][u] * rowv;
+        }
+        R[((int64_t)(n0 + ni) * 9 + tap) * ld + c] = r;
+    }
+    if (bias_out && bpart && c == 0 && tid < 16) {
+        float b = 0.f;
+        for (int s = 0; s < S; ++s) b += bpart[(int64_t)s * N + n0 + tid];
+        bias_out[n0 + tid] = b;
+    }
+}
+
 }  // namespace awr
 
 using namespace awr;
@@ -651,6 +874,72 @@ int awr_wino_dgrad_or_direct(const awr_conv_args* d, const float* U, void* strea
     p.nslots = d->stats ? (d->stat_slots > 0 ? d->stat_slots : AWR_STAT_SLOTS) : 0;
     p.B = d->B; p.H = d->Hin; p.W = d->Win; p.C = d->Cin; p.N = d->N;
     return awr_wino_conv(&p, stream);
+}
+
+
+// Weight gradient of a stride-1 3x3 convolution in the Winograd domain (see wino_wgrad_kernel).  R[N][9][ld] (ld >= C) and bias_grad[N] are ASSIGNED.
+// scratch: awr_wino_wgrad_scratch() floats.  Deterministic (ordered sums over the split copies).
+static int wino_wgrad_splits(int B, int H, int W, int C, int N) {
+    // ONE round of workgroups, one per CU (a second round costs a second 256 KB copy per CU and buys nothing: 433 -> 401 us on 128 -> 128 @ 64 x 64 x 64)
+    const int nblocks = B * (H / 4) * (W / 8), tiles = (C / 64) * (N / 64);
+    int S = (256 + tiles - 1) / tiles;
+    if (S > nblocks / 2) S = nblocks / 2;      // every split owns at least one PAIR of stages (the loop body of wino_wgrad_kernel)
+    return S < 1 ? 1 : S;
+}
+
+int awr_wino_wgrad_eligible(int B, int H, int W, int C, int N) {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (C % 64 || N % 64 || !pow2(H) || !pow2(W) || H < 8 || W < 8) return 0;
+    if ((int64_t)B * H * W * (C > N ? C : N) >= (1LL << 31)) return 0;
+    if (g_winograd & 4) return 1;
+    // every split stores a 256 KB copy of its tile (67 MB per launch whatever the layer): it takes a K loop of 8 stages to pay for it when the launch has
+    // four tiles or more, 48 with a single 64 x 64 tile (profiles/r06_winograd.txt: 64 -> 64 @ 32 x 32 x 64 is 0.76x the direct kernel, @ 64 x 64 1.07x)
+    const int tiles = (C / 64) * (N / 64), stages = B * (H / 4) * (W / 8) / wino_wgrad_splits(B, H, W, C, N);
+    return stages >= (tiles >= 4 ? 8 : 48);
+}
+
+int64_t awr_wino_wgrad_scratch(int B, int H, int W, int C, int N) {
+    const int S = wino_wgrad_splits(B, H, W, C, N);
+    return (int64_t)S * 16 * C * N + (int64_t)S * N;
+}
+
+int awr_wino_wgrad(const float* x, const float* dy, const float* x_scale, const float* x_shift, int x_relu, int B, int H, int W, int C, int N,
+                   float* scratch, float* R, int ld, float* bias_grad, void* stream) {
+    AWR_REQUIRE(x && dy && scratch && R, "wino_wgrad: NULL pointer");
+    AWR_REQUIRE((x_scale == nullptr) == (x_shift == nullptr), "wino_wgrad: x_scale / x_shift come together");
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    AWR_REQUIRE(B > 0 && C > 0 && N > 0 && C % 64 == 0 && N % 64 == 0 && pow2(H) && pow2(W) && H >= 8 && W >= 8 && ld >= C,
+                "wino_wgrad: C and N multiples of 64, power-of-two maps of at least 8 x 8 (B=%d H=%d W=%d C=%d N=%d ld=%d)", B, H, W, C, N, ld);
+    AWR_REQUIRE((int64_t)B * H * W * (C > N ? C : N) < (1LL << 31), "wino_wgrad: tensors of fewer than 2^31 elements (32-bit offsets)");
+    wino_wgrad_args a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.dy = dy; a.x_scale = x_scale; a.x_shift = x_shift; a.x_relu = x_relu;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N;
+    a.S = wino_wgrad_splits(B, H, W, C, N);
+    a.nblocks = B * (H / 4) * (W / 8);
+    a.lg_bpr = __builtin_ctz(W / 8);
+    a.lg_bpi = __builtin_ctz((H / 4) * (W / 8));
+    a.part = scratch;
+    a.bpart = bias_grad ? scratch + (int64_t)a.S * 16 * C * N : nullptr;
+    const size_t lds = (size_t)4 * 16 * WG_KT * 64 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino_wgrad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino_wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino_wgrad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) { set_error("wino_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AWR_ERR_HIP; }
+        attr_done = true;
+    }
+    const dim3 grid(a.S * (C / 64) * (N / 64));
+    if (x_scale && x_relu) hipLaunchKernelGGL((wino_wgrad_kernel<true, true>), grid, dim3(512), lds, as_stream(stream), a);
+    else if (x_scale) hipLaunchKernelGGL((wino_wgrad_kernel<true, false>), grid, dim3(512), lds, as_stream(stream), a);
+    else if (x_relu) hipLaunchKernelGGL((wino_wgrad_kernel<false, true>), grid, dim3(512), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino_wgrad_kernel<false, false>), grid, dim3(512), lds, as_stream(stream), a);
+    int rc = check_launch("wino_wgrad_kernel");
+    if (rc != AWR_OK) return rc;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(N / 16, C), dim3(256), 0, as_stream(stream), a.part, a.bpart, a.S, C, N, R, ld, bias_grad);
+    return check_launch("wino_wgrad_reduce_kernel");
 }
 
 }  // extern "C"

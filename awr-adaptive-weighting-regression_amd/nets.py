@@ -178,7 +178,7 @@ class AwrBackbone(nn.Module):
                 L.call("awr_set_conv_winograd", was_w)
             nw, wm = L.C.c_int(0), L.C.c_double(0)
             L.call("awr_plan_winograd", plan.h, L.C.byref(nw), L.C.byref(wm))
-            plan.n_winograd, plan.winograd_macs = nw.value, wm.value       # forward launches that run as Winograd F(2x2, 3x3); their algorithmic MACs
+            plan.n_winograd, plan.winograd_macs = nw.value, wm.value       # launches that run as Winograd F(2x2, 3x3) (forward, data / weight gradients); their algorithmic MACs
             plan.accum = acc          # 0 = ordered, 1 = blocked, 2 = auto (blocked per launch by K extent): what the plan's GEMM launches captured
             self._plans[key] = plan
         return plan

@@ -68,8 +68,8 @@ class TrainEngine:
         forward / data-gradient GEMMs of this engine's plan.  "blocked" is the parity mode (a conv's rounding error at torch-CPU's level, a few %
         slower); "auto" blocks only the launches with a long K extent (include/awr_hip.h: awr_set_gemm_accum), where an ordered chain's error
         is largest and blocking is cheapest; "ordered" is one chain per output element everywhere.
-        winograd: None (the process-wide mode, awr_amd.set_conv_winograd) | True | False -- Winograd F(2x2, 3x3) forward of the eligible stride-1
-        3x3 convolutions (include/awr_hip.h)."""
+        winograd: None (the process-wide mode, awr_amd.set_conv_winograd) | False | True ("forward") | "full" -- Winograd F(2x2, 3x3) forward, or forward +
+        data gradient + weight gradient, of the eligible stride-1 3x3 convolutions (include/awr_hip.h)."""
         if not next(net.parameters()).is_cuda:
             raise L.AwrError("TrainEngine needs the network on the GPU")
         self.net, self.B, self.H = net, batch_size, img_size

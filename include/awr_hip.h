@@ -587,11 +587,11 @@ int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
  * rounding differs -- measured 0.3-0.6x the direct kernel's error against float64 (chains of Cin terms instead of 9 Cin).
  * awr_wino_conv3x3 is the first form (windows gathered from global memory; kb = channels per stage, + 100 = 256-thread workgroups), kept for the
  * measurements in profiles/r06_winograd.txt.
- * Plans: awr_set_conv_winograd(1 | 2) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0; 2 = also the data gradients, + 4 =
- * ignore the launch-size rule: tests, + 8 = never the 64-channel tile form: A/B) makes plan builders run the FORWARD
+ * Plans: awr_set_conv_winograd(1 | 2) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0; 2 = also the data and weight
+ * gradients, + 4 = ignore the launch-size rules: tests, + 8 = never the 64-channel tile form: A/B) makes plan builders run the FORWARD
  * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
- * awr_wino2_conv3x3, and the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
- * awr_wino_dgrad_or_direct; weight gradients stay direct.
+ * awr_wino2_conv3x3, the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
+ * awr_wino_dgrad_or_direct, and the WEIGHT GRADIENT of the layers awr_wino_wgrad_eligible names through awr_wino_wgrad (below).
  * -----------------------------------------------------------------------------------------*/
 int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirror, float* U, void* stream);
 int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream);
@@ -615,6 +615,16 @@ int awr_wino_dgrad_supported(const awr_conv_args* d);
 int awr_set_conv_winograd(int on);
 int awr_get_conv_winograd(void);
 int awr_wino_eligible(int B, int H, int W, int C, int N);
+/* Weight gradient of a stride-1 3x3 convolution in the Winograd domain: dg = G^T [sum_patches (B^T d B) (.) (A dY A^T)] G -- 16 GEMMs over the patches,
+ * 2.25x fewer multiplies than the nine taps of awr_conv_wgrad.  x (B,H,W,C) is the convolution's input (optionally behind a fused per-channel affine
+ * + ReLU: a BatchNorm output that was never written), dy (B,H,W,N) the gradient of its output.  ASSIGNS R[N][9][ld] (the packed layout awr_conv_wgrad
+ * accumulates into for D = dY, G = X; ld >= C) and, if not NULL, bias_grad[N] = sum of dy over the pixels.  `scratch`: awr_wino_wgrad_scratch(...)
+ * floats (one copy of the transformed-domain tile per K split; summed in a fixed order: deterministic).  C, N multiples of 64, power-of-two maps >= 8 x 8.
+ * awr_wino_wgrad_eligible: 1 where a plan should use it (every split keeps a long enough K loop to pay for the copy it stores). */
+int awr_wino_wgrad(const float* x, const float* dy, const float* x_scale, const float* x_shift, int x_relu, int B, int H, int W, int C, int N,
+                   float* scratch, float* R, int ld, float* bias_grad, void* stream);
+int64_t awr_wino_wgrad_scratch(int B, int H, int W, int C, int N);
+int awr_wino_wgrad_eligible(int B, int H, int W, int C, int N);
 
 /* ------------------------------------------------------------------------------------------
  * NYU data path on the device (csrc/awr_nyu.hip).  Replaces the IMAGE work of the reference's per-sample loader --

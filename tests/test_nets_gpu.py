@@ -1039,6 +1039,16 @@ def test_winograd_forward_mode_meets_the_same_golden_bars(amd, dev, golden_dir, 
     assert 0 < nf < nfull, (nf, nfull)
 
 
+def test_winograd_full_mode_gradients_elementwise(amd, dev):
+    """"force" = forward, data gradients AND weight gradients (awr_wino_wgrad: the Winograd-domain weight gradient) of every stride-1 3x3 layer the kernels
+    can run, whatever the launch size: whole gradient tensors against float64 with the plan's own ReLU decisions, same bar as the direct mode."""
+    amd.set_conv_winograd("force")
+    try:
+        test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, "hourglass_1", 1.0)
+    finally:
+        amd.set_conv_winograd(False)
+
+
 def test_train_and_test_entry_points(dev, tmp_path):
     """`python train.py` / `python test.py` (reference train.py:231-236, test.py:113-116) as subprocesses on a synthetic
     dataset: one epoch, checkpoint written, test.py reloads it and writes the results file."""

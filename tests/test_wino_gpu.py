@@ -173,3 +173,50 @@ def test_winograd_data_gradient_epilogues(env, use_res, use_bnr, use_act):
     assert L.lib.awr_wino_dgrad_supported(C.byref(d)) == 1
     d.relu_out = 1
     assert L.lib.awr_wino_dgrad_supported(C.byref(d)) == 0
+
+
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,affine,relu_in,bias", [(2, 16, 16, 64, 64, False, False, True), (3, 8, 8, 128, 64, True, True, True),
+                                                                (1, 32, 16, 64, 128, True, False, False), (5, 8, 16, 64, 64, False, True, True),
+                                                                (4, 32, 32, 128, 128, True, True, True)])
+def test_winograd_weight_gradient_matches_float64(env, B, H, W, cin, cout, affine, relu_in, bias):
+    """awr_wino_wgrad: dg = G^T [sum_patches (B^T d B)(.)(A dY A^T)] G against autograd in float64 -- with the fused input affine / ReLU (padding
+    stays zero), the bias gradient, split-K ranges that do not divide the patch blocks evenly (B = 3, 5), packed rows longer than C (ld)"""
+    L, ops, dev = env
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + cin)
+    x = torch.randn(B, cin, H, W, generator=g)
+    dy = torch.randn(B, cout, H, W, generator=g)
+    sc = (torch.rand(cin, generator=g) + 0.5) if affine else None
+    sh = (torch.randn(cin, generator=g) * 0.3) if affine else None
+    a = x.double()
+    if affine:
+        a = a * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if relu_in:
+        a = a.clamp(min=0)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (gw,) = torch.autograd.grad((torch.nn.functional.conv2d(a, w, padding=1) * dy.double()).sum(), w)
+    gb = dy.double().sum(dim=(0, 2, 3))
+    assert L.lib.awr_wino_wgrad_eligible(B, H, W, cin, cout) in (0, 1)
+    n = int(L.lib.awr_wino_wgrad_scratch(B, H, W, cin, cout))
+    scratch = torch.full((n,), float("nan"), device=dev)
+    ld = cin + 64
+    R = torch.full((cout, 9, ld), float("nan"), device=dev)
+    bg = torch.full((cout,), float("nan"), device=dev) if bias else None
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().to(dev), dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    scd, shd = (sc.to(dev), sh.to(dev)) if affine else (None, None)
+    L.call("awr_wino_wgrad", L.ptr(xd), L.ptr(dyd), L.ptr(scd), L.ptr(shd), int(relu_in), B, H, W, cin, cout, L.ptr(scratch), L.ptr(R), ld, L.ptr(bg), L.stream())
+    torch.cuda.synchronize()
+    got = R[:, :, :cin].cpu().permute(0, 2, 1).reshape(cout, cin, 3, 3)
+    assert torch.isfinite(got).all()
+    assert torch.isnan(R[:, :, cin:]).all()                 # nothing beyond the C columns of a packed row is touched
+    err = float((got.double() - gw).abs().max()) / float(gw.abs().max())
+    assert err < 2e-5, err
+    if bias:
+        eb = float((bg.cpu().double() - gb).abs().max()) / float(gb.abs().max())
+        assert eb < 2e-5, eb
+    # twice the same launch: bit-identical (ordered sums over the split copies, no atomics)
+    R2 = torch.empty_like(R)
+    L.call("awr_wino_wgrad", L.ptr(xd), L.ptr(dyd), L.ptr(scd), L.ptr(shd), int(relu_in), B, H, W, cin, cout, L.ptr(scratch), L.ptr(R2), ld, L.ptr(bg), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(R2[:, :, :cin], R[:, :, :cin])
