@@ -52,9 +52,9 @@ def set_conv_winograd(on):
 
 
 def _winograd_code(on):
-    """False / None -> 0, True / "forward" -> 1 (forward launches), "full" -> 2 (forward + data gradients + weight gradients), "force" -> 6 (tests: "full" on every layer the
+    """False / None -> 0, True / "forward" -> 1 (forward launches), "full" -> 2 (forward + data gradients + weight gradients), "forward+wgrad" -> 3 (the data gradients stay direct), "force" -> 6 (tests: "full" on every layer the
     kernel can run, whatever the launch size)"""
-    return {"forward": 1, "full": 2, "force": 6}.get(on, 1 if on else 0) if not isinstance(on, int) or isinstance(on, bool) else int(on)
+    return {"forward": 1, "full": 2, "forward+wgrad": 3, "force": 6}.get(on, 1 if on else 0) if not isinstance(on, int) or isinstance(on, bool) else int(on)
 
 
 def get_conv_winograd():

@@ -1160,7 +1160,7 @@ struct Builder {
         }
         // Winograd-domain weight gradient (winograd = "full"; csrc/awr_wino.hip): stride-1 3x3 layers with channel counts in multiples of 64 whose K loop
         // is long enough to pay for the per-split copies; writes the same packed R (and slot 0 of the bias column sums) the direct kernel accumulates into
-        const bool wino_w = (awr_get_conv_winograd() & 3) == 2 && !P.det && awr_get_wgrad_products() == 1 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
+        const bool wino_w = (awr_get_conv_winograd() & 3) >= 2 && !P.det && awr_get_wgrad_products() == 1 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
                             !spec.deconv && !layer->head && wp.d_is_dy && awr_wino_wgrad_eligible(B, H, W, spec.cin_pad, spec.cout_pad);
         float* wscratch = nullptr;
         if (wino_w) {

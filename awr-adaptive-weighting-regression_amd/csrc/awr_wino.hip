@@ -765,8 +765,9 @@ int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirro
 static int g_winograd = []() { const char* e = getenv("AWR_WINOGRAD"); return e ? atoi(e) : 0; }();
 
 int awr_set_conv_winograd(int on) {
-    AWR_REQUIRE(on >= 0 && (on & 3) <= 2 && on < 16, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible), "
-                                                     "2 (forward and data gradient); + 4 (tests: wherever the kernel can run, whatever the launch size); + 8 (A/B: never the 64-channel tile form)");
+    AWR_REQUIRE(on >= 0 && on < 16, "conv_winograd: 0 (direct implicit GEMM everywhere), 1 (Winograd F(2x2, 3x3) forward where it is eligible), 2 (forward, data "
+                                    "and weight gradient), 3 (forward and weight gradient); + 4 (tests: wherever the kernels can run, whatever the launch size); "
+                                    "+ 8 (A/B: never the 64-channel tile form)");
     g_winograd = on;
     return AWR_OK;
 }

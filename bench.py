@@ -767,32 +767,32 @@ def main():
             except Exception as e:          # (the headline has been measured: report, do not lose the line)
                 out["data_path"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and nprod == 1 and not args.no_winograd and not args.deterministic:
-            # Winograd F(2x2, 3x3) forward of the stride-1 3x3 convolutions (awr_amd.set_conv_winograd, opt-in): the headline's step and the Hourglass-1
-            # step, same protocol; joints against the oracle in that mode
+            # Winograd F(2x2, 3x3) modes of the stride-1 3x3 convolutions (awr_amd.set_conv_winograd, opt-in): the headline's step, the Hourglass-1 step and
+            # config 5, same protocol
             eng = None
             torch.cuda.empty_cache()
             try:
                 wm = {"mode": "eligible stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (csrc/awr_wino.hip): 'forward' = their forward "
-                              "launches, 'full' = forward and data gradients (a Winograd data gradient leaves less room for the weight gradients that run beside it: "
-                              "ResNet18 prefers 'forward', the Hourglass 'full'); weight gradients direct; NOT the headline (value above is the direct path)",
-                      "train": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
-                                             "%s train step, batch %d, TrainEngine(winograd=True)" % (args.net, args.batch), winograd=True),
-                      "train_full": measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
-                                                  "%s train step, batch %d, TrainEngine(winograd='full')" % (args.net, args.batch), winograd="full")}
-                for k in ("train", "train_full"):
+                              "launches, 'forward+wgrad' = forward and weight gradients (the Winograd-domain weight gradient awr_wino_wgrad), 'full' = the data gradients "
+                              "too (a Winograd data gradient leaves less room for the weight gradients that run beside it: level with 'forward+wgrad' or a little "
+                              "behind); NOT the headline (value above is the direct path)"}
+                for k, mode in (("train", True), ("train_fw", "forward+wgrad"), ("train_full", "full")):
+                    wm[k] = measure_train(awr_amd, O, args.net, 14, 128, args.batch, ks, dev, args.steps, warm, peak_tf,
+                                          "%s train step, batch %d, TrainEngine(winograd=%r)" % (args.net, args.batch, mode), winograd=mode)
                     wm[k]["vs_headline"] = round(wm[k]["value"] / out["value"], 4)
                 if args.net == "resnet_18" and not args.no_hourglass_train and "hg1_train_b64" in out:
-                    for k, mode in (("hg1_train_b64", True), ("hg1_train_b64_full", "full")):
+                    for k, mode in (("hg1_train_b64_fw", "forward+wgrad"), ("hg1_train_b64_full", "full")):
                         wm[k] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
                                               "hourglass_1 train step, batch 64, TrainEngine(winograd=%r)" % (mode,), winograd=mode)
                         wm[k]["vs_direct"] = round(wm[k]["value"] / out["hg1_train_b64"]["value"], 4)
                     if "config5" in out:
                         try:
-                            wm["config5_full"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,
-                                                               "hourglass_2 256x256 J=21 train step, batch 128/GPU, TrainEngine(winograd='full')", winograd="full")
-                            wm["config5_full"]["vs_direct"] = round(wm["config5_full"]["value"] / out["config5"]["value"], 4)
+                            wm["config5_fw"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,
+                                                             "hourglass_2 256x256 J=21 train step, batch 128/GPU, TrainEngine(winograd='forward+wgrad')",
+                                                             winograd="forward+wgrad")
+                            wm["config5_fw"]["vs_direct"] = round(wm["config5_fw"]["value"] / out["config5"]["value"], 4)
                         except Exception as e:      # (a 152 GB plan: keep the rest of the record if it does not fit)
-                            wm["config5_full"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                            wm["config5_fw"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             except Exception as e:          # (the headline has been measured: report, do not lose the line)
                 wm = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             out["winograd_mode"] = wm

@@ -500,6 +500,9 @@ def test_reference_initialised_weights_meet_north_star(amd, dev, net):
                 (net, mode, s_, float(d.mean()), float(d.max()), gaps[s_])
 
 
+_YARD_CACHE = {}
+
+
 @pytest.mark.parametrize("net,cw", [("resnet_18", 0.0), ("resnet_18", 1.0), ("hourglass_1", 0.0), ("hourglass_1", 1.0), ("resnet_50", 0.0)])
 def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     """Whole gradient tensors (not norms) against float64, tensor by tensor -- with the ReLU decisions of the implementation under
@@ -519,10 +522,12 @@ def test_gradients_elementwise_against_the_fp64_yardstick(amd, dev, net, cw):
     ks = 1.0 if net.startswith("resnet") else 0.4
     img, jt_gt = O.synth_batch(B, 128, J, seed=23)
     sd = O.reference_init_state(net, J, seed=9)
-    ref = Y.trace(net, sd, img, jt_gt, ks, cw, True)
-    f32 = Y.trace(net, sd, img, jt_gt, ks, cw, False)
-    fl32, pl32 = Y.decisions_from_trace(ref, f32)
-    ref_f32 = Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=fl32, pools=pl32)
+    if (net, cw) not in _YARD_CACHE:      # (the float64 / fp32-oracle traces do not depend on the kernel mode under test: the Winograd wrapper reuses them)
+        ref = Y.trace(net, sd, img, jt_gt, ks, cw, True)
+        f32 = Y.trace(net, sd, img, jt_gt, ks, cw, False)
+        fl32, pl32 = Y.decisions_from_trace(ref, f32)
+        _YARD_CACHE[(net, cw)] = (ref, f32, fl32, pl32, Y.trace(net, sd, img, jt_gt, ks, cw, True, flips=fl32, pools=pl32))
+    ref, f32, fl32, pl32, ref_f32 = _YARD_CACHE[(net, cw)]
     m = make_net(amd, net, J, sd)
     eng = TrainEngine(m, B, 128, ks, coord_weight=cw, dense_weight=1.0, lr=1e-3, autotune=False)
     eng.step(img.to(dev), jt_gt.to(dev))
