@@ -584,21 +584,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
         // borders: clamp the address (always a valid element), zero the value at transform time -- sixteen unconditional loads, no branches
         const bool r0 = pr > 0, r3 = pr < PH - 1, q0 = pc > 0, q3 = 2 * pc + 2 < a.W;
         const int rowoff[4] = {r0 ? -a.W : 0, 0, a.W, r3 ? 2 * a.W : a.W}, coloff[4] = {q0 ? -1 : 0, 0, 1, q3 ? 2 : 1};
+        // four scalar row bases x four per-lane column offsets (sixteen scalar address pairs cost a tenth of the wave's issue slots: the counters said so)
         const float* px = a.x + ((int64_t)(b * a.H + 2 * pr) * a.W + 2 * pc) * a.C + c0;
+        int vcol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vcol[j] = lane + coloff[j] * a.C;
         q.mask = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const float* prow = px + rowoff[i] * a.C;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = (i == 0 ? r0 : i == 3 ? r3 : true) && (j == 0 ? q0 : j == 3 ? q3 : true);
-                q.v[i * 4 + j] = (px + (rowoff[i] + coloff[j]) * a.C)[lane];
+                q.v[i * 4 + j] = prow[vcol[j]];
                 q.mask |= ok ? 1u << (i * 4 + j) : 0u;
             }
+        }
         const float* pg = a.dy + ((int64_t)(b * a.H + 2 * pr) * a.W + 2 * pc) * a.N + n0;
+        const float* pg1 = pg + a.W * a.N;
         q.w[0] = pg[lane];
-        q.w[1] = (pg + a.N)[lane];
-        q.w[2] = (pg + a.W * a.N)[lane];
-        q.w[3] = (pg + a.W * a.N + a.N)[lane];
+        q.w[1] = pg[lane + a.N];
+        q.w[2] = pg1[lane];
+        q.w[3] = pg1[lane + a.N];
     };
     float bsum = 0.f;
     float d[16], tv[4][4], tw[4][2];
@@ -670,13 +677,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
     // (past the end the operand requests are clamped to the last stage and its slices go into the buffer nobody reads any more: the waits the compiler
     // derives stay "everything but the twenty newest requests" -- with a conditional request in the loop it falls back to vmcnt(0) at every use)
     auto stage = [&](int i, int buf, Regs& q) {
-#pragma unroll
-        for (int s = 0; s < WG_KT / 2; ++s) {
+        // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s (two register sets): with the schedule pinned per k-step, reading
+        // them where they are used puts an LDS round trip in front of every group of eight MFMAs
+        float fa[2][2][2], fb[2][2][2];
+        auto frags = [&](int s, int par) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const float* va = Vs + (buf * 16 + 2 * wave + p) * (WG_KT * 64) + half * 64 + l31 + s * 128;
                 const float* wb = Ws + (buf * 16 + 2 * wave + p) * (WG_KT * 64) + half * 64 + l31 + s * 128;
-                const float a0 = va[0], a1 = va[32], b0 = wb[0], b1 = wb[32];
+                fa[par][p][0] = va[0]; fa[par][p][1] = va[32];
+                fb[par][p][0] = wb[0]; fb[par][p][1] = wb[32];
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < WG_KT / 2; ++s) {
+            if (s + 1 < WG_KT / 2) frags(s + 1, (s + 1) & 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float a0 = fa[s & 1][p][0], a1 = fa[s & 1][p][1], b0 = fb[s & 1][p][0], b1 = fb[s & 1][p][1];
                 acc[p][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[p][0][0], 0, 0, 0);
                 acc[p][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[p][0][1], 0, 0, 0);
                 acc[p][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[p][1][0], 0, 0, 0);
