@@ -913,9 +913,10 @@ int awr_wino_wgrad_eligible(int B, int H, int W, int C, int N) {
     if ((int64_t)B * H * W * (C > N ? C : N) >= (1LL << 31)) return 0;
     if (g_winograd & 4) return 1;
     // every split stores a 256 KB copy of its tile (67 MB per launch whatever the layer): it takes a K loop of 8 stages to pay for it when the launch has
-    // four tiles or more, 48 with a single 64 x 64 tile (profiles/r06_winograd.txt: 64 -> 64 @ 32 x 32 x 64 is 0.76x the direct kernel, @ 64 x 64 1.07x)
+    // four tiles or more, 32 with a single 64 x 64 tile (profiles/r06_winograd.txt: 64 -> 64 @ 32 x 32 x 64, 8 stages, is 0.77x the direct kernel; @ 64 x 64,
+    // 32 stages, 1.10x; @ 128 x 128 x 32, 64 stages, 1.30x)
     const int tiles = (C / 64) * (N / 64), stages = B * (H / 4) * (W / 8) / wino_wgrad_splits(B, H, W, C, N);
-    return stages >= (tiles >= 4 ? 8 : 48);
+    return stages >= (tiles >= 4 ? 8 : 32);
 }
 
 int64_t awr_wino_wgrad_scratch(int B, int H, int W, int C, int N) {
