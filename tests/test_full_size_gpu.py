@@ -32,17 +32,21 @@ def _net(amd, name, J, sd):
 _ORACLE_STEP = {}       # the oracle's batch-64 step is a dozen seconds of host time: computed once per session, shared by the modes
 
 
-@pytest.mark.parametrize("winograd", [False, True])
+@pytest.mark.parametrize("winograd", [False, True, "full"])
 def test_config2_resnet18_train_step_batch64_vs_oracle(amd, dev, winograd):
     """BASELINE configs[1] (the headline shape): one fused train step at batch 64 -- loss, joints, BatchNorm running statistics and
-    the parameters after Adam -- against the oracle's step on the same 64 images; direct forward and Winograd F(2x2, 3x3) forward."""
+    the parameters after Adam -- against the oracle's step on the same 64 images; direct, Winograd F(2x2, 3x3) forward, and the full Winograd mode
+    (forward, data gradients and the Winograd-domain weight gradients of the layers the launch-size rules pick at this batch: the parameters after
+    Adam are the check on those)."""
     from awr_amd.trainer import TrainEngine
     J, B, ks = 14, 64, 1.0
     img, jt_gt = O.synth_batch(B, 128, J, seed=301)
     sd = O.reference_init_state("resnet_18", J, seed=3)
     m = _net(amd, "resnet_18", J, sd)
     eng = TrainEngine(m, B, 128, ks, coord_weight=0.0, dense_weight=1.0, lr=1e-3, winograd=winograd)
-    assert (eng.plan.n_winograd >= 4) == winograd, eng.plan.n_winograd
+    assert (eng.plan.n_winograd >= 4) == bool(winograd), eng.plan.n_winograd
+    if winograd == "full":      # more launches than the forward form's: data gradients and weight gradients
+        assert eng.plan.n_winograd >= 20, eng.plan.n_winograd
     losses, jt = eng.step(img.to(dev), jt_gt.to(dev))
     if "c2" not in _ORACLE_STEP:
         sdo, ost = {k: v.clone() for k, v in sd.items()}, {"step": 0, "m": {}, "v": {}}

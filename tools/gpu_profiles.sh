@@ -11,6 +11,9 @@ python bench.py --steps 20 --warmup 5 --no-split-mode > $OUT/bench_$TAG.json 2> 
 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --per-layer $OUT/per_layer_${TAG}_f32.txt > /dev/null 2>> $OUT/bench_$TAG.err
 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_${TAG}_hg1_train.txt > /dev/null 2>> $OUT/bench_$TAG.err
 python bench.py --mode infer --net hourglass_1 --batch 128 --steps 10 --warmup 3 $COMMON --per-layer $OUT/per_layer_${TAG}_hg1_infer_b128.txt > /dev/null 2>> $OUT/bench_$TAG.err
+# the opt-in Winograd mode "forward+wgrad" (AWR_WINOGRAD=3), serial replay per launch + its kernel statistics
+AWR_WINOGRAD=3 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --per-layer $OUT/per_layer_${TAG}_f32_winograd.txt > /dev/null 2>> $OUT/bench_$TAG.err
+AWR_WINOGRAD=3 python bench.py --steps 5 --warmup 2 $COMMON --wgrad-streams 0 --net hourglass_1 --per-layer $OUT/per_layer_${TAG}_hg1_train_winograd.txt > /dev/null 2>> $OUT/bench_$TAG.err
 prof() {  # name, command...
   local name=$1; shift
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$name -o trace -- "$@" > $OUT/prof_${TAG}_$name.log 2>&1 )
@@ -22,6 +25,8 @@ prof train_serial python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON 
 prof infer_r18_b128 python $GRAFT_REPO_ROOT/bench.py --mode infer --batch 128 --steps 10 --warmup 3
 prof infer_hg1_b128 python $GRAFT_REPO_ROOT/bench.py --mode infer --batch 128 --steps 10 --warmup 3 --net hourglass_1
 prof train_hg1 python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON --net hourglass_1
+AWR_WINOGRAD=3 prof train_hg1_winograd python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON --net hourglass_1
+AWR_WINOGRAD=3 prof train_winograd python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON
 cd /tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 $COMMON --wgrad-streams 0"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_$TAG -o pmc -- $CMD > $OUT/pmc_sq_$TAG.log 2>&1
