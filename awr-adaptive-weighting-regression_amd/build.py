@@ -77,8 +77,12 @@ def build_lib(force=False, verbose=True, study=None):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         deps = [path] + headers + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
         if force or _stale(obj, deps):
+            # --offload-compress: the gfx950 code objects travel compressed inside the fat binary (the ~420 live instantiations of the LDS-DMA GEMM are
+            # 10.5 MB of machine code uncompressed, 2 MB compressed; the HIP runtime inflates a translation unit's bundle when it loads it).
+            # AWR_BUILD_NO_COMPRESS=1 builds without it.
+            comp = [] if os.environ.get("AWR_BUILD_NO_COMPRESS") == "1" else ["--offload-compress"]
             jobs.append([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                         "-munsafe-fp-atomics", "-c", path, "-o", obj] + extra + (["-DAWR_STUDY"] if study else []))
+                         "-munsafe-fp-atomics", "-c", path, "-o", obj] + comp + extra + (["-DAWR_STUDY"] if study else []))
         objs.append(obj)
     if jobs:            # translation units are independent: compile them side by side (the GEMM files dominate the wall time)
         from concurrent.futures import ThreadPoolExecutor

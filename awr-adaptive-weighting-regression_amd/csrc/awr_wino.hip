@@ -736,18 +736,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 }
 
-// grid (N / 16, C), 256 threads = 16 positions x 16 output channels: sum the split copies in order, then dg = G^T dU G -> R[n][tap][c] (+ bias gradient)
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int S, int C, int N,
-                                                                float* __restrict__ R, int ld, float* __restrict__ bias_out) {
+// grid (N / 16, C), 1024 threads = 4 split groups x 16 positions x 16 output channels: sum the split copies (a fixed order: eight independent partial
+// sums per group -- the requests of a thread overlap instead of queueing behind one another -- then the groups in order), dg = G^T dU G -> R[n][tap][c]
+// (+ bias gradient).  (First form: 256 threads, one serial chain over all copies per thread: 108 us average in the ResNet18 step's trace, as long as the
+// matrix kernel it follows on the single-tile layers with 256 copies.)
+__global__ __launch_bounds__(1024) void wino_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int S, int C, int N,
+                                                                 float* __restrict__ R, int ld, float* __restrict__ bias_out) {
+    __shared__ float grp[4][16][17];
     __shared__ float dU[16][17];
-    const int tid = threadIdx.x, pos = tid >> 4, ni = tid & 15, c = blockIdx.y, n0 = blockIdx.x * 16;
+    const int tid = threadIdx.x & 255, g = threadIdx.x >> 8, pos = tid >> 4, ni = tid & 15, c = blockIdx.y, n0 = blockIdx.x * 16;
     const float* p = part + ((int64_t)pos * C + c) * N + n0 + ni;
     const int64_t sstride = (int64_t)16 * C * N;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += p[s * sstride];
-    dU[pos][ni] = v;
+    const int s_lo = (int)((int64_t)S * g / 4), s_hi = (int)((int64_t)S * (g + 1) / 4);
+    float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sp = s_lo;
+    for (; sp + 8 <= s_hi; sp += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] += p[(sp + u) * sstride];
+    for (int u = 0; sp < s_hi; ++sp, ++u) v8[u] += p[sp * sstride];
+    grp[g][pos][ni] = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
     __syncthreads();
-    if (tid < 144) {
+    if (g == 0) dU[pos][ni] = (grp[0][pos][ni] + grp[1][pos][ni]) + (grp[2][pos][ni] + grp[3][pos][ni]);
+    __syncthreads();
+    if (threadIdx.x < 144) {
         const int tap = tid >> 4, i = tap / 3, j = tap % 3;
         // rows of G^T: (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
         const float gi[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
@@ -761,10 +772,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
         }
         R[((int64_t)(n0 + ni) * 9 + tap) * ld + c] = r;
     }
-    if (bias_out && bpart && c == 0 && tid < 16) {
+    if (bias_out && bpart && c == 0 && threadIdx.x < 16) {
         float b = 0.f;
-        for (int s = 0; s < S; ++s) b += bpart[(int64_t)s * N + n0 + tid];
-        bias_out[n0 + tid] = b;
+        for (int sb = 0; sb < S; ++sb) b += bpart[(int64_t)sb * N + n0 + threadIdx.x];
+        bias_out[n0 + threadIdx.x] = b;
     }
 }
 
@@ -912,11 +923,10 @@ int awr_wino_wgrad_eligible(int B, int H, int W, int C, int N) {
     if (C % 64 || N % 64 || !pow2(H) || !pow2(W) || H < 8 || W < 8) return 0;
     if ((int64_t)B * H * W * (C > N ? C : N) >= (1LL << 31)) return 0;
     if (g_winograd & 4) return 1;
-    // every split stores a 256 KB copy of its tile (67 MB per launch whatever the layer): it takes a K loop of 8 stages to pay for it when the launch has
-    // four tiles or more, 32 with a single 64 x 64 tile (profiles/r06_winograd.txt: 64 -> 64 @ 32 x 32 x 64, 8 stages, is 0.77x the direct kernel; @ 64 x 64,
-    // 32 stages, 1.10x; @ 128 x 128 x 32, 64 stages, 1.30x)
-    const int tiles = (C / 64) * (N / 64), stages = B * (H / 4) * (W / 8) / wino_wgrad_splits(B, H, W, C, N);
-    return stages >= (tiles >= 4 ? 8 : 32);
+    // every split stores a 256 KB copy of its tile (67 MB per launch whatever the layer): it takes a K loop of 8 stages to pay for it
+    // (profiles/r06_winograd.txt: 64 -> 64 @ 32 x 32 x 64 = 8 stages per split: 1.32x the direct kernel; 256 -> 256 @ 8 x 8 x 64: 1.06-1.17x)
+    const int stages = B * (H / 4) * (W / 8) / wino_wgrad_splits(B, H, W, C, N);
+    return stages >= 8;
 }
 
 int64_t awr_wino_wgrad_scratch(int B, int H, int W, int C, int N) {
@@ -959,7 +969,7 @@ int awr_wino_wgrad(const float* x, const float* dy, const float* x_scale, const 
     else hipLaunchKernelGGL((wino_wgrad_kernel<false, false>), grid, dim3(512), lds, as_stream(stream), a);
     int rc = check_launch("wino_wgrad_kernel");
     if (rc != AWR_OK) return rc;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(N / 16, C), dim3(256), 0, as_stream(stream), a.part, a.bpart, a.S, C, N, R, ld, bias_grad);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(N / 16, C), dim3(1024), 0, as_stream(stream), a.part, a.bpart, a.S, C, N, R, ld, bias_grad);
     return check_launch("wino_wgrad_reduce_kernel");
 }
 
