@@ -1022,9 +1022,10 @@ def test_split_operand_mode_meets_the_same_golden_bars(amd, dev, golden_dir, net
 
 @pytest.mark.parametrize("net", ["resnet_18", "hourglass_1"])
 def test_winograd_forward_mode_meets_the_same_golden_bars(amd, dev, golden_dir, net):
-    """awr_amd.set_conv_winograd: the forward of the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/awr_wino.hip) -- fused input BatchNorm +
-    ReLU, bias, BatchNorm statistics from its epilogue; weight / data gradients direct.  Same golden vectors and bars as the direct mode (forward
-    maps, joints, BN running statistics, losses, gradient norms, two Adam steps); "force" = also on the two-image fixtures' small launches."""
+    """awr_amd.set_conv_winograd: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/awr_wino.hip) -- forward with fused input BatchNorm + ReLU,
+    bias, BatchNorm statistics from its epilogue; in the "force" mode used here (= "full" on every layer the kernels can run, whatever the launch size, so
+    that the two-image fixtures exercise them) also the data gradients and the Winograd-domain weight gradients.  Same golden vectors and bars as the direct
+    mode (forward maps, joints, BN running statistics, losses, gradient norms, two Adam steps)."""
     from awr_amd.trainer import TrainEngine
     amd.set_conv_winograd("force")
     try:
