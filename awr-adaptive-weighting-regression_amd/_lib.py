@@ -84,7 +84,8 @@ class WinoArgs(C.Structure):
     """awr_wino_args (include/awr_hip.h)"""
     _fields_ = [("in_", C.c_void_p), ("U", C.c_void_p), ("bias", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("res", C.c_void_p), ("bnr_y", C.c_void_p), ("bnr_coef", C.c_void_p), ("bnr_act", C.c_void_p),
-                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("N", C.c_int), ("relu", C.c_int), ("relu_in", C.c_int), ("nslots", C.c_int)]
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("N", C.c_int), ("relu", C.c_int), ("relu_in", C.c_int), ("nslots", C.c_int),
+                ("out_scale", C.c_void_p), ("out_shift", C.c_void_p)]
 
 
 class NyuSample(C.Structure):

@@ -28,7 +28,7 @@ _MI355X = dict(use_hipgraph=False,    # True: replay each step as one hipGraph (
                                       # nothing measurable from it (1.851e-4 mm from the oracle either way, profiles/r05_parity_report.json) and pay ~3 %
                accum="auto",          # accumulation order of the training GEMMs: "auto" | "ordered" | "blocked" (TrainEngine)
                winograd=None,         # Winograd F(2x2, 3x3) forward of the stride-1 3x3 convolutions: None = the process-wide mode (awr_amd.set_conv_winograd,
-                                      # $AWR_WINOGRAD), False / True (forward) / "full" (forward + data and weight gradients) = this run's own
+                                      # $AWR_WINOGRAD), False / True (forward) / "full" (forward + data and weight gradients) = this run's own (the scoring pass takes the forward form)
                device_loader=True)    # NYU datasets built from this config keep their decoded frames in HBM and crop / augment / normalise on the
                                       # GPU (awr_amd.nyu_device: bit-identical to the host loader nyu_data.NYU, which False selects)
 

@@ -680,6 +680,7 @@ struct awr_plan {
     std::vector<std::pair<const awr_conv_args*, double>> wino_dg;      // candidate data-gradient launches (argument block, MACs): Winograd if the COMPLETED block is supported
     double wino_macs = 0;            // algorithmic multiply-adds of those launches (they execute 16 / 36 of them)
     std::vector<std::pair<ConvLayer*, float*>> wino;      // ... and whose forward runs as Winograd F(2x2, 3x3): (layer, U[16][cin_pad][cout_pad])
+    std::deque<awr_wino_args> wino_args;                  // argument blocks of those forward launches (stable addresses)
     std::vector<DualLayer*> dual_layers;
     std::deque<Tn> tensors;
     std::deque<awr_conv_args> cargs;
@@ -796,6 +797,12 @@ struct Builder {
             return nullptr;
         }
         return P.scratch + off;
+    }
+
+    // the forward of this stride-1 3x3 layer may run as Winograd F(2x2, 3x3) (mode, kernel constraints, launch-size rule)
+    bool wino_fwd_ok(const Spec& spec, int B, int H, int W) const {
+        return awr_get_conv_winograd() && !P.det && awr_get_gemm_products() == 1 && !spec.deconv && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
+               awr_wino_eligible(B, H, W, spec.cin_pad, spec.cout_pad);
     }
 
     Op& push(std::vector<Op>& list, const std::string& name, std::function<int(void*)> fn) {
@@ -916,9 +923,10 @@ struct Builder {
         // Winograd F(2x2, 3x3) forward (round 6, awr_set_conv_winograd; csrc/awr_wino.hip): stride-1 3x3 convolutions whose epilogue is bias /
         // ReLU / statistics.  2.25x fewer multiplies, chains of Cin terms instead of 9 Cin (so no blocked accumulation is needed).  Weight and
         // data gradients stay direct: they only need x and d(y).
-        if (awr_get_conv_winograd() && !P.det && awr_get_gemm_products() == 1 && !spec.deconv && spec.k == 3 && spec.stride == 1 && spec.pad == 1 &&
-            !o.res && !o.out_scale && (o.in_scale == nullptr) == (o.in_shift == nullptr) &&
-            awr_wino_eligible(B, x->H, x->W, spec.cin_pad, spec.cout_pad)) {
+        // Inference plans (round 6, last step): the folded eval-mode BatchNorm (out_scale / out_shift) and the residual add of a BasicBlock are epilogue
+        // forms of the kernel too.
+        if (wino_fwd_ok(spec, B, x->H, x->W) && (!P.training || (!o.res && !o.out_scale)) && !(o.out_scale && o.want_stats) &&
+            (o.in_scale == nullptr) == (o.in_shift == nullptr) && (o.out_scale == nullptr) == (o.out_shift == nullptr)) {
             float* U = nullptr;
             for (auto& wl : P.wino)
                 if (wl.first == layer) U = wl.second;
@@ -926,12 +934,16 @@ struct Builder {
                 U = alloc<float>((int64_t)16 * spec.cin_pad * spec.cout_pad);
                 P.wino.push_back({layer, U});
             }
-            const float *in = x->buf, *isc = o.in_scale, *ish = o.in_shift;
-            float* out = y->buf;
-            double* st = y->stats.p;
-            const int nsl = y->stats.p ? y->stats.nslots : 0, rin = o.relu_in, rout = o.relu_out, H = x->H, W = x->W, C = spec.cin_pad, Nn = spec.cout_pad;
+            P.wino_args.emplace_back();
+            awr_wino_args* wa = &P.wino_args.back();
+            memset(wa, 0, sizeof *wa);
+            wa->in = x->buf; wa->U = U; wa->bias = bias; wa->in_scale = o.in_scale; wa->in_shift = o.in_shift; wa->out = y->buf;
+            wa->stats = y->stats.p; wa->nslots = y->stats.p ? y->stats.nslots : 0;
+            wa->res = o.res ? o.res->buf : nullptr;
+            wa->out_scale = o.out_scale; wa->out_shift = o.out_shift;
+            wa->B = B; wa->H = x->H; wa->W = x->W; wa->C = spec.cin_pad; wa->N = spec.cout_pad; wa->relu = o.relu_out; wa->relu_in = o.relu_in;
             const std::string name = "awr_conv_gemm:" + layer->name;
-            Op& op = f(name, [=](void* s) { return awr_wino2_conv3x3(in, U, bias, isc, ish, rin, out, st, nsl, B, H, W, C, Nn, rout, s); });
+            Op& op = f(name, [wa](void* s) { return awr_wino_conv(wa, s); });
             op.gemm = true;
             op.macs = gemm_macs(prob, B, spec);
             P.n_wino++;
@@ -1897,8 +1909,10 @@ struct NetBuilder {
         Tn* y = b.conv(x, C(p + ".conv1"), o);
         ConvOpt o2;
         o2.out_scale = s3.first; o2.out_shift = s3.second; o2.relu_out = true;
-        // conv2 and conv3 (+ the skip conv, as extra K of the second GEMM) in one launch when the batch fills the chip
-        if (dual) {
+        // conv2 and conv3 (+ the skip conv, as extra K of the second GEMM) in one launch when the batch fills the chip -- unless the Winograd mode takes
+        // conv2 (2.25x fewer multiplies beat the saved round trip of its output: profiles/r06_winograd.txt)
+        if (b.wino_fwd_ok(C(p + ".conv2")->spec, y->B, y->H, y->W)) {
+        } else if (dual) {
             if (Tn* fused = b.conv_pair(y, C(p + ".conv2"), o2, nullptr, nullptr, dual, x)) return fused;
         } else if (!skip) {
             if (Tn* fused = b.conv_pair(y, C(p + ".conv2"), o2, C(p + ".conv3"), x)) return fused;

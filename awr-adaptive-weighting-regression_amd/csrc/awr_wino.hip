@@ -234,6 +234,8 @@ struct wino2_args {
     const float* bias;
     const float* in_scale;   // optional fused input affine (+ ReLU): the previous BatchNorm, applied to valid pixels only (padding stays zero)
     const float* in_shift;
+    const float* out_scale;  // optional per-output-channel affine after the bias (a folded eval-mode BatchNorm): (acc + bias) * scale + shift, then + res, then ReLU
+    const float* out_shift;
     float* out;
     double* stats;           // optional: per-channel sum / sum of squares of the stored output, [nslots][2][N] (awr_bn_finalize's layout)
     // data-gradient epilogue (awr_conv_args.res / bnr_y / bnr_coef / bnr_act of the direct kernel): out = mask(acc + res), stats += (sum g, sum g * xhat)
@@ -437,6 +439,11 @@ __global__ __launch_bounds__(TN == 64 ? 1024 : 512) __attribute__((amdgpu_waves_
             if (a.bias) bs = ld4(a.bias + nq);
             float4 y0 = make_float4(s[0].x + s[1].x + s[2].x + bs.x, s[0].y + s[1].y + s[2].y + bs.y, s[0].z + s[1].z + s[2].z + bs.z, s[0].w + s[1].w + s[2].w + bs.w);
             float4 y1 = make_float4(s[1].x - s[2].x - s[3].x + bs.x, s[1].y - s[2].y - s[3].y + bs.y, s[1].z - s[2].z - s[3].z + bs.z, s[1].w - s[2].w - s[3].w + bs.w);
+            if (a.out_scale) {          // folded eval-mode BatchNorm (inference plans)
+                const float4 osc = ld4(a.out_scale + nq), osh = ld4(a.out_shift + nq);
+                y0 = make_float4(y0.x * osc.x + osh.x, y0.y * osc.y + osh.y, y0.z * osc.z + osh.z, y0.w * osc.w + osh.w);
+                y1 = make_float4(y1.x * osc.x + osh.x, y1.y * osc.y + osh.y, y1.z * osc.z + osh.z, y1.w * osc.w + osh.w);
+            }
             const int64_t ooff = (((int64_t)b * a.H + 2 * (pr0 + pr) + rr) * a.W + 2 * (pc0 + pc)) * a.N + nq;
             if (a.res) {
                 const float4 r0 = ld4(a.res + ooff), r1 = ld4(a.res + ooff + a.N);
@@ -846,7 +853,9 @@ int awr_wino_conv(const awr_wino_args* p, void* stream) {
     const int PH = H / 2, PW = W / 2;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     AWR_REQUIRE(pow2(PH) && pow2(PW), "wino_conv: power-of-two maps only (H=%d, W=%d)", H, W);
-    wino2_args a{p->in, p->U, p->bias, p->in_scale, p->in_shift, p->out, p->stats, p->res, p->bnr_y, p->bnr_coef, p->bnr_act,
+    AWR_REQUIRE((p->out_scale == nullptr) == (p->out_shift == nullptr), "wino_conv: out_scale / out_shift come together");
+    AWR_REQUIRE(!p->out_scale || (!p->stats && !p->bnr_y), "wino_conv: the output affine (folded eval-mode BatchNorm) excludes statistics / the BatchNorm-backward reduction");
+    wino2_args a{p->in, p->U, p->bias, p->in_scale, p->in_shift, p->out_scale, p->out_shift, p->out, p->stats, p->res, p->bnr_y, p->bnr_coef, p->bnr_act,
                  B, H, W, C, N, p->relu, p->relu_in, p->nslots, 0, 0, 0};
     a.PCt = PW < 32 ? PW : 32;
     a.PRt = PH < W_TP / a.PCt ? PH : W_TP / a.PCt;

@@ -405,9 +405,11 @@ TrainEngine.load_optimizer_state_dict = lambda self, sd: _load_opt_into(self, sd
 class InferEngine:
     """test.py:67-86 without the per-sample host loop: img -> dense map -> joints, eval-mode BN."""
 
-    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=False, autotune=True, parity=False):
+    def __init__(self, net, batch_size, img_size, kernel_size, use_graph=False, autotune=True, parity=False, winograd=None):
         """parity=True: blocked accumulation in the GEMMs of this engine's plan (awr_amd.set_gemm_accum) -- scoring passes (test.py:67-86) care
-        about the last digits of the joints, not about the last few per cent of throughput."""
+        about the last digits of the joints, not about the last few per cent of throughput.
+        winograd: None (the process-wide mode, awr_amd.set_conv_winograd) | False | True -- the eligible stride-1 3x3 convolutions of the eval plan as
+        Winograd F(2x2, 3x3) with the folded BatchNorm / residual add in its epilogue (Hourglass: instead of the fused conv2 + conv3 launch)."""
         self.net, self.B, self.H, self.ks = net, batch_size, img_size, float(kernel_size)
         self.parity = bool(parity)
         if self.parity and (int(L.lib.awr_get_gemm_products()) != 1 or int(L.lib.awr_get_gemm_staging()) == 0):
@@ -418,7 +420,7 @@ class InferEngine:
                           "scoring with ordered accumulation" % (L.lib.awr_get_gemm_products(), L.lib.awr_get_gemm_staging()))
             self.parity = False
         net.eval()
-        self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if self.parity else None)
+        self.plan = net.get_plan(batch_size, img_size, False, accum="blocked" if self.parity else None, winograd=winograd)
         if self.plan.n_side == 0:          # forward branches (ResNet downsample projections, Hourglass skip residuals) run beside the main chain
             self.plan.set_streams(4)
         self._autotune, self._compiled = bool(autotune), False
@@ -699,7 +701,7 @@ class Trainer:
         world = torch.distributed.get_world_size(self.pg) if self.pg is not None else 1
         # config.parity_infer = True scores with blocked accumulation (eval-mode plans measure no gain from it: off by default since round 6)
         inf = self._last_infer = InferEngine(self.net, cfg.batch_size, cfg.img_size, cfg.kernel_size, use_graph=False,
-                                             parity=bool(getattr(cfg, "parity_infer", False)))
+                                             parity=bool(getattr(cfg, "parity_infer", False)), winograd=getattr(cfg, "winograd", None))
         ev = self.EvalUtil(self.testData.img_size, self.testData.paras, self.testData.flip, self.testData.jt_num)
         n, bs = len(self.testData), cfg.batch_size
         mine = [b for b in range((n + bs - 1) // bs) if b % world == self.rank]

@@ -257,7 +257,7 @@ def _pool_info(L):
     return k.value
 
 
-def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None, parity=False):
+def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, graph, peak_tf, flop_mult, per_layer="", net=None, parity=False, winograd=None):
     """test.py:67-86 path: eval-mode BatchNorm folded into the GEMM epilogues, img -> dense map -> joints.  Returns images/s, ms per
     batch and the fraction of the MFMA roofline (algorithmic conv FLOPs of the forward / time / peak)."""
     from awr_amd.trainer import InferEngine
@@ -265,7 +265,7 @@ def measure_inference(awr_amd, O, net_name, batch, dev, rank, steps, warmup, gra
     if net is None:
         torch.manual_seed(0)
         net = _make_net(awr_amd, net_name).cuda()
-    inf = InferEngine(net, batch, 128, ks, use_graph=graph, parity=parity)
+    inf = InferEngine(net, batch, 128, ks, use_graph=graph, parity=parity, winograd=winograd)
     imgs, _ = O.synth_batch(batch, 128, 14, seed=1234 + rank)
     imgs = imgs.to(dev)
     for _ in range(warmup):
@@ -785,6 +785,11 @@ def main():
                         wm[k] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
                                               "hourglass_1 train step, batch 64, TrainEngine(winograd=%r)" % (mode,), winograd=mode)
                         wm[k]["vs_direct"] = round(wm[k]["value"] / out["hg1_train_b64"]["value"], 4)
+                    if "config3" in out:      # inference: the folded BatchNorm / residual add in the Winograd epilogue; Hourglass conv2 instead of the fused conv2 + conv3 launch
+                        wm["config3"] = measure_inference(awr_amd, O, "hourglass_1", 128, dev, rank, 20, 5, args.graph, peak_tf, flop_mult, winograd=True)
+                        wm["config3"]["vs_direct"] = round(wm["config3"]["value"] / out["config3"]["value"], 4)
+                        wm["forward_b128"] = measure_inference(awr_amd, O, "resnet_18", 128, dev, rank, 30, 5, args.graph, peak_tf, flop_mult, winograd=True)
+                        wm["forward_b128"]["vs_direct"] = round(wm["forward_b128"]["value"] / out["forward"]["b128"]["value"], 4)
                     if "config5" in out:
                         try:
                             wm["config5_fw"] = measure_train(awr_amd, O, "hourglass_2", 21, 256, 128, 0.4, dev, 5, 3, peak_tf,

@@ -605,6 +605,8 @@ typedef struct awr_wino_args {
     double* stats;
     const float *res, *bnr_y, *bnr_coef, *bnr_act;
     int B, H, W, C, N, relu, relu_in, nslots;
+    const float *out_scale, *out_shift;      /* optional per-output-channel affine after the bias (a folded eval-mode BatchNorm: inference plans):
+                                                out = [relu]((acc + bias) * out_scale + out_shift [+ res]); `res` may then be any (B,H,W,N) tensor */
 } awr_wino_args;
 int awr_wino_conv(const awr_wino_args* a, void* stream);
 /* plans: the data gradient of a stride-1 3x3 convolution described by the DIRECT kernel's argument block `d` -- as Winograd (U = awr_wino_weights(...,

@@ -101,6 +101,12 @@ def test_config3_hourglass1_inference_batch128_vs_oracle_and_slices(amd, dev):
     for lo in (0, 56, 120):
         js = small(img[lo:lo + 8].to(dev)).cpu()
         assert float((js - jt[lo:lo + 8]).norm(dim=-1).max()) * 150.0 <= 1e-3, lo
+    # the same pass with the Winograd mode: conv2 of the full-resolution residuals as Winograd F(2x2, 3x3) (folded BatchNorm + ReLU in its epilogue) instead of
+    # the fused conv2 + conv3 launch -- same bar against the oracle
+    eng_w = InferEngine(m, B, 128, ks, winograd=True)
+    assert eng_w.plan.n_winograd >= 5, eng_w.plan.n_winograd
+    dw = (eng_w(img.to(dev)).cpu() - ref).norm(dim=-1) * 150.0
+    assert float(dw.mean()) <= NORTH_STAR_MEAN_MM and float(dw.max()) <= 5e-3, (float(dw.mean()), float(dw.max()))
 
 
 def test_config1_resnet18_eval_batch4_split_k_path_vs_oracle(amd, dev):
