@@ -46,7 +46,8 @@ def set_gemm_accum(mode):
 def set_conv_winograd(on):
     """Process-wide: plans built afterwards run the FORWARD (True / "forward") or the forward, the data gradient and the weight gradient ("full") of
     every eligible stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the FP32 matrix pipe (include/awr_hip.h: awr_set_conv_winograd;
-    csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-1.2x the direct kernels' rounding error, not bit-compatible with them."""
+    csrc/awr_wino.hip) -- 2.25x fewer multiplies, 0.3-1.4x the direct kernels' rounding error, not bit-compatible with them.  Inference plans (InferEngine)
+    take the forward form in every non-zero mode."""
     from . import _lib as L
     L.call("awr_set_conv_winograd", _winograd_code(on))
 

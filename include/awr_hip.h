@@ -591,7 +591,9 @@ int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
  * gradients, + 4 = ignore the launch-size rules: tests, + 8 = never the 64-channel tile form: A/B) makes plan builders run the FORWARD
  * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
  * awr_wino2_conv3x3, the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
- * awr_wino_dgrad_or_direct, and the WEIGHT GRADIENT of the layers awr_wino_wgrad_eligible names through awr_wino_wgrad (below).
+ * awr_wino_dgrad_or_direct, and the WEIGHT GRADIENT of the layers awr_wino_wgrad_eligible names through awr_wino_wgrad (below).  Inference plans take the
+ * forward form with the folded eval-mode BatchNorm and a residual add in the epilogue (awr_wino_args.out_scale / out_shift / res); a Hourglass residual then runs
+ * conv2 as Winograd followed by the direct conv3 (+ skip) GEMM instead of the fused two-GEMM launch (awr_conv_args.w2).
  * -----------------------------------------------------------------------------------------*/
 int awr_wino_weights(const float* w, int N, int C, int Npad, int Cpad, int mirror, float* U, void* stream);
 int awr_wino_conv3x3(const float* in, const float* U, const float* bias, float* out, int B, int H, int W, int C, int N, int relu, int kb, void* stream);
