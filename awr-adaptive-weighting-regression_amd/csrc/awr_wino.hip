@@ -812,7 +812,7 @@ int awr_set_conv_winograd(int on) {
 int awr_get_conv_winograd(void) { return g_winograd; }
 
 int awr_wino_eligible(int B, int H, int W, int C, int N) {
-    const int minside = (g_winograd & 4) ? 4 : 16;
+    const int minside = (g_winograd & 4) ? 4 : 8;      // (8 x 8 maps: only where the batch still gives 256 workgroups -- ResNet18 layer4 at batch 128 and up)
     if (H < minside || W < minside || (H & (H - 1)) || (W & (W - 1)) || C % 8 || N % 32) return 0;
     if ((int64_t)B * H * W * C >= (1LL << 31)) return 0;
     const int PH = H / 2, PW = W / 2, PCt = PW < 32 ? PW : 32, PRt = PH < W_TP / PCt ? PH : W_TP / PCt, nimg = W_TP / (PRt * PCt);

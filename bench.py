@@ -785,6 +785,11 @@ def main():
                         wm[k] = measure_train(awr_amd, O, "hourglass_1", 14, 128, 64, 0.4, dev, 10, 3, peak_tf,
                                               "hourglass_1 train step, batch 64, TrainEngine(winograd=%r)" % (mode,), winograd=mode)
                         wm[k]["vs_direct"] = round(wm[k]["value"] / out["hg1_train_b64"]["value"], 4)
+                    if args.batch == 64 and not args.no_b256:      # BASELINE configs[3]'s per-GPU shape (layer4's 8 x 8 maps fill the chip from batch 128 on)
+                        wm["b256_full"] = measure_train(awr_amd, O, "resnet_18", 14, 128, 256, 1.0, dev, 8, 3, peak_tf,
+                                                        "resnet_18 train step, batch 256/GPU, TrainEngine(winograd='full')", winograd="full")
+                        if isinstance(out.get("b256"), dict) and out["b256"].get("value"):
+                            wm["b256_full"]["vs_direct"] = round(wm["b256_full"]["value"] / out["b256"]["value"], 4)
                     if "config3" in out:      # inference: the folded BatchNorm / residual add in the Winograd epilogue; Hourglass conv2 instead of the fused conv2 + conv3 launch
                         wm["config3"] = measure_inference(awr_amd, O, "hourglass_1", 128, dev, rank, 20, 5, args.graph, peak_tf, flop_mult, winograd=True)
                         wm["config3"]["vs_direct"] = round(wm["config3"]["value"] / out["config3"]["value"], 4)

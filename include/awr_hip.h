@@ -589,7 +589,7 @@ int awr_plan_set_dp(awr_plan* plan, awr_dp* dp);
  * measurements in profiles/r06_winograd.txt.
  * Plans: awr_set_conv_winograd(1 | 2) (process-wide, captured when a plan is built, default $AWR_WINOGRAD or 0; 2 = also the data and weight
  * gradients, + 4 = ignore the launch-size rules: tests, + 8 = never the 64-channel tile form: A/B) makes plan builders run the FORWARD
- * of every eligible layer (awr_wino_eligible: maps >= 16 x 16, enough workgroups to fill the chip; epilogue = bias / ReLU / statistics) through
+ * of every eligible layer (awr_wino_eligible: maps >= 8 x 8, at least 256 workgroups; epilogue = bias / ReLU / statistics) through
  * awr_wino2_conv3x3, the DATA GRADIENT of those layers (mirrored transform, accumulate / BatchNorm-backward-reduction epilogues) through
  * awr_wino_dgrad_or_direct, and the WEIGHT GRADIENT of the layers awr_wino_wgrad_eligible names through awr_wino_wgrad (below).  Inference plans take the
  * forward form with the folded eval-mode BatchNorm and a residual add in the epilogue (awr_wino_args.out_scale / out_shift / res); a Hourglass residual then runs
