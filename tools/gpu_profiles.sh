@@ -27,6 +27,8 @@ prof infer_hg1_b128 python $GRAFT_REPO_ROOT/bench.py --mode infer --batch 128 --
 prof train_hg1 python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON --net hourglass_1
 AWR_WINOGRAD=3 prof train_hg1_winograd python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON --net hourglass_1
 AWR_WINOGRAD=3 prof train_winograd python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $COMMON
+AWR_WINOGRAD=1 prof infer_r18_b128_winograd python $GRAFT_REPO_ROOT/bench.py --mode infer --batch 128 --steps 10 --warmup 3
+AWR_WINOGRAD=1 prof infer_hg1_b128_winograd python $GRAFT_REPO_ROOT/bench.py --mode infer --batch 128 --steps 10 --warmup 3 --net hourglass_1
 cd /tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 $COMMON --wgrad-streams 0"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_$TAG -o pmc -- $CMD > $OUT/pmc_sq_$TAG.log 2>&1
