@@ -147,3 +147,38 @@ def test_network_level_layout_without_a_gpu(lib):
     assert L.lib.awr_net_create(2, 1, 14, 2, C.byref(C.c_void_p())) == -1 and "kind" in L.last_error()
     assert L.lib.awr_net_create(0, 1, 14, 3, C.byref(C.c_void_p())) == -1
     assert L.lib.awr_net_create(0, 34, 14, 2, C.byref(C.c_void_p())) == -1 and "depth" in L.last_error()      # resnet_deconv.py:9-13 builds 18/50/101/152
+
+
+def test_winograd_entry_points_without_gpu(lib):
+    """Round 6: the Winograd entry points validate their arguments before any HIP call; the launch-size rules (awr_wino_eligible /
+    awr_wino_wgrad_eligible) and the split-copy scratch size are host arithmetic; awr_wino_args carries the inference epilogue fields; the
+    Python mode names map to the C codes."""
+    import ctypes as C
+    import awr_amd
+    L = lib
+    assert C.sizeof(L.WinoArgs) == 11 * 8 + 8 * 4 + 2 * 8 and L.WinoArgs.out_scale.offset == 11 * 8 + 8 * 4
+    # mode codes
+    assert [awr_amd._winograd_code(m) for m in (None, False, True, "forward", "full", "forward+wgrad", "force", 3)] == [0, 0, 1, 1, 2, 3, 6, 3]
+    assert L.lib.awr_set_conv_winograd(-1) == -1 and L.lib.awr_set_conv_winograd(64) == -1
+    was = L.lib.awr_get_conv_winograd()
+    try:
+        assert L.lib.awr_set_conv_winograd(0) == 0
+        # forward / data gradient: power-of-two maps of 8 x 8 and up, C % 8, N % 32, at least 256 workgroups
+        assert L.lib.awr_wino_eligible(64, 64, 64, 128, 128) == 1           # Hourglass 3x3 at full resolution
+        assert L.lib.awr_wino_eligible(64, 8, 8, 512, 512) == 1             # ResNet18 layer4 at batch 64: 16 tiles x 16 channel tiles
+        assert L.lib.awr_wino_eligible(64, 8, 8, 128, 128) == 0             # ... a Hourglass level of that size: 64 workgroups
+        assert L.lib.awr_wino_eligible(64, 4, 4, 512, 512) == 0 and L.lib.awr_wino_eligible(64, 24, 24, 64, 64) == 0 and L.lib.awr_wino_eligible(64, 64, 64, 60, 64) == 0
+        # weight gradient: C and N multiples of 64, at least 8 stages (2 x 4 patch blocks) per split
+        assert L.lib.awr_wino_wgrad_eligible(64, 64, 64, 128, 128) == 1 and L.lib.awr_wino_wgrad_eligible(64, 32, 32, 64, 64) == 1
+        assert L.lib.awr_wino_wgrad_eligible(2, 64, 64, 128, 128) == 0 and L.lib.awr_wino_wgrad_eligible(64, 64, 64, 96, 128) == 0
+        assert L.lib.awr_wino_wgrad_eligible(64, 4, 4, 512, 512) == 0
+        # one 16 x C x N tile copy per split (one split per CU's workgroup: 256 / tiles) + the bias column sums
+        assert int(L.lib.awr_wino_wgrad_scratch(64, 64, 64, 128, 128)) == 64 * 16 * 128 * 128 + 64 * 128
+        assert int(L.lib.awr_wino_wgrad_scratch(64, 8, 8, 512, 512)) == 4 * 16 * 512 * 512 + 4 * 512
+        L.lib.awr_set_conv_winograd(4)                                       # tests' mode: wherever the kernels can run
+        assert L.lib.awr_wino_eligible(2, 4, 4, 8, 32) == 1 and L.lib.awr_wino_wgrad_eligible(2, 8, 8, 64, 64) == 1 and L.lib.awr_wino_wgrad_eligible(2, 8, 8, 32, 64) == 0
+    finally:
+        L.lib.awr_set_conv_winograd(was)
+    assert L.lib.awr_wino_wgrad(None, None, None, None, 0, 1, 8, 8, 64, 64, None, None, 64, None, None) == -1 and "NULL" in L.last_error()
+    assert L.lib.awr_wino_weights(None, 64, 64, 64, 64, 0, None, None) == -1
+    assert L.lib.awr_wino_conv(None, None) == -1
